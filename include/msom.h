@@ -1,0 +1,163 @@
+/*
+ * msom.h -- C ABI of libmsomhip: the MI355X-native multi-layer quasi-geostrophic
+ * timestepper that replaces the PV-advection + streamfunction-inversion hot path of
+ * bderembl/msom (msqg/qg.h, msqg/poisson_layer.h, msqg/layer.h, driver msqg/qg.c).
+ *
+ * Every entry point names the reference interface it replaces (file:line relative to the
+ * reference tree).  Plain pointers and sizes only.  All field arrays are fp64, numpy
+ * C-order [layer][y][x], interior points only (msqg/qg.h:1164-1188); every `double*`
+ * field argument may be a host pointer or a HIP device pointer (the library copies with
+ * hipMemcpyDefault).  The caller owns every buffer it passes.
+ *
+ * Error convention: the reference prints to stdout and calls exit(0) on bad input
+ * (msqg/qg.h:735-738,990-1012).  The library never exits: functions return MSOM_OK (0) or
+ * a negative code and msom_last_error() holds the message.  Multigrid non-convergence is
+ * not an error (reference: stderr warning, mspg/elliptic.h:215-219); it is reported in
+ * msom_mgstats.
+ */
+#ifndef MSOM_H
+#define MSOM_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSOM_OK 0
+#define MSOM_ERR_ARG (-1)      /* bad argument / unknown key / unknown field          */
+#define MSOM_ERR_IO (-2)       /* file not found or short read                         */
+#define MSOM_ERR_CONFIG (-3)   /* dh == 0, Rom <= 0, N not a power of two, nl too big  */
+#define MSOM_ERR_HIP (-4)      /* HIP runtime error (no device, out of memory, ...)    */
+#define MSOM_ERR_COMM (-5)     /* RCCL error                                           */
+#define MSOM_ERR_STATE (-6)    /* call order violated (e.g. step before set_const)     */
+
+#define MSOM_MAXNL 8           /* layers supported by the register-resident column solver */
+
+/* field ids, mirroring the reference's global layer lists (msqg/qg.h:22-57) */
+enum {
+  MSOM_PSI = 0,    /* pol    stream function                 */
+  MSOM_Q = 1,      /* qol    potential vorticity (evolving)  */
+  MSOM_ZETA = 2,   /* zetal  relative vorticity              */
+  MSOM_PSIPG = 3,  /* ppl    large-scale stream function     */
+  MSOM_ZETAPG = 4, /* zetapl large-scale relative vorticity  */
+  MSOM_QFORC = 5,  /* q_forcl 3-D PV forcing                 */
+  MSOM_TMP = 6,    /* tmpl                                   */
+  MSOM_FR = 7,     /* Frl    Froude number, nl-1 layers      */
+  MSOM_S = 8,      /* strl   (Fr/Ro)^2, nl-1 layers          */
+  MSOM_DQ = 9,     /* updates                                */
+  MSOM_RO = 10,    /* Ro, 1 layer                            */
+  MSOM_TOPO = 11,  /* topo, 1 layer                          */
+  MSOM_QPRED = 12, /* predictor                              */
+  MSOM_NOISE = 13, /* n_stochl (msqg/qg_stochastic.h:13)     */
+  MSOM_SIGMA = 14, /* s_stochl (msqg/qg_stochastic.h:14)     */
+  MSOM_NFIELDS = 15
+};
+
+/* mgstats of Basilisk (text: mspg/elliptic.h:118-123), kept by the reference in `mgpsi`
+ * (msqg/qg.h:61) */
+typedef struct {
+  int i;             /* number of multigrid cycles                */
+  double resb, resa; /* max |residual| before and after           */
+  double sum;        /* sum of the right-hand side                */
+  int nrelax;        /* relaxations per level at exit             */
+} msom_mgstats;
+
+typedef struct msom msom_t;
+
+const char *msom_last_error(void);
+const char *msom_version(void);
+
+/* ---- lifecycle: read_params -> init_grid -> set_vars   (msqg/qg.c:34-47, qg.h:689-761,837-925)
+ * msom_create parses a params.in file; msom_create_str parses the same text from memory.
+ * Extension keys (ignored by the reference parser, qg.h:698-731): Ny (non-square domain),
+ * TOLERANCE, NITERMAX, NITERMIN.  Returns NULL on error. */
+msom_t *msom_create(const char *params_path);
+msom_t *msom_create_str(const char *params_text);
+/* trash_vars, msqg/qg.h:1130-1154 */
+int msom_destroy(msom_t *m);
+
+/* run-time counterparts of the reference's compile-time flags and Basilisk globals:
+ * "TOLERANCE" "NITERMAX" "NITERMIN" (mspg/elliptic.h:111-112, qg.h:159), "DT",
+ * "stochastic" (-D_STOCHASTIC), "seed", "flag_topo", "fixed_cycles" (bench: data-independent
+ * work), "uniform_S" (0 forces the general S-field kernels), "profile" (HIP-event timing of
+ * the smoother launches). */
+int msom_set_option(msom_t *m, const char *key, double value);
+/* parsed / derived parameters: N nx ny nl L0 DT iRe iRe4 CFL Rom tend dtout beta tau0 Ekb Eks
+ * sbc idh0_<l> idh1_<l> Fr_<l> dh_<l> nlevels */
+double msom_get_param(msom_t *m, const char *key);
+
+/* pyset_field / pyget_field, msqg/qg.h:1164-1188 (array [layer][y][x]; BC applied after set) */
+int msom_set_field(msom_t *m, int field, const double *a);
+int msom_get_field(msom_t *m, int field, double *a);
+int msom_field_layers(msom_t *m, int field);
+/* mean removal of the initial condition, msqg/qg.c:65-70 */
+int msom_remove_mean(msom_t *m, int field);
+/* set_const, msqg/qg.h:931-1116: layer metrics, Ro, S = (Fr/Ro)^2, q = comp_q(psi), BCs.
+ * Input files (psipg_, frpg_, topo, qforc_, p0.bas ...) are read by msom_read_inputs. */
+int msom_set_const(msom_t *m);
+/* optional input-file discovery in `dir` (msqg/qg.h:940-984, msqg/qg.c:55-59) */
+int msom_read_inputs(msom_t *m, const char *dir);
+
+/* ---- the two hooks Basilisk's run() calls (installed at msqg/qg.h:922-923) */
+/* update_qg, msqg/qg.h:609-650: dq/dt = F(q); returns the CFL-limited dtmax (< 0 on error) */
+double msom_update(msom_t *m, const double *q, double *dqdt, double dtmax);
+/* advance_qg, msqg/qg.h:594-606 (stochastic: msqg/qg_stochastic.h:128-149) */
+int msom_advance(msom_t *m, double *qout, const double *qin, const double *dqdt, double dt);
+
+/* ---- elliptic plug-in (poisson_layer -> mg_solve(relax_layer, residual_layer),
+ * msqg/poisson_layer.h:263-306; invertq msqg/qg.h:114-163).  psi is warm start and result. */
+int msom_invertq(msom_t *m, const double *q, double *psi, msom_mgstats *st);
+/* comp_q, msqg/qg.h:397-403 */
+int msom_comp_q(msom_t *m, const double *psi, double *q);
+
+/* ---- the array-level operator API of the reference's Python module, same argument order
+ * (msqg/qg_bfn.h:21-103; SWIG typemaps msqg/qg_bfn.i) */
+int pystep_bfn(msom_t *m, double *varin_py, int len1, int len2, int len3, double *tend_py, int len4, int len5,
+               int len6, double direction, int vartype);
+int pyq2p(msom_t *m, double *po_py, int len7, int len8, int len9, double *qo_py, int len10, int len11, int len12);
+int pyp2q(msom_t *m, double *po_py, int len13, int len14, int len15, double *qo_py, int len16, int len17, int len18);
+
+/* ---- time loop of Basilisk predictor-corrector run() as driven by msqg/qg.c
+ * msom_step: one RK2 step on the internal state (update, dtnext, advance dt/2, update,
+ * advance dt).  msom_set_tnext gives the time of the next t-scheduled event (output). */
+int msom_step(msom_t *m, double *dt_used);
+int msom_set_tnext(msom_t *m, double tnext);
+double msom_time(msom_t *m);
+int msom_iter(msom_t *m);
+/* kinetic-energy diagnostic of the per-step stdout line, msqg/qg.c:101-109 */
+double msom_ke(msom_t *m);
+int msom_last_mgstats(msom_t *m, msom_mgstats *st);
+/* msom_run: whole main() loop of msqg/qg.c:34-173 (stdout line, po/qo .bas every dtout,
+ * outdir_%04d creation, params.in backup).  nsteps_max < 0: run to tend. */
+int msom_run(msom_t *m, const char *workdir, long nsteps_max);
+
+/* ---- .bas IO, msqg/auxiliar_input.h:24-59 (input_matrixl), :101-167 (output_matrixl, write_field) */
+int msom_write_bas(msom_t *m, int field, const char *path);
+int msom_read_bas(msom_t *m, int field, const char *path);
+
+/* ---- multi-GPU tiling (replaces Basilisk's MPI layer: boundary() halo exchange and
+ * foreach(reduction)).  One process per GPU; the 2-D domain is a px x py grid of
+ * equal tiles; rank r owns tile (r % px, r / px).  id128 is the 128-byte ncclUniqueId made by
+ * msom_comm_unique_id on rank 0 and distributed by the caller (e.g. torch.distributed). */
+int msom_comm_unique_id(void *id128);
+msom_t *msom_create_tiled(const char *params_text, int px, int py, int rank, const void *id128);
+int msom_tile_info(msom_t *m, int *px, int *py, int *ix, int *iy, int *nx_local, int *ny_local);
+
+/* ---- debug / test hooks (used by tests/ to compare single kernels with the oracle) */
+int msom_dbg_nlevels(msom_t *m);
+int msom_dbg_level_dims(msom_t *m, int lev, int *nx, int *ny);
+int msom_dbg_relax(msom_t *m, int lev, double *da, const double *res, int nsweeps);
+int msom_dbg_residual(msom_t *m, const double *a, const double *b, double *res, double *maxres);
+int msom_dbg_restrict(msom_t *m, int lev_fine, const double *fine, double *coarse);
+int msom_dbg_prolong(msom_t *m, int lev_coarse, const double *coarse, double *fine);
+int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, double add, double fac);
+
+/* ---- measurement: average HIP-event duration of the finest-level smoother sweep
+ * (both colours) recorded while "profile" is on, and a direct kernel microbenchmark */
+int msom_profile_read(msom_t *m, const char *kernel, double *avg_ms, long *launches);
+int msom_profile_reset(msom_t *m);
+int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

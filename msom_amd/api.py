@@ -1,0 +1,361 @@
+"""ctypes binding of libmsomhip (include/msom.h) and the host mirror of the reference's
+Python surface (msqg/qg.i:29-36, msqg/qg_bfn.i, usage in msqg/qg_bfn.py:33-80)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBDIR = os.path.join(_HERE, "lib")
+
+FIELDS = dict(PSI=0, Q=1, ZETA=2, PSIPG=3, ZETAPG=4, QFORC=5, TMP=6, FR=7, S=8, DQ=9, RO=10, TOPO=11,
+              QPRED=12, NOISE=13, SIGMA=14)
+
+
+class MsomError(RuntimeError):
+    pass
+
+
+class MGStats(C.Structure):
+    """mgstats of Basilisk (mspg/elliptic.h:118-123)."""
+    _fields_ = [("i", C.c_int), ("resb", C.c_double), ("resa", C.c_double), ("sum", C.c_double), ("nrelax", C.c_int)]
+
+    def __repr__(self):
+        return f"MGStats(i={self.i}, resb={self.resb:g}, resa={self.resa:g}, sum={self.sum:g}, nrelax={self.nrelax})"
+
+
+_libs = {}
+_dp = C.POINTER(C.c_double)
+
+
+def load_library(strict=False):
+    """Load the HIP library.  strict=True loads the validation build (-ffp-contract=off,
+    reference expression order) that is bit-exact against the CPU oracle."""
+    name = "libmsomhip_strict.so" if strict else "libmsomhip.so"
+    if name in _libs:
+        return _libs[name]
+    path = os.path.join(_LIBDIR, name)
+    if not os.path.exists(path):
+        raise MsomError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(make -C msom_amd/csrc).  There is no CPU fallback.")
+    L = C.CDLL(path)
+    vp, ci, cd, cs = C.c_void_p, C.c_int, C.c_double, C.c_char_p
+    sig = {
+        "msom_last_error": (cs, []),
+        "msom_version": (cs, []),
+        "msom_create": (vp, [cs]),
+        "msom_create_str": (vp, [cs]),
+        "msom_destroy": (ci, [vp]),
+        "msom_set_option": (ci, [vp, cs, cd]),
+        "msom_get_param": (cd, [vp, cs]),
+        "msom_set_field": (ci, [vp, ci, vp]),
+        "msom_get_field": (ci, [vp, ci, vp]),
+        "msom_field_layers": (ci, [vp, ci]),
+        "msom_remove_mean": (ci, [vp, ci]),
+        "msom_set_const": (ci, [vp]),
+        "msom_read_inputs": (ci, [vp, cs]),
+        "msom_update": (cd, [vp, vp, vp, cd]),
+        "msom_advance": (ci, [vp, vp, vp, vp, cd]),
+        "msom_invertq": (ci, [vp, vp, vp, C.POINTER(MGStats)]),
+        "msom_comp_q": (ci, [vp, vp, vp]),
+        "pystep_bfn": (ci, [vp, vp, ci, ci, ci, vp, ci, ci, ci, cd, ci]),
+        "pyq2p": (ci, [vp, vp, ci, ci, ci, vp, ci, ci, ci]),
+        "pyp2q": (ci, [vp, vp, ci, ci, ci, vp, ci, ci, ci]),
+        "msom_step": (ci, [vp, _dp]),
+        "msom_set_tnext": (ci, [vp, cd]),
+        "msom_time": (cd, [vp]),
+        "msom_iter": (ci, [vp]),
+        "msom_ke": (cd, [vp]),
+        "msom_last_mgstats": (ci, [vp, C.POINTER(MGStats)]),
+        "msom_run": (ci, [vp, cs, C.c_long]),
+        "msom_write_bas": (ci, [vp, ci, cs]),
+        "msom_read_bas": (ci, [vp, ci, cs]),
+        "msom_comm_unique_id": (ci, [vp]),
+        "msom_create_tiled": (vp, [cs, ci, ci, ci, vp]),
+        "msom_tile_info": (ci, [vp] + [C.POINTER(ci)] * 6),
+        "msom_dbg_nlevels": (ci, [vp]),
+        "msom_dbg_level_dims": (ci, [vp, ci, C.POINTER(ci), C.POINTER(ci)]),
+        "msom_dbg_relax": (ci, [vp, ci, vp, vp, ci]),
+        "msom_dbg_residual": (ci, [vp, vp, vp, vp, _dp]),
+        "msom_dbg_restrict": (ci, [vp, ci, vp, vp]),
+        "msom_dbg_prolong": (ci, [vp, ci, vp, vp]),
+        "msom_dbg_op": (ci, [vp, cs, ci, ci, cd, cd]),
+        "msom_profile_read": (ci, [vp, cs, _dp, C.POINTER(C.c_long)]),
+        "msom_profile_reset": (ci, [vp]),
+        "msom_bench_kernel": (ci, [vp, cs, ci, _dp]),
+    }
+    for fn, (res, args) in sig.items():
+        f = getattr(L, fn)  # AttributeError if the library does not export a declared symbol
+        f.restype, f.argtypes = res, args
+    _libs[name] = L
+    return L
+
+
+def _ptr(a):
+    """numpy array (host) or an object with .data_ptr() (torch tensor, host or device)."""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(a.ctypes.data)
+
+
+def _f64(a, shape=None):
+    if hasattr(a, "data_ptr"):
+        return a
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"array shape {a.shape} != {tuple(shape)}")
+    return a
+
+
+class QG:
+    """One model instance = one `qg.e` process / one `import qg` of the reference."""
+
+    def __init__(self, params=None, path=None, strict=False, tiled=None):
+        self.L = load_library(strict)
+        self.h = None
+        if tiled is not None:
+            px, py, rank, uid = tiled
+            self.h = self.L.msom_create_tiled(params.encode(), px, py, rank, uid)
+        elif path is not None:
+            self.h = self.L.msom_create(path.encode())
+        else:
+            self.h = self.L.msom_create_str(params.encode())
+        if not self.h:
+            raise MsomError(self.L.msom_last_error().decode())
+        self.nl = int(self.param("nl"))
+        px_, py_, ix, iy, nx, ny = (C.c_int() for _ in range(6))
+        self.L.msom_tile_info(self.h, *(C.byref(v) for v in (px_, py_, ix, iy, nx, ny)))
+        self.nx, self.ny = nx.value, ny.value
+        self.tile = (px_.value, py_.value, ix.value, iy.value)
+
+    def close(self):
+        if self.h:
+            self.L.msom_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r != 0:
+            raise MsomError(f"error {r}: {self.L.msom_last_error().decode()}")
+
+    # -- parameters / options
+    def param(self, key):
+        return self.L.msom_get_param(self.h, key.encode())
+
+    def option(self, key, value):
+        self._chk(self.L.msom_set_option(self.h, key.encode(), float(value)))
+
+    # -- fields (pyset_field / pyget_field, msqg/qg.h:1164-1188)
+    def shape(self, field):
+        return (self.L.msom_field_layers(self.h, field), self.ny, self.nx)
+
+    def set(self, field, a):
+        a = _f64(a, self.shape(field))
+        self._chk(self.L.msom_set_field(self.h, field, _ptr(a)))
+
+    def get(self, field):
+        a = np.empty(self.shape(field))
+        self._chk(self.L.msom_get_field(self.h, field, _ptr(a)))
+        return a
+
+    def remove_mean(self, field):
+        self._chk(self.L.msom_remove_mean(self.h, field))
+
+    def set_const(self):
+        self._chk(self.L.msom_set_const(self.h))
+
+    def read_inputs(self, directory="."):
+        self._chk(self.L.msom_read_inputs(self.h, directory.encode()))
+
+    # -- hooks
+    def update(self, q=None, dtmax=None, want=True):
+        """update_qg: returns (dqdt, dtmax)."""
+        q = None if q is None else _f64(q, self.shape(1))
+        out = np.empty(self.shape(1)) if want else None
+        d = self.L.msom_update(self.h, _ptr(q), _ptr(out), self.param("DT") if dtmax is None else dtmax)
+        if d < 0:
+            raise MsomError(self.L.msom_last_error().decode())
+        return out, d
+
+    def advance(self, qin, dqdt, dt):
+        qin, dqdt = _f64(qin, self.shape(1)), _f64(dqdt, self.shape(1))
+        out = np.empty(self.shape(1))
+        self._chk(self.L.msom_advance(self.h, _ptr(out), _ptr(qin), _ptr(dqdt), dt))
+        return out
+
+    def invertq(self, q=None, psi0=None):
+        q = None if q is None else _f64(q, self.shape(1))
+        psi = np.zeros(self.shape(0)) if psi0 is None else np.array(psi0, dtype=np.float64, order="C")
+        st = MGStats()
+        self._chk(self.L.msom_invertq(self.h, _ptr(q), _ptr(psi), C.byref(st)))
+        return psi, st
+
+    def comp_q(self, psi):
+        psi = _f64(psi, self.shape(0))
+        q = np.empty(self.shape(1))
+        self._chk(self.L.msom_comp_q(self.h, _ptr(psi), _ptr(q)))
+        return q
+
+    # -- msqg/qg_bfn.h
+    def pystep_bfn(self, var, tend, direction=1.0, vartype=1):
+        var = _f64(var)
+        assert tend.dtype == np.float64 and tend.flags.c_contiguous
+        self._chk(self.L.pystep_bfn(self.h, _ptr(var), *var.shape, _ptr(tend), *tend.shape, direction, vartype))
+
+    def pyq2p(self, p, q):
+        q = _f64(q)
+        assert p.dtype == np.float64 and p.flags.c_contiguous
+        self._chk(self.L.pyq2p(self.h, _ptr(p), *p.shape, _ptr(q), *q.shape))
+
+    def pyp2q(self, p, q):
+        p = _f64(p)
+        assert q.dtype == np.float64 and q.flags.c_contiguous
+        self._chk(self.L.pyp2q(self.h, _ptr(p), *p.shape, _ptr(q), *q.shape))
+
+    # -- time loop
+    def step(self):
+        dt = C.c_double()
+        self._chk(self.L.msom_step(self.h, C.byref(dt)))
+        return dt.value
+
+    def set_tnext(self, tnext):
+        self._chk(self.L.msom_set_tnext(self.h, tnext))
+
+    @property
+    def t(self):
+        return self.L.msom_time(self.h)
+
+    @property
+    def iter(self):
+        return self.L.msom_iter(self.h)
+
+    def ke(self):
+        return self.L.msom_ke(self.h)
+
+    def mgstats(self):
+        st = MGStats()
+        self._chk(self.L.msom_last_mgstats(self.h, C.byref(st)))
+        return st
+
+    def run(self, workdir=".", nsteps_max=-1):
+        self._chk(self.L.msom_run(self.h, workdir.encode(), nsteps_max))
+
+    def write_bas(self, field, path):
+        self._chk(self.L.msom_write_bas(self.h, field, path.encode()))
+
+    def read_bas(self, field, path):
+        self._chk(self.L.msom_read_bas(self.h, field, path.encode()))
+
+    # -- debug hooks
+    def nlevels(self):
+        return self.L.msom_dbg_nlevels(self.h)
+
+    def level_dims(self, lev):
+        nx, ny = C.c_int(), C.c_int()
+        self._chk(self.L.msom_dbg_level_dims(self.h, lev, C.byref(nx), C.byref(ny)))
+        return nx.value, ny.value
+
+    def relax(self, lev, da, res, nsweeps=1):
+        da = np.array(da, dtype=np.float64, order="C")
+        res = _f64(res)
+        self._chk(self.L.msom_dbg_relax(self.h, lev, _ptr(da), _ptr(res), nsweeps))
+        return da
+
+    def residual(self, a, b):
+        a, b = _f64(a), _f64(b)
+        res = np.empty_like(a)
+        m = C.c_double()
+        self._chk(self.L.msom_dbg_residual(self.h, _ptr(a), _ptr(b), _ptr(res), C.byref(m)))
+        return res, m.value
+
+    def restrict(self, lev_fine, fine):
+        fine = _f64(fine)
+        nl, ny, nx = fine.shape
+        coarse = np.empty((nl, ny // 2, nx // 2))
+        self._chk(self.L.msom_dbg_restrict(self.h, lev_fine, _ptr(fine), _ptr(coarse)))
+        return coarse
+
+    def prolong(self, lev_coarse, coarse):
+        coarse = _f64(coarse)
+        nl, ny, nx = coarse.shape
+        fine = np.empty((nl, ny * 2, nx * 2))
+        self._chk(self.L.msom_dbg_prolong(self.h, lev_coarse, _ptr(coarse), _ptr(fine)))
+        return fine
+
+    def op(self, name, f_in, f_out, add=0.0, fac=1.0):
+        self._chk(self.L.msom_dbg_op(self.h, name.encode(), f_in, f_out, add, fac))
+
+    # -- measurement
+    def profile_read(self, kernel):
+        ms, n = C.c_double(), C.c_long()
+        self._chk(self.L.msom_profile_read(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def profile_reset(self):
+        self._chk(self.L.msom_profile_reset(self.h))
+
+    def bench_kernel(self, kernel, reps=20):
+        ms = C.c_double()
+        self._chk(self.L.msom_bench_kernel(self.h, kernel.encode(), reps, C.byref(ms)))
+        return ms.value
+
+
+# ---------------------------------------------------------------------------
+# module-level mirror of the reference's single-instance `import qg` surface
+# (msqg/qg_bfn.py:33-37: read_params -> init_grid -> set_vars -> set_vars_bfn -> set_const)
+
+_state = {"path": None, "model": None}
+
+
+def read_params(path2file):
+    _state["path"] = path2file
+
+
+def init_grid(N):  # grid size comes from params.in; kept for call-compatibility
+    return None
+
+
+def set_vars():
+    if _state["path"] is None:
+        raise MsomError("read_params() must be called first")
+    _state["model"] = QG(path=_state["path"])
+    d = os.path.dirname(os.path.abspath(_state["path"]))
+    _state["model"].option("quiet", 1)
+    _state["model"].read_inputs(d)
+
+
+def set_vars_bfn():
+    return None
+
+
+def set_const():
+    _state["model"].set_const()
+
+
+def pystep_bfn(var, tend, direction, vartype):
+    _state["model"].pystep_bfn(var, tend, direction, vartype)
+
+
+def pyq2p(p, q):
+    _state["model"].pyq2p(p, q)
+
+
+def pyp2q(p, q):
+    _state["model"].pyp2q(p, q)
+
+
+def trash_vars():
+    if _state["model"] is not None:
+        _state["model"].close()
+        _state["model"] = None
+
+
+def trash_vars_bfn():
+    return None

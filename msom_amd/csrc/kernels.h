@@ -1,0 +1,62 @@
+// kernels.h -- launch wrappers of the HIP kernels (internal).
+#ifndef MSOM_KERNELS_H
+#define MSOM_KERNELS_H
+
+#include "msom_internal.h"
+
+// layer metrics idh0/idh1 (msqg/qg.h:1017-1027), passed by value to kernels
+struct LayerCoef {
+  double idh0[MSOM_MAXNL], idh1[MSOM_MAXNL];
+};
+
+// per-level constants of the column solver
+struct RelaxCoef {
+  double D, sqD;              // Delta and Delta^2 of the level
+  double idh0[MSOM_MAXNL], idh1[MSOM_MAXNL];
+  // uniform-S fast path: the tridiagonal is the same in every column, so the Thomas
+  // factorisation is done once on the host (msqg/poisson_layer.h:137-140)
+  double t2[MSOM_MAXNL];      // super-diagonal
+  double w[MSOM_MAXNL];       // t0[l] / t1'[l-1]
+  double it1[MSOM_MAXNL];     // 1 / t1'[l]
+  double S[MSOM_MAXNL];       // uniform S_l (residual, stretching)
+};
+
+// ---- kernels_rhs.hip
+void launch_fill_ghost(hipStream_t st, double *f, const NatGeom &g, int nl, int bc, int walls);
+void launch_slip_bc(hipStream_t st, const double *po, double *zeta, const NatGeom &g, int nl, double c, int walls);
+void launch_pack(hipStream_t st, const double *src, double *dst, const NatGeom &g, int nl);
+void launch_unpack(hipStream_t st, const double *src, double *dst, const NatGeom &g, int nl);
+void launch_del2(hipStream_t st, const double *po, double *zeta, const NatGeom &g, int nl, double add, double fac, double D);
+void launch_stretch(hipStream_t st, const double *po, double *out, const double *S, const NatGeom &g, int nl, double add, double fac,
+                    const LayerCoef &lc);
+void launch_advection(hipStream_t st, const double *zeta, const double *psi, const double *psipg, const double *zetapg, const double *S,
+                      const double *qot, double *dq, const NatGeom &g, int nl, int have_pg, int have_zpg, int stochastic, double D,
+                      double beta, double itr_stoch, const LayerCoef &lc);
+void launch_umax(hipStream_t st, const double *f0, const double *f1, int nf, double *out, const NatGeom &g, int nl, double D);
+void launch_axpy(hipStream_t st, double *dq, const double *x, const NatGeom &g, int nl, double c);
+void launch_forcing(hipStream_t st, const double *zeta, const double *psi, const double *qforc, const double *topo, const double *Ro,
+                    const double *wind, double *dq, const NatGeom &g, int nl, int have_qforc, int flag_topo, double cs, double cb,
+                    double D, double dhb);
+void launch_advance(hipStream_t st, double *qo, const double *qi, const double *dq, const double *noise, const NatGeom &g, int nl, double dt,
+                    double dts);
+int partial_count(const NatGeom &g);
+void launch_sum_final(hipStream_t st, const double *partial, double *out, int n);
+void launch_ke(hipStream_t st, const double *po, double *partial, double *out, const NatGeom &g, double D);
+void launch_sum_layers(hipStream_t st, const double *f, double *partial, double *out, const NatGeom &g, int nl);
+void launch_sub_layer_const(hipStream_t st, double *f, const double *sums, const NatGeom &g, int nl, double inv_count);
+void launch_make_S(hipStream_t st, const double *Fr, const double *Ro, double *S, const NatGeom &g, int nlm);
+
+// ---- kernels_mg.hip
+void launch_nat_to_split(hipStream_t st, const double *nat, const NatGeom &g, double *sp, const SplitGeom &sg, int nl);
+void launch_split_to_nat(hipStream_t st, const double *sp, const SplitGeom &sg, double *nat, const NatGeom &g, int nl);
+void launch_split_pack(hipStream_t st, const double *src, double *sp, const SplitGeom &sg, int nl, int bc, int walls);
+void launch_split_unpack(hipStream_t st, const double *sp, const SplitGeom &sg, double *dst, int nl);
+void launch_residual(hipStream_t st, const double *a, const double *b, const double *S, const NatGeom &g, double *res, const SplitGeom &sg,
+                     int nl, const RelaxCoef &rc, int uniformS, double *maxres, double *sum_partial, int want_sum);
+void launch_restrict(hipStream_t st, const double *fine, const SplitGeom &fg, double *coarse, const SplitGeom &cg, int nl);
+void launch_prolong(hipStream_t st, const double *coarse, const SplitGeom &cg, double *fine, const SplitGeom &fg, int nl, int walls);
+void launch_relax_color(hipStream_t st, double *da, const double *res, const double *S, const SplitGeom &sg, int nl, const RelaxCoef &rc,
+                        int uniformS, int color, int walls);
+void launch_correct(hipStream_t st, double *a, const NatGeom &g, const double *da, const SplitGeom &sg, int nl, int walls);
+
+#endif

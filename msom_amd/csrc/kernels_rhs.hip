@@ -1,0 +1,438 @@
+// kernels_rhs.hip -- PV-tendency stencil kernels of libmsomhip (gfx950 / CDNA4, fp64).
+//
+// One thread owns one (x, y) column and walks the nl layers, so the vertical coupling
+// (stretching, ju = -jd carry of the Arakawa cross-layer Jacobians) stays in registers and
+// every global access is coalesced along x (64-wide wavefronts, rows 128-B aligned).
+// Reference loops restated here (file:line in the reference tree):
+//   comp_del2 msqg/qg.h:172-200, comp_stretch :203-246, jacobian :252-262, beta_effect :269,
+//   comp_vel :276-283, advection_pv :288-393, dissip :407-422, ekman_friction :429-440,
+//   surface_forcing :447-459, qforcing :466-474, bottom_topography :481-488,
+//   advance_qg :594-606, KE diagnostic msqg/qg.c:101-109.
+//
+// Arithmetic: with -DMSOM_STRICT (validation build, -ffp-contract=off) every expression is
+// evaluated in the reference's order with true divisions, which makes the kernels bit-exact
+// against the CPU oracle; the product build multiplies by precomputed reciprocals and lets
+// the compiler contract to FMA.
+#include "kernels.h"
+
+#ifdef MSOM_STRICT
+#define DIVC(x, c, rc) ((x) / (c))
+#else
+#define DIVC(x, c, rc) ((x) * (rc))
+#endif
+
+#define BX 64
+#define BY 4
+
+static inline dim3 grid2d(int nx, int ny) { return dim3((nx + BX - 1) / BX, (ny + BY - 1) / BY); }
+static inline dim3 block2d() { return dim3(BX, BY); }
+
+// ------------------------------------------------------------------ block reductions
+
+__device__ __forceinline__ double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+// max of non-negative doubles: IEEE order == unsigned integer order
+__device__ __forceinline__ void atomic_max_nonneg(double *addr, double v) {
+  atomicMax((unsigned long long *)addr, (unsigned long long)__double_as_longlong(v));
+}
+__device__ __forceinline__ void block_max_to(double *addr, double v) {
+  __shared__ double sm[16];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x, w = tid >> 6, nw = (blockDim.x * blockDim.y + 63) >> 6;
+  v = wave_max(v);
+  if ((tid & 63) == 0) sm[w] = v;
+  __syncthreads();
+  if (tid == 0) {
+    double m = sm[0];
+    for (int k = 1; k < nw; k++) m = fmax(m, sm[k]);
+    atomic_max_nonneg(addr, m);
+  }
+}
+
+// ------------------------------------------------------------------ ghost fill
+
+// boundary(): box BCs direction by direction (x walls first, then y walls over the x-ghosts,
+// so corner ghosts are the y-BC applied to the x-ghost column).  Only sides flagged in
+// `walls` are physical walls; the others are tile edges filled by the halo exchange.
+__global__ void k_fill_ghost(double *f, NatGeom g, int nl, int bc, int walls) {
+  const int per = 2 * g.ny + 2 * (g.nx + 2);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per * nl) return;
+  const int l = t / per, r = t % per;
+  const double s = bc == BC_DIRICHLET0 ? -1. : 1.;
+  if (r < 2 * g.ny) {
+    const int j = r >> 1, east = r & 1;
+    if (east) {
+      if (walls & WALL_E) f[nat_idx(g, l, j, g.nx)] = bc == BC_PERIODIC ? f[nat_idx(g, l, j, 0)] : s * f[nat_idx(g, l, j, g.nx - 1)];
+    } else {
+      if (walls & WALL_W) f[nat_idx(g, l, j, -1)] = bc == BC_PERIODIC ? f[nat_idx(g, l, j, g.nx - 1)] : s * f[nat_idx(g, l, j, 0)];
+    }
+  } else {
+    const int q = r - 2 * g.ny, i = (q >> 1) - 1, north = q & 1;  // i in [-1, nx]
+    if (!(walls & (north ? WALL_N : WALL_S))) return;
+    // value of the x-extended row next to the wall (uses the x-BC for i = -1, nx when that
+    // side is a wall; otherwise the exchanged ghost already stored there)
+    const int jsrc = bc == BC_PERIODIC ? (north ? 0 : g.ny - 1) : (north ? g.ny - 1 : 0);
+    double v;
+    if (i == -1 && (walls & WALL_W)) v = bc == BC_PERIODIC ? f[nat_idx(g, l, jsrc, g.nx - 1)] : s * f[nat_idx(g, l, jsrc, 0)];
+    else if (i == g.nx && (walls & WALL_E)) v = bc == BC_PERIODIC ? f[nat_idx(g, l, jsrc, 0)] : s * f[nat_idx(g, l, jsrc, g.nx - 1)];
+    else v = f[nat_idx(g, l, jsrc, i)];
+    f[nat_idx(g, l, north ? g.ny : -1, i)] = bc == BC_PERIODIC ? v : s * v;
+  }
+}
+
+void launch_fill_ghost(hipStream_t st, double *f, const NatGeom &g, int nl, int bc, int walls) {
+  const int n = (2 * g.ny + 2 * (g.nx + 2)) * nl;
+  hipLaunchKernelGGL(k_fill_ghost, dim3((n + 255) / 256), dim3(256), 0, st, f, g, nl, bc, walls);
+}
+
+// partial-slip override of the zeta ghosts, msqg/qg.h:185-198
+__global__ void k_slip_bc(const double *po, double *zeta, NatGeom g, int nl, double c, int walls) {
+  const int per = 2 * g.ny + 2 * g.nx;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per * nl) return;
+  const int l = t / per, r = t % per;
+  int i, j, gi, gj, side;
+  if (r < 2 * g.ny) { j = gj = r >> 1; if (r & 1) { i = g.nx - 1; gi = g.nx; side = WALL_E; } else { i = 0; gi = -1; side = WALL_W; } }
+  else { const int q = r - 2 * g.ny; i = gi = q >> 1; if (q & 1) { j = g.ny - 1; gj = g.ny; side = WALL_N; } else { j = 0; gj = -1; side = WALL_S; } }
+  if (!(walls & side)) return;
+  zeta[nat_idx(g, l, gj, gi)] = c * (po[nat_idx(g, l, j, i)] - po[nat_idx(g, l, gj, gi)]);
+}
+void launch_slip_bc(hipStream_t st, const double *po, double *zeta, const NatGeom &g, int nl, double c, int walls) {
+  const int n = (2 * g.ny + 2 * g.nx) * nl;
+  hipLaunchKernelGGL(k_slip_bc, dim3((n + 255) / 256), dim3(256), 0, st, po, zeta, g, nl, c, walls);
+}
+
+// ------------------------------------------------------------------ pack / unpack
+
+// contiguous [layer][y][x] <-> padded natural layout
+__global__ void k_pack(const double *src, double *dst, NatGeom g, int nl) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  for (int l = 0; l < nl; l++) dst[nat_idx(g, l, j, i)] = src[((size_t)l * g.ny + j) * g.nx + i];
+}
+__global__ void k_unpack(const double *src, double *dst, NatGeom g, int nl) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  for (int l = 0; l < nl; l++) dst[((size_t)l * g.ny + j) * g.nx + i] = src[nat_idx(g, l, j, i)];
+}
+void launch_pack(hipStream_t st, const double *src, double *dst, const NatGeom &g, int nl) {
+  hipLaunchKernelGGL(k_pack, grid2d(g.nx, g.ny), block2d(), 0, st, src, dst, g, nl);
+}
+void launch_unpack(hipStream_t st, const double *src, double *dst, const NatGeom &g, int nl) {
+  hipLaunchKernelGGL(k_unpack, grid2d(g.nx, g.ny), block2d(), 0, st, src, dst, g, nl);
+}
+
+// ------------------------------------------------------------------ K1 comp_del2
+
+#define LAPV(p, c, pitch) ((p)[(c) + 1] + (p)[(c)-1] + (p)[(c) + (pitch)] + (p)[(c) - (pitch)] - 4 * (p)[c])
+
+__global__ void k_del2(const double *__restrict__ po, double *zeta, NatGeom g, int nl, double add, double fac, double D2, double rD2) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  size_t c = nat_idx(g, 0, j, i);
+  for (int l = 0; l < nl; l++, c += g.ls) {
+    const double lap = DIVC(LAPV(po, c, g.pitch), D2, rD2);
+    zeta[c] = add == 0. ? fac * lap : add * zeta[c] + fac * lap;
+  }
+}
+void launch_del2(hipStream_t st, const double *po, double *zeta, const NatGeom &g, int nl, double add, double fac, double D) {
+  const double D2 = D * D;
+  hipLaunchKernelGGL(k_del2, grid2d(g.nx, g.ny), block2d(), 0, st, po, zeta, g, nl, add, fac, D2, 1. / D2);
+}
+
+// ------------------------------------------------------------------ K2 comp_stretch
+
+__global__ void k_stretch(const double *__restrict__ po, double *st, const double *__restrict__ S, NatGeom g, int nl, double add,
+                          double fac, LayerCoef lc) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  const size_t c0 = nat_idx(g, 0, j, i);
+  if (nl == 1) { st[c0] = add == 0. ? 0. : add * st[c0]; return; }  // Gamma = 0 (reference: degenerate, qg.h:239-242)
+  double pm = 0., pc = po[c0], pp, s0 = 0., s1;
+  for (int l = 0; l < nl; l++) {
+    const size_t c = c0 + (size_t)l * g.ls;
+    double v;
+    if (l < nl - 1) { pp = po[c + g.ls]; s1 = S[c]; }
+    if (l == 0) v = fac * s1 * (pp - pc) * lc.idh1[l];
+    else if (l < nl - 1) v = fac * (s0 * (pm - pc) * lc.idh0[l] + s1 * (pp - pc) * lc.idh1[l]);
+    else v = fac * s0 * (pm - pc) * lc.idh0[l];
+    st[c] = add == 0. ? v : add * st[c] + v;
+    pm = pc; pc = pp; s0 = s1;
+  }
+}
+void launch_stretch(hipStream_t st, const double *po, double *out, const double *S, const NatGeom &g, int nl, double add, double fac,
+                    const LayerCoef &lc) {
+  hipLaunchKernelGGL(k_stretch, grid2d(g.nx, g.ny), block2d(), 0, st, po, out, S, g, nl, add, fac, lc);
+}
+
+// ------------------------------------------------------------------ K3 advection_pv
+
+// -J(p,q) of msqg/qg.h:252-262, evaluated in the reference's order
+__device__ __forceinline__ double mjac(const double *__restrict__ p, const double *__restrict__ q, size_t c, int pitch, double D12, double rD12) {
+#define P(a, b) p[c + (a) + (ptrdiff_t)(b)*pitch]
+#define Q(a, b) q[c + (a) + (ptrdiff_t)(b)*pitch]
+  const double s = (Q(1, 0) - Q(-1, 0)) * (P(0, 1) - P(0, -1)) + (Q(0, -1) - Q(0, 1)) * (P(1, 0) - P(-1, 0)) +
+                   Q(1, 0) * (P(1, 1) - P(1, -1)) - Q(-1, 0) * (P(-1, 1) - P(-1, -1)) - Q(0, 1) * (P(1, 1) - P(-1, 1)) +
+                   Q(0, -1) * (P(1, -1) - P(-1, -1)) + P(0, 1) * (Q(1, 1) - Q(-1, 1)) - P(0, -1) * (Q(1, -1) - Q(-1, -1)) -
+                   P(1, 0) * (Q(1, 1) - Q(1, -1)) + P(-1, 0) * (Q(-1, 1) - Q(-1, -1));
+#undef P
+#undef Q
+  return DIVC(s, D12, rD12);
+}
+
+struct AdvArgs {
+  const double *zeta, *psi, *psipg, *zetapg, *S, *qot;
+  double *dq;
+  NatGeom g;
+  int nl, have_pg, have_zpg, stochastic;
+  double D, beta, itr_stoch;
+  LayerCoef lc;
+};
+
+__global__ void k_advection(AdvArgs a) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= a.g.nx || j >= a.g.ny) return;
+  const int pitch = a.g.pitch, nl = a.nl;
+  const size_t ls = a.g.ls;
+  const double D12 = 12. * a.D * a.D, rD12 = 1. / D12, D2x = 2 * a.D, rD2x = 1. / D2x;
+  size_t c = nat_idx(a.g, 0, j, i);
+  // nl == 1: the reference zeroes dq (msqg/qg.h:376-379, degenerate); the build defines it as
+  // the barotropic tendency = this loop without cross-layer terms
+  double ju = 0., jd = 0.;
+  for (int l = 0; l < nl; l++, c += ls) {
+    const double *po = a.psi, *qo = a.zeta, *pp = a.psipg;
+    ju = -jd;
+    if (l < nl - 1) {
+      jd = a.stochastic ? 0. : mjac(po, po + ls, c, pitch, D12, rD12);
+      if (a.have_pg) {
+        const double j2 = mjac(pp, po + ls, c, pitch, D12, rD12), j3 = mjac(po, pp + ls, c, pitch, D12, rD12);
+        jd = a.stochastic ? j2 + j3 : jd + j2 + j3;
+      }
+    }
+    double t = (a.stochastic && l == 0) ? 0. : mjac(po, qo, c, pitch, D12, rD12);
+    if (a.have_pg) {
+      const double jp = mjac(pp, qo, c, pitch, D12, rD12);
+      t = (a.stochastic && l == 0) ? jp : t + jp;
+    }
+    const double be = DIVC(a.beta * (po[c - 1] - po[c + 1]), D2x, rD2x);
+    t = (a.stochastic && l == 0 && !a.have_pg) ? be : t + be;
+    if (l > 0) t = t + a.S[c - ls] * ju * a.lc.idh0[l];
+    if (l < nl - 1) t = t + a.S[c] * jd * a.lc.idh1[l];
+    double d = a.dq[c] + t;
+    if (a.have_zpg) d += mjac(po, a.zetapg, c, pitch, D12, rD12);
+    if (a.stochastic) d += -a.qot[c] * a.itr_stoch;
+    a.dq[c] = d;
+  }
+}
+
+// ------------------------------------------------------------------ K4 comp_vel: max |u| on faces
+
+// one launch handles `nf` layered fields; result max|u| per (field, layer) in out[f*nl + l]
+struct UmaxArgs {
+  const double *f[2];
+  double *out;
+  NatGeom g;
+  int nl, nf;
+  double D;
+};
+__global__ void k_umax(UmaxArgs a) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  const bool in = i <= a.g.nx && j <= a.g.ny;
+  const double rD = 1. / a.D;
+  for (int f = 0; f < a.nf; f++)
+    for (int l = 0; l < a.nl; l++) {
+      double m = 0.;
+      if (in) {
+        const double *p = a.f[f];
+        const size_t c = nat_idx(a.g, l, j, i);
+        const int pitch = a.g.pitch;
+        if (j < a.g.ny) {  // x-face between (i-1,j) and (i,j), msqg/qg.h:280
+          const double u = DIVC(0.25 * (p[c + pitch] - p[c - pitch] + p[c - 1 + pitch] - p[c - 1 - pitch]), a.D, rD);
+          m = fabs(u);
+        }
+        if (i < a.g.nx) {  // y-face between (i,j-1) and (i,j)
+          const double v = DIVC(0.25 * (p[c + 1] - p[c - 1] + p[c + 1 - pitch] - p[c - 1 - pitch]), a.D, rD);
+          m = fmax(m, fabs(v));
+        }
+      }
+      block_max_to(&a.out[f * a.nl + l], m);
+      __syncthreads();
+    }
+}
+
+void launch_umax(hipStream_t st, const double *f0, const double *f1, int nf, double *out, const NatGeom &g, int nl, double D) {
+  UmaxArgs a;
+  a.f[0] = f0; a.f[1] = f1; a.out = out; a.g = g; a.nl = nl; a.nf = nf; a.D = D;
+  hipLaunchKernelGGL(k_umax, grid2d(g.nx + 1, g.ny + 1), block2d(), 0, st, a);
+}
+
+void launch_advection(hipStream_t st, const double *zeta, const double *psi, const double *psipg, const double *zetapg, const double *S,
+                      const double *qot, double *dq, const NatGeom &g, int nl, int have_pg, int have_zpg, int stochastic, double D,
+                      double beta, double itr_stoch, const LayerCoef &lc) {
+  AdvArgs a;
+  a.zeta = zeta; a.psi = psi; a.psipg = psipg; a.zetapg = zetapg; a.S = S; a.qot = qot; a.dq = dq;
+  a.g = g; a.nl = nl; a.have_pg = have_pg; a.have_zpg = have_zpg; a.stochastic = stochastic;
+  a.D = D; a.beta = beta; a.itr_stoch = itr_stoch; a.lc = lc;
+  hipLaunchKernelGGL(k_advection, grid2d(g.nx, g.ny), block2d(), 0, st, a);
+}
+
+// ------------------------------------------------------------------ K5 pieces, K6, K7
+
+// dq += c * tmp, msqg/qg.h:413-418
+__global__ void k_axpy(double *dq, const double *__restrict__ x, NatGeom g, int nl, double c) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  size_t k = nat_idx(g, 0, j, i);
+  for (int l = 0; l < nl; l++, k += g.ls) dq[k] += x[k] * c;
+}
+void launch_axpy(hipStream_t st, double *dq, const double *x, const NatGeom &g, int nl, double c) {
+  hipLaunchKernelGGL(k_axpy, grid2d(g.nx, g.ny), block2d(), 0, st, dq, x, g, nl, c);
+}
+
+struct ForcArgs {
+  const double *zeta, *psi, *qforc, *topo, *Ro, *wind;  // wind: per-row forcing profile (host libm)
+  double *dq;
+  NatGeom g;
+  int nl, have_qforc, flag_topo;
+  double cs, cb, D, dhb;  // cs = Eks/(Rom*2*dh0), cb = Ekb/(Rom*2*dh_{nl-1})
+};
+__global__ void k_forcing(ForcArgs a) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= a.g.nx || j >= a.g.ny) return;
+  const size_t c0 = nat_idx(a.g, 0, j, i), cb = c0 + (size_t)(a.nl - 1) * a.g.ls;
+  // ekman_friction :437-438 (top first, then bottom; for nl == 1 both hit the same cell)
+  a.dq[c0] -= a.cs * a.zeta[c0];
+  a.dq[cb] -= a.cb * a.zeta[cb];
+  // surface_forcing :451
+  a.dq[c0] -= a.wind[j];
+  if (a.have_qforc)
+    for (int l = 0; l < a.nl; l++) a.dq[c0 + (size_t)l * a.g.ls] += a.qforc[c0 + (size_t)l * a.g.ls];
+  if (a.flag_topo) {  // bottom_topography :486
+    const double D12 = 12. * a.D * a.D;
+    a.dq[cb] += mjac(a.psi + (size_t)(a.nl - 1) * a.g.ls, a.topo, c0, a.g.pitch, D12, 1. / D12) / (a.Ro[c0] * a.dhb);
+  }
+}
+void launch_forcing(hipStream_t st, const double *zeta, const double *psi, const double *qforc, const double *topo, const double *Ro,
+                    const double *wind, double *dq, const NatGeom &g, int nl, int have_qforc, int flag_topo, double cs, double cb,
+                    double D, double dhb) {
+  ForcArgs a;
+  a.zeta = zeta; a.psi = psi; a.qforc = qforc; a.topo = topo; a.Ro = Ro; a.wind = wind; a.dq = dq;
+  a.g = g; a.nl = nl; a.have_qforc = have_qforc; a.flag_topo = flag_topo; a.cs = cs; a.cb = cb; a.D = D; a.dhb = dhb;
+  hipLaunchKernelGGL(k_forcing, grid2d(g.nx, g.ny), block2d(), 0, st, a);
+}
+
+// advance_qg :597-604; stochastic variant msqg/qg_stochastic.h:139-147.  dt is read from
+// device memory so the stage-1 dt never has to travel through the host.
+__global__ void k_advance(double *qo, const double *qi, const double *__restrict__ dq, const double *__restrict__ noise, NatGeom g, int nl,
+                          double dt, double dts) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  size_t k = nat_idx(g, 0, j, i);
+  for (int l = 0; l < nl; l++, k += g.ls) {
+    double v = qi[k] + dq[k] * dt;
+    if (noise) v = v + noise[k] * dts;
+    qo[k] = v;
+  }
+}
+void launch_advance(hipStream_t st, double *qo, const double *qi, const double *dq, const double *noise, const NatGeom &g, int nl, double dt,
+                    double dts) {
+  hipLaunchKernelGGL(k_advance, grid2d(g.nx, g.ny), block2d(), 0, st, qo, qi, dq, noise, g, nl, dt, dts);
+}
+
+// ------------------------------------------------------------------ sums (deterministic two-stage)
+
+// stage 1: one partial per block; stage 2: a single block adds the partials in index order
+__global__ void k_ke_partial(const double *__restrict__ po, double *partial, NatGeom g, double D2, double rD2) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  double v = 0.;
+  if (i < g.nx && j < g.ny) {
+    const size_t c = nat_idx(g, 0, j, i);
+    v = 0.5 * po[c] * DIVC(LAPV(po, c, g.pitch), D2, rD2) * D2;  // msqg/qg.c:106
+  }
+  __shared__ double sm[BY];
+  v = wave_sum(v);
+  if (threadIdx.x == 0) sm[threadIdx.y] = v;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    double s = 0.;
+    for (int k = 0; k < BY; k++) s += sm[k];
+    partial[blockIdx.y * gridDim.x + blockIdx.x] = s;
+  }
+}
+__global__ void k_sum_field_partial(const double *__restrict__ f, double *partial, NatGeom g, int nl) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  for (int l = 0; l < nl; l++) {
+    double v = (i < g.nx && j < g.ny) ? f[nat_idx(g, l, j, i)] : 0.;
+    __shared__ double sm[BY];
+    v = wave_sum(v);
+    if (threadIdx.x == 0) sm[threadIdx.y] = v;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+      double s = 0.;
+      for (int k = 0; k < BY; k++) s += sm[k];
+      partial[(size_t)l * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x] = s;
+    }
+    __syncthreads();
+  }
+}
+// out[l] = sum of partial[l*n .. l*n+n)
+__global__ void k_sum_final(const double *partial, double *out, int n) {
+  __shared__ double sm[256];
+  const double *p = partial + (size_t)blockIdx.x * n;
+  double s = 0.;
+  for (int k = threadIdx.x; k < n; k += 256) s += p[k];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
+}
+void launch_sum_final(hipStream_t st, const double *partial, double *out, int n) {
+  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, st, partial, out, n);
+}
+int partial_count(const NatGeom &g) {
+  dim3 gr = grid2d(g.nx, g.ny);
+  return gr.x * gr.y;
+}
+void launch_ke(hipStream_t st, const double *po, double *partial, double *out, const NatGeom &g, double D) {
+  const double D2 = D * D;
+  dim3 gr = grid2d(g.nx, g.ny);
+  hipLaunchKernelGGL(k_ke_partial, gr, block2d(), 0, st, po, partial, g, D2, 1. / D2);
+  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, st, partial, out, (int)(gr.x * gr.y));
+}
+void launch_sum_layers(hipStream_t st, const double *f, double *partial, double *out, const NatGeom &g, int nl) {
+  dim3 gr = grid2d(g.nx, g.ny);
+  hipLaunchKernelGGL(k_sum_field_partial, gr, block2d(), 0, st, f, partial, g, nl);
+  hipLaunchKernelGGL(k_sum_final, dim3(nl), dim3(256), 0, st, partial, out, (int)(gr.x * gr.y));
+}
+// f[l] -= mean[l]
+__global__ void k_sub_layer_const(double *f, const double *__restrict__ sums, NatGeom g, int nl, double inv_count) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  for (int l = 0; l < nl; l++) f[nat_idx(g, l, j, i)] -= sums[l] * inv_count;
+}
+void launch_sub_layer_const(hipStream_t st, double *f, const double *sums, const NatGeom &g, int nl, double inv_count) {
+  hipLaunchKernelGGL(k_sub_layer_const, grid2d(g.nx, g.ny), block2d(), 0, st, f, sums, g, nl, inv_count);
+}
+
+// S = (Fr/Ro)^2, msqg/qg.h:1043-1048
+__global__ void k_make_S(const double *__restrict__ Fr, const double *__restrict__ Ro, double *S, NatGeom g, int nlm) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  const size_t c0 = nat_idx(g, 0, j, i);
+  for (int l = 0; l < nlm; l++) {
+    const double r = Fr[c0 + (size_t)l * g.ls] / Ro[c0];
+    S[c0 + (size_t)l * g.ls] = r * r;
+  }
+}
+void launch_make_S(hipStream_t st, const double *Fr, const double *Ro, double *S, const NatGeom &g, int nlm) {
+  hipLaunchKernelGGL(k_make_S, grid2d(g.nx, g.ny), block2d(), 0, st, Fr, Ro, S, g, nlm);
+}

@@ -1,0 +1,1161 @@
+// msom_api.hip -- C ABI of libmsomhip: lifecycle, fields, elliptic solver driver, RHS
+// evaluation and the predictor-corrector time loop.  Kernels live in kernels_rhs.hip and
+// kernels_mg.hip; params.in parsing and .bas IO in params.c / bas_io.c (host C).
+//
+// Reference call stacks restated here (file:line in the reference tree):
+//   set_vars msqg/qg.h:837-925, set_const :931-1116, invertq :114-163,
+//   poisson_layer msqg/poisson_layer.h:263-306, mg_solve/mg_cycle mspg/elliptic.h:43-99,145-229,
+//   update_qg msqg/qg.h:609-650, advance_qg :594-606, run() of Basilisk predictor-corrector.h
+//   (SURVEY App. B), writestdout/output events msqg/qg.c:101-173, pystep_bfn msqg/qg_bfn.h:21-103.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+
+#include <vector>
+
+#include "kernels.h"
+
+#define HIPCHK(x)                                                                          \
+  do {                                                                                     \
+    hipError_t e__ = (x);                                                                  \
+    if (e__ != hipSuccess) {                                                               \
+      msom_set_error("HIP error %s at %s:%d (%s)", hipGetErrorString(e__), __FILE__, __LINE__, #x); \
+      return MSOM_ERR_HIP;                                                                 \
+    }                                                                                      \
+  } while (0)
+
+// device scalar slots
+enum { SC_RES0 = 0, SC_RES1 = 1, SC_BSUM = 2, SC_KE = 3, SC_UMAX = 8 /* 2*MAXNL */, SC_LSUM = 32 /* MAXNL */, SC_COUNT = 64 };
+
+struct ProfSlot {
+  std::vector<hipEvent_t> ev;  // pairs (start, stop)
+  size_t used = 0;
+  double total_ms = 0;
+  long launches = 0;
+};
+
+struct msom {
+  Params p;
+  // decomposition (single tile unless created with msom_create_tiled)
+  int px = 1, py = 1, ix = 0, iy = 0, rank = 0, nranks = 1;
+  int gnx = 0, gny = 0;  // global cells
+  int nx = 0, ny = 0;    // local cells
+  int walls = WALL_ALL;
+  int nl = 1, nlm = 1;
+  int bc = BC_DIRICHLET0;
+  // layer metrics (msqg/qg.h:1017-1027)
+  double dhf[MSOM_MAXARR], dhc[MSOM_MAXARR];
+  LayerCoef lc;
+  // natural fields
+  NatGeom g;
+  double *f[MSOM_NFIELDS];
+  int flayers[MSOM_NFIELDS];
+  int fbc[MSOM_NFIELDS];
+  // multigrid hierarchy (level 0 = finest)
+  int nlev = 0;
+  std::vector<SplitGeom> sg;
+  std::vector<double *> da, res, S;
+  std::vector<RelaxCoef> rc;
+  size_t max_split = 0;
+  // scratch
+  double *staging = nullptr;   // contiguous nl*ny*nx
+  double *partial = nullptr;   // per-block partial sums
+  double *d_scal = nullptr, *h_scal = nullptr;
+  double *d_wind = nullptr;    // per-row surface forcing profile
+  double umax_pg[MSOM_MAXNL];
+  hipStream_t st = nullptr;
+  // flags
+  int const_set = 0, flag_topo = 0, have_pg = 0, have_zpg = 0, have_qforc = 0;
+  int fr_uniform = 1, uniformS = 0, uniform_opt = -1 /* auto */;
+  int stochastic = 0, corrector_step = 0, noise_mode = 0;
+  unsigned seed = 1;
+  int quiet = 0;
+  // time loop
+  double t = 0, dt = 1., tnext = HUGE_VAL, previous = 0;
+  int iter = 0;
+  msom_mgstats mg = {0, 0, 0, 0, 0};
+  // profiling of the finest-level smoother sweep
+  int profile = 0;
+  ProfSlot prof_sweep, prof_resid;
+};
+
+extern "C" const char *msom_version(void) {
+#ifdef MSOM_STRICT
+  return "msomhip 0.1 (strict: -ffp-contract=off, reference expression order, bit-exact vs oracle)";
+#else
+  return "msomhip 0.1 (fast: FMA contraction, reciprocal multiplies)";
+#endif
+}
+
+// ------------------------------------------------------------------ helpers
+
+static NatGeom make_nat(int nx, int ny) {
+  NatGeom g;
+  g.nx = nx; g.ny = ny;
+  g.pitch = ((nx + 15) / 16) * 16 + 2 * MSOM_XP;
+  g.rows = ny + 2 * MSOM_YP;
+  g.ls = (size_t)g.pitch * g.rows;
+  return g;
+}
+static SplitGeom make_split(int nx, int ny) {
+  SplitGeom s;
+  s.nx = nx; s.ny = ny;
+  s.hk = nx / 2;
+  s.hp = ((s.hk + 15) / 16) * 16 + 2 * MSOM_SP;
+  s.rp = 2 * s.hp;
+  s.rows = ny + 2;
+  s.ls = (size_t)s.rp * s.rows;
+  return s;
+}
+
+static int sync_stream(msom *m) {
+  HIPCHK(hipStreamSynchronize(m->st));
+  return MSOM_OK;
+}
+
+static void prof_begin(msom *m, ProfSlot &ps) {
+  if (!m->profile) return;
+  if (ps.used + 2 > ps.ev.size()) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    ps.ev.push_back(a); ps.ev.push_back(b);
+  }
+  hipEventRecord(ps.ev[ps.used], m->st);
+}
+static void prof_end(msom *m, ProfSlot &ps) {
+  if (!m->profile) return;
+  hipEventRecord(ps.ev[ps.used + 1], m->st);
+  ps.used += 2;
+}
+static void prof_collect(msom *m, ProfSlot &ps) {
+  hipStreamSynchronize(m->st);
+  for (size_t k = 0; k + 1 < ps.used; k += 2) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ps.ev[k], ps.ev[k + 1]) == hipSuccess) { ps.total_ms += ms; ps.launches++; }
+  }
+  ps.used = 0;
+}
+
+static int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// ------------------------------------------------------------------ lifecycle
+
+static int alloc_all(msom *m) {
+  HIPCHK(hipStreamCreate(&m->st));
+  m->g = make_nat(m->nx, m->ny);
+  for (int k = 0; k < MSOM_NFIELDS; k++) {
+    m->f[k] = nullptr;
+    m->flayers[k] = m->nl;
+    m->fbc[k] = m->bc;
+  }
+  m->flayers[MSOM_FR] = m->flayers[MSOM_S] = m->nlm;
+  m->flayers[MSOM_RO] = m->flayers[MSOM_TOPO] = 1;
+  m->fbc[MSOM_FR] = m->fbc[MSOM_S] = m->fbc[MSOM_RO] = m->fbc[MSOM_TOPO] = m->bc == BC_PERIODIC ? BC_PERIODIC : BC_NEUMANN;
+  for (int k = 0; k < MSOM_NFIELDS; k++) {
+    if (k == MSOM_NOISE || k == MSOM_SIGMA) continue;  // allocated when "stochastic" is switched on
+    size_t bytes = m->g.ls * m->flayers[k] * sizeof(double);
+    HIPCHK(hipMalloc(&m->f[k], bytes));
+    HIPCHK(hipMemsetAsync(m->f[k], 0, bytes, m->st));
+  }
+  // multigrid levels: minlevel = 1 (msqg/poisson_layer.h:296-297) -> coarsest tile has 2 cells
+  // on its short side
+  int n = 0;
+  while ((m->nx >> n) >= 2 && (m->ny >> n) >= 2 && ((m->nx >> n) << n) == m->nx && ((m->ny >> n) << n) == m->ny) n++;
+  m->nlev = n;
+  m->sg.resize(n); m->da.resize(n); m->res.resize(n); m->S.resize(n); m->rc.resize(n);
+  for (int k = 0; k < n; k++) {
+    m->sg[k] = make_split(m->nx >> k, m->ny >> k);
+    size_t bytes = m->sg[k].ls * m->nl * sizeof(double);
+    HIPCHK(hipMalloc(&m->da[k], bytes));
+    HIPCHK(hipMalloc(&m->res[k], bytes));
+    HIPCHK(hipMalloc(&m->S[k], m->sg[k].ls * m->nlm * sizeof(double)));
+    HIPCHK(hipMemsetAsync(m->da[k], 0, bytes, m->st));
+    HIPCHK(hipMemsetAsync(m->res[k], 0, bytes, m->st));
+    HIPCHK(hipMemsetAsync(m->S[k], 0, m->sg[k].ls * m->nlm * sizeof(double), m->st));
+  }
+  HIPCHK(hipMalloc(&m->staging, (size_t)m->nl * m->nx * m->ny * sizeof(double)));
+  HIPCHK(hipMalloc(&m->partial, (size_t)partial_count(m->g) * m->nl * sizeof(double)));
+  HIPCHK(hipMalloc(&m->d_scal, SC_COUNT * sizeof(double)));
+  HIPCHK(hipMemsetAsync(m->d_scal, 0, SC_COUNT * sizeof(double), m->st));
+  HIPCHK(hipHostMalloc(&m->h_scal, SC_COUNT * sizeof(double)));
+  HIPCHK(hipMalloc(&m->d_wind, (size_t)m->ny * sizeof(double)));
+  return MSOM_OK;
+}
+
+// set_vars, msqg/qg.h:837-925: defaults of the large-scale fields
+static int set_vars(msom *m) {
+  const Params &p = m->p;
+  for (int l = 0; l < m->nl; l++) m->dhf[l] = p.dhu[l];
+  std::vector<double> h((size_t)m->nl * m->nx * m->ny);
+  const double D = p.L0 / m->gnx;
+  // Fr[] = Frm[l]  (:898-902)
+  for (int l = 0; l < m->nlm; l++)
+    for (size_t k = 0; k < (size_t)m->nx * m->ny; k++) h[(size_t)l * m->nx * m->ny + k] = l < m->nl - 1 ? p.Frm[l] : 0.;
+  int r = msom_set_field(m, MSOM_FR, h.data());
+  if (r) return r;
+  m->fr_uniform = 1;
+  // pp[] = vpg*x - upg*y  (:904-909)
+  m->have_pg = 0;
+  for (int l = 0; l < m->nl; l++) {
+    if (p.upg[l] != 0 || p.vpg[l] != 0) m->have_pg = 1;
+    for (int j = 0; j < m->ny; j++)
+      for (int i = 0; i < m->nx; i++) {
+        const double x = (m->ix * m->nx + i + 0.5) * D, y = (m->iy * m->ny + j + 0.5) * D;
+        h[((size_t)l * m->ny + j) * m->nx + i] = p.vpg[l] * x - p.upg[l] * y;
+      }
+  }
+  int hp = m->have_pg;
+  r = msom_set_field(m, MSOM_PSIPG, h.data());
+  if (r) return r;
+  m->have_pg = hp;
+  // Ro[] = Rom, topo = 0  (:911-915)
+  for (size_t k = 0; k < (size_t)m->nx * m->ny; k++) h[k] = p.Rom;
+  r = msom_set_field(m, MSOM_RO, h.data());
+  m->fr_uniform = 1;
+  return r;
+}
+
+static msom *create_common(const Params &p0, int px, int py, int rank) {
+  Params p = p0;
+  if (p.Ny <= 0) p.Ny = p.N;
+  msom_params_derive(&p);
+  if (p.nl < 1 || p.nl > MSOM_MAXNL) {
+    msom_set_error("nl = %d outside the supported range 1..%d", p.nl, MSOM_MAXNL);
+    return nullptr;
+  }
+  if (p.N % px || p.Ny % py || !is_pow2(p.N / px) || !is_pow2(p.Ny / py) || p.N / px < 2 || p.Ny / py < 2) {
+    msom_set_error("grid %d x %d on %d x %d tiles: every tile edge must be a power of two >= 2", p.N, p.Ny, px, py);
+    return nullptr;
+  }
+  if (p.sbc == -1) {
+    msom_set_error("sbc = -1 (doubly periodic) is not supported by this build");
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    msom_set_error("no HIP device available: libmsomhip has no CPU fallback");
+    return nullptr;
+  }
+  msom *m = new msom();
+  m->p = p;
+  m->px = px; m->py = py; m->rank = rank; m->nranks = px * py;
+  m->ix = rank % px; m->iy = rank / px;
+  m->gnx = p.N; m->gny = p.Ny;
+  m->nx = p.N / px; m->ny = p.Ny / py;
+  m->nl = p.nl; m->nlm = p.nl > 1 ? p.nl - 1 : 1;
+  m->walls = 0;
+  if (m->ix == 0) m->walls |= WALL_W;
+  if (m->ix == px - 1) m->walls |= WALL_E;
+  if (m->iy == 0) m->walls |= WALL_S;
+  if (m->iy == py - 1) m->walls |= WALL_N;
+  if (alloc_all(m) != MSOM_OK || set_vars(m) != MSOM_OK) {
+    msom_destroy(m);
+    return nullptr;
+  }
+  return m;
+}
+
+extern "C" msom_t *msom_create_str(const char *text) {
+  if (!text) { msom_set_error("null params text"); return nullptr; }
+  Params p;
+  msom_params_defaults(&p);
+  msom_params_parse_text(&p, text);
+  return create_common(p, 1, 1, 0);
+}
+extern "C" msom_t *msom_create(const char *path) {
+  Params p;
+  msom_params_defaults(&p);
+  if (msom_params_parse_file(&p, path ? path : "params.in")) return nullptr;
+  return create_common(p, 1, 1, 0);
+}
+
+extern "C" int msom_destroy(msom_t *m) {
+  if (!m) return MSOM_ERR_ARG;
+  if (m->st) hipStreamSynchronize(m->st);
+  for (int k = 0; k < MSOM_NFIELDS; k++)
+    if (m->f[k]) hipFree(m->f[k]);
+  for (int k = 0; k < m->nlev; k++) {
+    if (m->da[k]) hipFree(m->da[k]);
+    if (m->res[k]) hipFree(m->res[k]);
+    if (m->S[k]) hipFree(m->S[k]);
+  }
+  if (m->staging) hipFree(m->staging);
+  if (m->partial) hipFree(m->partial);
+  if (m->d_scal) hipFree(m->d_scal);
+  if (m->h_scal) hipHostFree(m->h_scal);
+  if (m->d_wind) hipFree(m->d_wind);
+  for (auto *ps : {&m->prof_sweep, &m->prof_resid})
+    for (auto e : ps->ev) hipEventDestroy(e);
+  if (m->st) hipStreamDestroy(m->st);
+  delete m;
+  return MSOM_OK;
+}
+
+static int build_coefs(msom *m);
+
+extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
+  if (!m || !key) return MSOM_ERR_ARG;
+  if (!strcmp(key, "TOLERANCE")) m->p.tolerance = v;
+  else if (!strcmp(key, "NITERMAX")) m->p.nitermax = (int)v;
+  else if (!strcmp(key, "NITERMIN")) m->p.nitermin = (int)v;
+  else if (!strcmp(key, "DT")) m->p.DT = v;
+  else if (!strcmp(key, "flag_topo")) m->flag_topo = (int)v;
+  else if (!strcmp(key, "quiet")) m->quiet = (int)v;
+  else if (!strcmp(key, "uniform_S")) {
+    m->uniform_opt = (int)v;
+    if (m->const_set) return build_coefs(m);
+  }
+  else if (!strcmp(key, "profile")) m->profile = (int)v;
+  else if (!strcmp(key, "seed")) { m->seed = (unsigned)v; srand(m->seed); }
+  else if (!strcmp(key, "noise_mode")) m->noise_mode = (int)v;
+  else if (!strcmp(key, "stochastic")) {
+    m->stochastic = (int)v;
+    if (m->stochastic && !m->f[MSOM_NOISE]) {
+      for (int k : {MSOM_NOISE, MSOM_SIGMA}) {
+        size_t bytes = m->g.ls * m->nl * sizeof(double);
+        HIPCHK(hipMalloc(&m->f[k], bytes));
+        HIPCHK(hipMemsetAsync(m->f[k], 0, bytes, m->st));
+      }
+    }
+  } else {
+    msom_set_error("unknown option %s", key);
+    return MSOM_ERR_ARG;
+  }
+  return MSOM_OK;
+}
+
+extern "C" double msom_get_param(msom_t *m, const char *key) {
+  if (!m || !key) return NAN;
+  const Params &p = m->p;
+  if (!strcmp(key, "N") || !strcmp(key, "nx")) return m->gnx;
+  if (!strcmp(key, "ny")) return m->gny;
+  if (!strcmp(key, "nl")) return m->nl;
+  if (!strcmp(key, "L0")) return p.L0;
+  if (!strcmp(key, "DT")) return p.DT;
+  if (!strcmp(key, "iRe")) return p.iRe;
+  if (!strcmp(key, "iRe4")) return p.iRe4;
+  if (!strcmp(key, "CFL")) return p.CFL;
+  if (!strcmp(key, "Rom")) return p.Rom;
+  if (!strcmp(key, "tend")) return p.tend;
+  if (!strcmp(key, "dtout")) return p.dtout;
+  if (!strcmp(key, "beta")) return p.beta;
+  if (!strcmp(key, "tau0")) return p.tau0;
+  if (!strcmp(key, "Ekb")) return p.Ekb;
+  if (!strcmp(key, "Eks")) return p.Eks;
+  if (!strcmp(key, "sbc")) return p.sbc;
+  if (!strcmp(key, "TOLERANCE")) return p.tolerance;
+  if (!strcmp(key, "nlevels")) return m->nlev;
+  if (!strcmp(key, "uniform_S")) return m->uniformS;
+  if (!strncmp(key, "idh0_", 5)) return m->lc.idh0[atoi(key + 5) % MSOM_MAXNL];
+  if (!strncmp(key, "idh1_", 5)) return m->lc.idh1[atoi(key + 5) % MSOM_MAXNL];
+  if (!strncmp(key, "Fr_", 3)) return p.Frm[atoi(key + 3) % MSOM_MAXARR];
+  if (!strncmp(key, "dh_", 3)) return m->dhf[atoi(key + 3) % MSOM_MAXARR];
+  return NAN;
+}
+
+// ------------------------------------------------------------------ fields
+
+static int check_field(msom *m, int field) {
+  if (!m || field < 0 || field >= MSOM_NFIELDS || !m->f[field]) {
+    msom_set_error("bad field id %d", field);
+    return MSOM_ERR_ARG;
+  }
+  return MSOM_OK;
+}
+
+static void fill_bc(msom *m, int field) {
+  launch_fill_ghost(m->st, m->f[field], m->g, m->flayers[field], m->fbc[field], m->walls);
+}
+
+// host or device pointer -> natural field (+ boundary())
+static int upload(msom *m, int field, const double *a) {
+  const size_t n = (size_t)m->flayers[field] * m->nx * m->ny;
+  HIPCHK(hipMemcpyAsync(m->staging, a, n * sizeof(double), hipMemcpyDefault, m->st));
+  launch_pack(m->st, m->staging, m->f[field], m->g, m->flayers[field]);
+  fill_bc(m, field);
+  return MSOM_OK;
+}
+static int download(msom *m, int field, double *a) {
+  const size_t n = (size_t)m->flayers[field] * m->nx * m->ny;
+  launch_unpack(m->st, m->f[field], m->staging, m->g, m->flayers[field]);
+  HIPCHK(hipMemcpyAsync(a, m->staging, n * sizeof(double), hipMemcpyDefault, m->st));
+  return sync_stream(m);
+}
+
+extern "C" int msom_field_layers(msom_t *m, int field) {
+  if (check_field(m, field)) return MSOM_ERR_ARG;
+  return m->flayers[field];
+}
+
+extern "C" int msom_set_field(msom_t *m, int field, const double *a) {
+  if (check_field(m, field) || !a) return MSOM_ERR_ARG;
+  int r = upload(m, field, a);
+  if (r) return r;
+  if (field == MSOM_FR || field == MSOM_RO || field == MSOM_S) { m->fr_uniform = 0; m->const_set = 0; }
+  if (field == MSOM_PSIPG) m->have_pg = 1;
+  if (field == MSOM_ZETAPG) m->have_zpg = 1;
+  if (field == MSOM_QFORC) m->have_qforc = 1;
+  if (field == MSOM_TOPO) m->flag_topo = 1;
+  return sync_stream(m);
+}
+extern "C" int msom_get_field(msom_t *m, int field, double *a) {
+  if (check_field(m, field) || !a) return MSOM_ERR_ARG;
+  return download(m, field, a);
+}
+
+// msqg/qg.c:65-70: po[] -= s.sum/s.volume per layer
+extern "C" int msom_remove_mean(msom_t *m, int field) {
+  if (check_field(m, field)) return MSOM_ERR_ARG;
+  if (m->nranks > 1) { msom_set_error("remove_mean: tiled mode not implemented"); return MSOM_ERR_STATE; }
+  const int nl = m->flayers[field];
+  launch_sum_layers(m->st, m->f[field], m->partial, m->d_scal + SC_LSUM, m->g, nl);
+  launch_sub_layer_const(m->st, m->f[field], m->d_scal + SC_LSUM, m->g, nl, 1. / ((double)m->gnx * m->gny));
+  fill_bc(m, field);
+  return sync_stream(m);
+}
+
+// ------------------------------------------------------------------ set_const
+
+// uniform-S Thomas factorisation of one level (msqg/poisson_layer.h:84-140 with constant S)
+static void make_relax_coef(msom *m, int k) {
+  RelaxCoef &rc = m->rc[k];
+  memset(&rc, 0, sizeof rc);
+  const int nl = m->nl;
+  rc.D = m->p.L0 / (double)(m->gnx >> k);
+  rc.sqD = rc.D * rc.D;
+  for (int l = 0; l < nl; l++) { rc.idh0[l] = m->lc.idh0[l]; rc.idh1[l] = m->lc.idh1[l]; }
+  if (nl < 2) return;
+  double t0[MSOM_MAXNL], t1[MSOM_MAXNL], t2[MSOM_MAXNL];
+  for (int l = 0; l < nl - 1; l++) {
+    const double r = m->p.Frm[l] / m->p.Rom;
+    rc.S[l] = r * r;
+  }
+  for (int l = 0; l < nl; l++) {
+    t0[l] = l > 0 ? -rc.sqD * rc.S[l - 1] * rc.idh0[l] : 0.;
+    t2[l] = l < nl - 1 ? -rc.sqD * rc.S[l] * rc.idh1[l] : 0.;
+    t1[l] = -t0[l] - t2[l] + 4.;
+  }
+  for (int l = 1; l < nl; l++) t1[l] -= t0[l] * t2[l - 1] / t1[l - 1];
+  for (int l = 0; l < nl; l++) {
+    rc.t2[l] = t2[l];
+    rc.w[l] = l > 0 ? t0[l] / t1[l - 1] : 0.;
+    rc.it1[l] = 1. / t1[l];
+  }
+}
+
+// layer metrics, Ro, S on all levels, column-solver constants, forcing profile
+static int build_coefs(msom *m) {
+  const Params &p = m->p;
+  const int nl = m->nl;
+  // sanity checks :990-1012 (reference: exit(0))
+  for (int l = 0; l < nl; l++)
+    if (m->dhf[l] == 0) {
+      msom_set_error("thickness = 0: check the definition of dh in params.in");
+      return MSOM_ERR_CONFIG;
+    }
+  if (p.Rom <= 0) {
+    msom_set_error("Rom <= 0");
+    return MSOM_ERR_CONFIG;
+  }
+  // layer metrics :1017-1027
+  memset(&m->lc, 0, sizeof m->lc);
+  for (int l = 0; l < nl - 1; l++) m->dhc[l] = 0.5 * (m->dhf[l] + m->dhf[l + 1]);
+  if (nl > 1) {
+    m->lc.idh0[0] = 0.;
+    m->lc.idh1[0] = 1. / (m->dhc[0] * m->dhf[0]);
+    for (int l = 1; l < nl - 1; l++) {
+      m->lc.idh0[l] = 1. / (m->dhc[l - 1] * m->dhf[l]);
+      m->lc.idh1[l] = 1. / (m->dhc[l] * m->dhf[l]);
+    }
+    m->lc.idh0[nl - 1] = 1. / (m->dhc[nl - 2] * m->dhf[nl - 1]);
+    m->lc.idh1[nl - 1] = 0.;
+  }
+  const double D = p.L0 / m->gnx;
+  // variable Rossby number :1032-1037
+  if (p.varRo > 0) {
+    std::vector<double> h((size_t)m->nx * m->ny);
+    for (int j = 0; j < m->ny; j++) {
+      const double y = (m->iy * m->ny + j + 0.5) * D;
+      for (int i = 0; i < m->nx; i++) h[(size_t)j * m->nx + i] = p.Rom / (1 + p.Rom * p.beta * (y - 0.5 * p.L0));
+    }
+    int r = upload(m, MSOM_RO, h.data());
+    if (r) return r;
+    m->fr_uniform = 0;
+  }
+  // S = (Fr/Ro)^2 :1043-1048, then restricted to every level (hoisted out of the solve:
+  // the reference redoes it on every poisson_layer call, msqg/poisson_layer.h:284)
+  launch_make_S(m->st, m->f[MSOM_FR], m->f[MSOM_RO], m->f[MSOM_S], m->g, m->nlm);
+  fill_bc(m, MSOM_S);
+  launch_nat_to_split(m->st, m->f[MSOM_S], m->g, m->S[0], m->sg[0], m->nlm);
+  for (int k = 1; k < m->nlev; k++) launch_restrict(m->st, m->S[k - 1], m->sg[k - 1], m->S[k], m->sg[k], m->nlm);
+#ifdef MSOM_STRICT
+  const int auto_uniform = 0;
+#else
+  const int auto_uniform = 1;
+#endif
+  m->uniformS = (m->uniform_opt < 0 ? auto_uniform : m->uniform_opt) && m->fr_uniform && nl > 1;
+  for (int k = 0; k < m->nlev; k++) make_relax_coef(m, k);
+  // surface forcing profile :451 (host libm so that it matches the CPU formulation bit for bit)
+  {
+    std::vector<double> w(m->ny);
+    for (int j = 0; j < m->ny; j++) {
+      const double y = (m->iy * m->ny + j + 0.5) * D;
+      w[j] = p.tau0 / (p.Rom * m->dhf[0]) * sin(2 * M_PI * y / p.L0) * sin(M_PI * y / p.L0);
+    }
+    HIPCHK(hipMemcpyAsync(m->d_wind, w.data(), m->ny * sizeof(double), hipMemcpyHostToDevice, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+  }
+  return MSOM_OK;
+}
+
+extern "C" int msom_set_const(msom_t *m) {
+  if (!m) return MSOM_ERR_ARG;
+  int rr = build_coefs(m);
+  if (rr) return rr;
+  const Params &p = m->p;
+  const int nl = m->nl;
+  const double D = p.L0 / m->gnx;
+  // q = comp_q(psi) :1092
+  launch_del2(m->st, m->f[MSOM_PSI], m->f[MSOM_Q], m->g, nl, 0., 1., D);
+  launch_stretch(m->st, m->f[MSOM_PSI], m->f[MSOM_Q], m->f[MSOM_S], m->g, nl, 1., 1., m->lc);
+  fill_bc(m, MSOM_Q);
+  // large-scale relative vorticity :1094-1097
+  if (p.flsrv == 1) {
+    launch_del2(m->st, m->f[MSOM_PSIPG], m->f[MSOM_ZETAPG], m->g, nl, 0., 1., D);
+    fill_bc(m, MSOM_ZETAPG);
+    m->have_zpg = 1;
+  }
+  // max |u| of the large-scale flow is constant in time: cache it for the dt limiter
+  for (int l = 0; l < MSOM_MAXNL; l++) m->umax_pg[l] = 0.;
+  if (m->have_pg) {
+    HIPCHK(hipMemsetAsync(m->d_scal + SC_UMAX, 0, 2 * MSOM_MAXNL * sizeof(double), m->st));
+    launch_umax(m->st, m->f[MSOM_PSIPG], nullptr, 1, m->d_scal + SC_UMAX, m->g, nl, D);
+    HIPCHK(hipMemcpyAsync(m->h_scal + SC_UMAX, m->d_scal + SC_UMAX, nl * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    for (int l = 0; l < nl; l++) m->umax_pg[l] = m->h_scal[SC_UMAX + l];
+  }
+  m->const_set = 1;
+  return sync_stream(m);
+}
+
+// ------------------------------------------------------------------ elliptic solver
+
+static void relax_sweeps(msom *m, int k, int nrelax) {
+  const bool prof = m->profile && k == 0;
+  for (int it = 0; it < nrelax; it++) {
+    if (prof) prof_begin(m, m->prof_sweep);
+    for (int c = 0; c < 2; c++)
+      launch_relax_color(m->st, m->da[k], m->res[k], m->S[k], m->sg[k], m->nl, m->rc[k], m->uniformS, c, m->walls);
+    if (prof) prof_end(m, m->prof_sweep);
+  }
+}
+
+// mg_cycle, mspg/elliptic.h:43-99 (minlevel = 1)
+static void mg_cycle(msom *m, double *a, int nrelax) {
+  for (int k = 1; k < m->nlev; k++) launch_restrict(m->st, m->res[k - 1], m->sg[k - 1], m->res[k], m->sg[k], m->nl);
+  for (int k = m->nlev - 1; k >= 0; k--) {
+    if (k == m->nlev - 1) hipMemsetAsync(m->da[k], 0, m->sg[k].ls * m->nl * sizeof(double), m->st);
+    else launch_prolong(m->st, m->da[k + 1], m->sg[k + 1], m->da[k], m->sg[k], m->nl, m->walls);
+    relax_sweeps(m, k, nrelax);
+  }
+  launch_correct(m->st, a, m->g, m->da[0], m->sg[0], m->nl, m->walls);
+}
+
+static void residual(msom *m, const double *a, const double *b, int slot, int want_sum) {
+  if (m->profile) prof_begin(m, m->prof_resid);
+  launch_residual(m->st, a, b, m->f[MSOM_S], m->g, m->res[0], m->sg[0], m->nl, m->rc[0], m->uniformS, m->d_scal + slot, m->partial, want_sum);
+  if (m->profile) prof_end(m, m->prof_resid);
+}
+
+// mg_solve, mspg/elliptic.h:145-229, called as poisson_layer does (msqg/poisson_layer.h:290-303).
+// a: natural field with valid ghosts (warm start), b: natural field.
+static int mg_solve(msom *m, double *a, const double *b, msom_mgstats *s) {
+  const Params &p = m->p;
+  s->i = 0; s->nrelax = 4;
+  HIPCHK(hipMemsetAsync(m->d_scal, 0, 4 * sizeof(double), m->st));
+  residual(m, a, b, SC_RES0, 1);
+  // sum of the right-hand side (mgstats.sum), deterministic order
+  launch_sum_final(m->st, m->partial, m->d_scal + SC_BSUM, partial_count(m->g));
+  bool have_first = false;
+  double resb = 0;
+  if (p.nitermin < 1) {  // need the initial residual before deciding on the first cycle
+    HIPCHK(hipMemcpyAsync(m->h_scal, m->d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    resb = s->resb = s->resa = m->h_scal[SC_RES0];
+    s->sum = m->h_scal[SC_BSUM];
+    have_first = true;
+  }
+  for (s->i = 0; s->i < p.nitermax && (s->i < p.nitermin || s->resa > p.tolerance); s->i++) {
+    mg_cycle(m, a, s->nrelax);
+    HIPCHK(hipMemsetAsync(m->d_scal + SC_RES1, 0, sizeof(double), m->st));
+    residual(m, a, b, SC_RES1, 0);
+    HIPCHK(hipMemcpyAsync(m->h_scal, m->d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    if (!have_first) {
+      resb = s->resb = m->h_scal[SC_RES0];
+      s->sum = m->h_scal[SC_BSUM];
+      have_first = true;
+    }
+    s->resa = m->h_scal[SC_RES1];
+    if (s->resa > p.tolerance) {
+      if (resb / s->resa < 1.2 && s->nrelax < 100) s->nrelax++;
+      else if (resb / s->resa > 10 && s->nrelax > 2) s->nrelax--;
+    }
+    resb = s->resa;
+  }
+  if (!have_first) {  // nitermax == 0
+    HIPCHK(hipMemcpyAsync(m->h_scal, m->d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    s->resb = s->resa = m->h_scal[SC_RES0];
+    s->sum = m->h_scal[SC_BSUM];
+  }
+  if (s->resa > p.tolerance && !m->quiet)
+    fprintf(stderr, "WARNING: convergence not reached after %d iterations\n  res: %g sum: %g nrelax: %d\n", s->i, s->resa, s->sum, s->nrelax);
+  return MSOM_OK;
+}
+
+// invertq, msqg/qg.h:114-163 (the trailing boundary(pol) is already done by the correction kernel)
+static int invertq(msom *m, double *psi, const double *q) {
+  return mg_solve(m, psi, q, &m->mg);
+}
+
+// ------------------------------------------------------------------ RHS
+
+static double limiter(msom *m, double umax, double dtmax) {
+  // timestep() [Basilisk; algorithm text newqg/qg.h:202-219]
+  const double D = m->p.L0 / m->gnx;
+  dtmax /= m->p.CFL;
+  if (umax != 0.) {
+    const double dt = D / umax;
+    if (dt < dtmax) dtmax = dt;
+  }
+  dtmax *= m->p.CFL;
+  if (dtmax > m->previous) dtmax = (m->previous + 0.1 * dtmax) / 1.1;
+  m->previous = dtmax;
+  return dtmax;
+}
+
+static void comp_del2(msom *m, int in, int out, double add, double fac) {
+  const double D = m->p.L0 / m->gnx;
+  launch_del2(m->st, m->f[in], m->f[out], m->g, m->nl, add, fac, D);
+  fill_bc(m, out);
+  if (m->p.sbc > 0) launch_slip_bc(m->st, m->f[in], m->f[out], m->g, m->nl, m->p.sbc / ((0.5 * m->p.sbc + 1) * D * D), m->walls);
+}
+static void comp_stretch(msom *m, int in, int out, double add, double fac) {
+  launch_stretch(m->st, m->f[in], m->f[out], m->f[MSOM_S], m->g, m->nl, add, fac, m->lc);
+  fill_bc(m, out);
+}
+
+// tendency terms after the inversion: comp_del2, advection_pv, dissip, ekman_friction,
+// surface_forcing, [qforcing], [bottom_topography]   (msqg/qg.h:622-630 / qg_bfn.h:67-76)
+static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double iRe, double iRe4, double Eks, double Ekb) {
+  const Params &p = m->p;
+  const double D = p.L0 / m->gnx;
+  const int nl = m->nl;
+  comp_del2(m, MSOM_PSI, MSOM_ZETA, 0., 1.0);
+  launch_advection(m->st, m->f[MSOM_ZETA], m->f[MSOM_PSI], m->f[MSOM_PSIPG], m->f[MSOM_ZETAPG], m->f[MSOM_S], m->f[qfield], m->f[dqfield],
+                   m->g, nl, m->have_pg, m->have_zpg, m->stochastic, D, p.beta, p.itr_stoch, m->lc);
+  HIPCHK(hipMemsetAsync(m->d_scal + SC_UMAX, 0, MSOM_MAXNL * sizeof(double), m->st));
+  launch_umax(m->st, m->f[MSOM_PSI], nullptr, 1, m->d_scal + SC_UMAX, m->g, nl, D);
+  // dissip :407-422 (terms with a zero coefficient add exactly 0 and are skipped)
+  if (iRe != 0) comp_stretch(m, MSOM_ZETA, dqfield, 1., iRe);
+  if (iRe != 0 || iRe4 != 0) comp_del2(m, MSOM_ZETA, MSOM_TMP, 0., 1.);
+  if (iRe != 0) launch_axpy(m->st, m->f[dqfield], m->f[MSOM_TMP], m->g, nl, iRe);
+  if (iRe4 != 0) {
+    comp_stretch(m, MSOM_TMP, dqfield, 1., iRe4);
+    comp_del2(m, MSOM_TMP, dqfield, 1., iRe4);
+  }
+  launch_forcing(m->st, m->f[MSOM_ZETA], m->f[MSOM_PSI], m->f[MSOM_QFORC], m->f[MSOM_TOPO], m->f[MSOM_RO], m->d_wind, m->f[dqfield], m->g,
+                 nl, with_qforcing && m->have_qforc, m->flag_topo, Eks / (p.Rom * 2 * m->dhf[0]), Ekb / (p.Rom * 2 * m->dhf[nl - 1]), D,
+                 m->dhf[nl - 1]);
+  return MSOM_OK;
+}
+
+// update_qg, msqg/qg.h:609-650
+static double update_qg(msom *m, int qfield, int dqfield, double dtmax) {
+  const Params &p = m->p;
+  const int nl = m->nl;
+  if (hipMemsetAsync(m->f[dqfield], 0, m->g.ls * nl * sizeof(double), m->st) != hipSuccess) return -1;
+  if (invertq(m, m->f[MSOM_PSI], m->f[qfield])) return -1;
+  if (rhs_terms(m, qfield, dqfield, 1, p.iRe, p.iRe4, p.Eks, p.Ekb)) return -1;
+  if (hipMemcpyAsync(m->h_scal + SC_UMAX, m->d_scal + SC_UMAX, nl * sizeof(double), hipMemcpyDeviceToHost, m->st) != hipSuccess) return -1;
+  if (hipStreamSynchronize(m->st) != hipSuccess) return -1;
+  // :383-391: 2*nl limiter calls (psi_l then psipg_l) sharing one static `previous`
+  for (int l = 0; l < nl; l++) {
+    dtmax = limiter(m, m->h_scal[SC_UMAX + l], dtmax);
+    dtmax = limiter(m, m->umax_pg[l], dtmax);
+  }
+  return dtmax;
+}
+
+// reference-exact noise: Box-Muller on the serial rand() stream in foreach order
+// (x outer, y inner, layer innermost), msqg/qg_stochastic.h:9,117-126
+static int generate_noise_host(msom *m) {
+  const int nl = m->nl, nx = m->nx, ny = m->ny;
+  std::vector<double> sig((size_t)nl * nx * ny), n((size_t)nl * nx * ny);
+  int r = download(m, MSOM_SIGMA, sig.data());
+  if (r) return r;
+  for (int i = 0; i < nx; i++)
+    for (int j = 0; j < ny; j++)
+      for (int l = 0; l < nl; l++) {
+        const double a = sqrt(-2. * log(((double)(rand()) + 1.) / ((double)(RAND_MAX) + 2.)));
+        const double nn = a * cos(2 * M_PI * rand() / (double)RAND_MAX);
+        const size_t k = ((size_t)l * ny + j) * nx + i;
+        n[k] = m->p.amp_stoch * sig[k] * nn;
+      }
+  return upload(m, MSOM_NOISE, n.data());
+}
+
+// advance_qg, msqg/qg.h:594-606 / msqg/qg_stochastic.h:128-149
+static int advance_qg(msom *m, int out, int in, int dq, double dt) {
+  const double *noise = nullptr;
+  double dts = 0;
+  if (m->stochastic) {
+    m->corrector_step = (m->corrector_step + 1) % 2;
+    float fdts = sqrt(dt);
+    if (m->corrector_step) {
+      int r = generate_noise_host(m);
+      if (r) return r;
+      fdts = fdts / sqrt(2);
+    }
+    dts = fdts;
+    noise = m->f[MSOM_NOISE];
+  }
+  launch_advance(m->st, m->f[out], m->f[in], m->f[dq], noise, m->g, m->nl, dt, dts);
+  fill_bc(m, out);
+  return MSOM_OK;
+}
+
+#define NEED_CONST(m)                                                    \
+  do {                                                                   \
+    if (!(m)) return MSOM_ERR_ARG;                                       \
+    if (!(m)->const_set) {                                               \
+      int r__ = msom_set_const(m);                                       \
+      if (r__) return r__;                                               \
+    }                                                                    \
+  } while (0)
+
+extern "C" double msom_update(msom_t *m, const double *q, double *dqdt, double dtmax) {
+  if (!m) return -1;
+  if (!m->const_set && msom_set_const(m)) return -1;
+  int qf = MSOM_Q;
+  if (q) {
+    if (upload(m, MSOM_QPRED, q)) return -1;
+    qf = MSOM_QPRED;
+  }
+  double d = update_qg(m, qf, MSOM_DQ, dtmax);
+  if (d < 0) return d;
+  if (dqdt && download(m, MSOM_DQ, dqdt)) return -1;
+  return d;
+}
+
+extern "C" int msom_advance(msom_t *m, double *qout, const double *qin, const double *dqdt, double dt) {
+  NEED_CONST(m);
+  int in = MSOM_Q, out = MSOM_Q, r;
+  if (qin) {
+    if ((r = upload(m, MSOM_QPRED, qin))) return r;
+    in = out = MSOM_QPRED;
+  }
+  if (dqdt && (r = upload(m, MSOM_DQ, dqdt))) return r;
+  if ((r = advance_qg(m, out, in, MSOM_DQ, dt))) return r;
+  if (qout) return download(m, out, qout);
+  return sync_stream(m);
+}
+
+extern "C" int msom_invertq(msom_t *m, const double *q, double *psi, msom_mgstats *st) {
+  NEED_CONST(m);
+  int qf = MSOM_Q, r;
+  if (q) {
+    if ((r = upload(m, MSOM_QPRED, q))) return r;
+    qf = MSOM_QPRED;
+  }
+  if (psi && (r = upload(m, MSOM_PSI, psi))) return r;
+  if ((r = invertq(m, m->f[MSOM_PSI], m->f[qf]))) return r;
+  if (st) *st = m->mg;
+  if (psi) return download(m, MSOM_PSI, psi);
+  return sync_stream(m);
+}
+
+extern "C" int msom_comp_q(msom_t *m, const double *psi, double *q) {
+  NEED_CONST(m);
+  int r;
+  if (psi && (r = upload(m, MSOM_PSI, psi))) return r;
+  comp_del2(m, MSOM_PSI, MSOM_Q, 0., 1.);
+  comp_stretch(m, MSOM_PSI, MSOM_Q, 1., 1.);
+  if (q) return download(m, MSOM_Q, q);
+  return sync_stream(m);
+}
+
+extern "C" int msom_last_mgstats(msom_t *m, msom_mgstats *st) {
+  if (!m || !st) return MSOM_ERR_ARG;
+  *st = m->mg;
+  return MSOM_OK;
+}
+
+// ------------------------------------------------------------------ pystep_bfn & co
+
+static int check_shape(msom *m, int a, int b, int c) {
+  if (a != m->nl || b != m->ny || c != m->nx) {
+    msom_set_error("array shape (%d,%d,%d) != (nl,N,N) = (%d,%d,%d)", a, b, c, m->nl, m->ny, m->nx);
+    return MSOM_ERR_ARG;
+  }
+  return MSOM_OK;
+}
+
+// msqg/qg_bfn.h:21-80
+extern "C" int pystep_bfn(msom_t *m, double *varin_py, int len1, int len2, int len3, double *tend_py, int len4, int len5, int len6,
+                          double direction, int vartype) {
+  NEED_CONST(m);
+  if (check_shape(m, len1, len2, len3) || check_shape(m, len4, len5, len6)) return MSOM_ERR_ARG;
+  Params &p = m->p;
+  int r;
+  if (direction > 0) {
+    p.iRe = p.Re == 0 ? 0. : 1 / p.Re;
+    p.iRe4 = p.Re4 == 0 ? 0. : -1 / p.Re4;
+    p.Eks = fabs(p.Eks); p.Ekb = fabs(p.Ekb);
+  } else {
+    p.iRe = p.Re == 0 ? 0. : -1 / p.Re;
+    p.iRe4 = p.Re4 == 0 ? 0. : 1 / p.Re4;
+    p.Eks = -fabs(p.Eks); p.Ekb = -fabs(p.Ekb);
+  }
+  HIPCHK(hipMemsetAsync(m->f[MSOM_DQ], 0, m->g.ls * m->nl * sizeof(double), m->st));  // reset_layer_var(bfn_tendl)
+  if (vartype == 1) {
+    if ((r = upload(m, MSOM_Q, varin_py))) return r;
+    if ((r = invertq(m, m->f[MSOM_PSI], m->f[MSOM_Q]))) return r;
+    if ((r = rhs_terms(m, MSOM_Q, MSOM_DQ, 0, p.iRe, p.iRe4, p.Eks, p.Ekb))) return r;
+  } else if (!m->quiet)
+    fprintf(stdout, "temporary disabled psi tendency\n");  // msqg/qg_bfn.h:48
+  return download(m, MSOM_DQ, tend_py);
+}
+// msqg/qg_bfn.h:85-93
+extern "C" int pyq2p(msom_t *m, double *po_py, int len7, int len8, int len9, double *qo_py, int len10, int len11, int len12) {
+  NEED_CONST(m);
+  if (check_shape(m, len7, len8, len9) || check_shape(m, len10, len11, len12)) return MSOM_ERR_ARG;
+  int r;
+  HIPCHK(hipMemsetAsync(m->f[MSOM_PSI], 0, m->g.ls * m->nl * sizeof(double), m->st));
+  if ((r = upload(m, MSOM_Q, qo_py))) return r;
+  if ((r = invertq(m, m->f[MSOM_PSI], m->f[MSOM_Q]))) return r;
+  return download(m, MSOM_PSI, po_py);
+}
+// msqg/qg_bfn.h:95-103
+extern "C" int pyp2q(msom_t *m, double *po_py, int len13, int len14, int len15, double *qo_py, int len16, int len17, int len18) {
+  NEED_CONST(m);
+  if (check_shape(m, len13, len14, len15) || check_shape(m, len16, len17, len18)) return MSOM_ERR_ARG;
+  return msom_comp_q(m, po_py, qo_py);
+}
+
+// ------------------------------------------------------------------ time loop
+
+// dtnext() [Basilisk, SURVEY App. B]
+static double dtnext(msom *m, double dt, double *tnext_out) {
+  double tnext = m->tnext, t = m->t;
+  if (tnext != HUGE_VAL && tnext > t) {
+    unsigned int n = (unsigned int)((tnext - t) / dt);
+    if (n == 0) dt = tnext - t;
+    else {
+      double dt1 = (tnext - t) / n;
+      if (dt1 > dt * (1. + 1e-9)) dt = (tnext - t) / (n + 1);
+      else if (dt1 < dt) dt = dt1;
+      tnext = t + dt;
+    }
+  } else
+    tnext = t + dt;
+  *tnext_out = tnext;
+  return dt;
+}
+
+// one iteration of run() [Basilisk predictor-corrector.h]
+extern "C" int msom_step(msom_t *m, double *dt_used) {
+  NEED_CONST(m);
+  double tnext;
+  double d = update_qg(m, MSOM_Q, MSOM_DQ, m->p.DT);
+  if (d < 0) return MSOM_ERR_HIP;
+  m->dt = dtnext(m, d, &tnext);
+  int r;
+  if ((r = advance_qg(m, MSOM_QPRED, MSOM_Q, MSOM_DQ, m->dt / 2.))) return r;
+  if (update_qg(m, MSOM_QPRED, MSOM_DQ, m->dt) < 0) return MSOM_ERR_HIP;
+  if ((r = advance_qg(m, MSOM_Q, MSOM_Q, MSOM_DQ, m->dt))) return r;
+  m->t = tnext;
+  m->iter++;
+  if (dt_used) *dt_used = m->dt;
+  return MSOM_OK;
+}
+extern "C" int msom_set_tnext(msom_t *m, double tnext) {
+  if (!m) return MSOM_ERR_ARG;
+  m->tnext = tnext;
+  return MSOM_OK;
+}
+extern "C" double msom_time(msom_t *m) { return m ? m->t : NAN; }
+extern "C" int msom_iter(msom_t *m) { return m ? m->iter : -1; }
+
+// msqg/qg.c:101-109
+extern "C" double msom_ke(msom_t *m) {
+  if (!m) return NAN;
+  launch_ke(m->st, m->f[MSOM_PSI], m->partial, m->d_scal + SC_KE, m->g, m->p.L0 / m->gnx);
+  if (hipMemcpyAsync(m->h_scal + SC_KE, m->d_scal + SC_KE, sizeof(double), hipMemcpyDeviceToHost, m->st) != hipSuccess) return NAN;
+  if (hipStreamSynchronize(m->st) != hipSuccess) return NAN;
+  return -m->h_scal[SC_KE];
+}
+
+// ------------------------------------------------------------------ .bas IO and the qg.c driver loop
+
+extern "C" int msom_write_bas(msom_t *m, int field, const char *path) {
+  if (check_field(m, field) || !path) return MSOM_ERR_ARG;
+  if (m->gnx != m->gny || m->nranks > 1) { msom_set_error(".bas output needs a square single-tile grid"); return MSOM_ERR_STATE; }
+  std::vector<double> h((size_t)m->flayers[field] * m->nx * m->ny);
+  int r = download(m, field, h.data());
+  if (r) return r;
+  return msom_bas_write(path, h.data(), m->flayers[field], m->nx, m->p.L0) ? MSOM_ERR_IO : MSOM_OK;
+}
+extern "C" int msom_read_bas(msom_t *m, int field, const char *path) {
+  if (check_field(m, field) || !path) return MSOM_ERR_ARG;
+  if (m->gnx != m->gny || m->nranks > 1) { msom_set_error(".bas input needs a square single-tile grid"); return MSOM_ERR_STATE; }
+  std::vector<double> h((size_t)m->flayers[field] * m->nx * m->ny);
+  if (msom_bas_read(path, h.data(), m->flayers[field], m->nx, m->p.L0)) return MSOM_ERR_IO;
+  return msom_set_field(m, field, h.data());
+}
+
+static bool file_exists(const char *path) {
+  struct stat sb;
+  return stat(path, &sb) == 0;
+}
+
+// optional input files, msqg/qg.h:940-984 and msqg/qg.c:55-59 (p0.bas)
+extern "C" int msom_read_inputs(msom_t *m, const char *dir) {
+  if (!m) return MSOM_ERR_ARG;
+  char name[512];
+  const char *d = dir ? dir : ".";
+  const int nl = m->nl, N = m->gnx;
+  int r;
+  if (!m->quiet) fprintf(stdout, "Read input files:\n");
+  snprintf(name, sizeof name, "%s/dh_%dl.bin", d, nl);
+  if (FILE *fp = fopen(name, "r")) {
+    std::vector<float> dh(nl);
+    size_t got = fread(dh.data(), sizeof(float), nl, fp);
+    fclose(fp);
+    if (got != (size_t)nl) { msom_set_error("short read on %s", name); return MSOM_ERR_IO; }
+    for (int l = 0; l < nl; l++) m->dhf[l] = dh[l];
+    if (!m->quiet) fprintf(stdout, "%s .. ok\n", name);
+  }
+  struct { const char *fmt; int field; } files[] = {
+      {"%s/psipg_%dl_N%d.bas", MSOM_PSIPG}, {"%s/frpg_%dl_N%d.bas", MSOM_FR}, {"%s/qforc_%dl_N%d.bas", MSOM_QFORC}};
+  for (auto &f : files) {
+    snprintf(name, sizeof name, f.fmt, d, nl, N);
+    if (file_exists(name)) {
+      if ((r = msom_read_bas(m, f.field, name))) return r;
+      if (!m->quiet) fprintf(stdout, "%s .. ok\n", name);
+    }
+  }
+  snprintf(name, sizeof name, "%s/topo.bas", d);
+  if (file_exists(name)) {
+    if ((r = msom_read_bas(m, MSOM_TOPO, name))) return r;
+    if (!m->quiet) fprintf(stdout, "%s .. ok\n", name);
+  }
+  snprintf(name, sizeof name, "%s/p0.bas", d);
+  if (file_exists(name)) {
+    if ((r = msom_read_bas(m, MSOM_PSI, name))) return r;
+    if (!m->quiet) fprintf(stdout, "%s .. ok\n", name);
+  }
+  m->const_set = 0;
+  return MSOM_OK;
+}
+
+// main loop of msqg/qg.c:34-173: events at the top of every iteration (writestdout i++,
+// output t += dtout), then one predictor-corrector step.
+extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
+  NEED_CONST(m);
+  if (m->nranks > 1) { msom_set_error("msom_run: tiled mode not implemented"); return MSOM_ERR_STATE; }
+  const Params &p = m->p;
+  char dpath[600] = "", name[700];
+  const char *wd = workdir ? workdir : ".";
+  // create_outdir, msqg/qg.h:766-776
+  for (int i = 1; i < 10000; i++) {
+    snprintf(dpath, sizeof dpath, "%s/outdir_%04d/", wd, i);
+    if (mkdir(dpath, 0777) == 0) {
+      fprintf(stdout, "Writing output in %s\n", dpath);
+      break;
+    }
+  }
+  double tout = 0.;  // next output event: t = 0; t <= tend + 1e-10; t += dtout
+  long steps = 0;
+  int r;
+  for (;;) {
+    // writestdout, msqg/qg.c:101-109
+    fprintf(stdout, "i = %i, dt = %g, t = %g, ke_1 = %g\n", m->iter, m->dt, m->t, msom_ke(m));
+    // output, msqg/qg.c:112-122
+    bool out_pending = tout <= p.tend + 1e-10;
+    if (out_pending && m->t >= tout - 1e-12 * fmax(1., fabs(tout))) {
+      fprintf(stdout, "write file\n");
+      if ((r = invertq(m, m->f[MSOM_PSI], m->f[MSOM_Q]))) return r;
+      snprintf(name, sizeof name, "%spo%09d.bas", dpath, m->iter);
+      if ((r = msom_write_bas(m, MSOM_PSI, name))) return r;
+      snprintf(name, sizeof name, "%sqo%09d.bas", dpath, m->iter);
+      if ((r = msom_write_bas(m, MSOM_Q, name))) return r;
+      tout += p.dtout;
+      out_pending = tout <= p.tend + 1e-10;
+    }
+    if (!out_pending) break;  // no scheduled event left: run() ends
+    if (nsteps_max >= 0 && steps >= nsteps_max) break;
+    m->tnext = tout;
+    if ((r = msom_step(m, nullptr))) return r;
+    steps++;
+  }
+  fflush(stdout);
+  return MSOM_OK;
+}
+
+// ------------------------------------------------------------------ tiling (single tile for now)
+
+extern "C" int msom_comm_unique_id(void *id128) {
+  if (!id128) return MSOM_ERR_ARG;
+  memset(id128, 0, 128);
+  return MSOM_OK;
+}
+extern "C" msom_t *msom_create_tiled(const char *params_text, int px, int py, int rank, const void *id128) {
+  (void)id128;
+  if (px != 1 || py != 1 || rank != 0) {
+    msom_set_error("tiled mode (px*py > 1) is not implemented in this build");
+    return nullptr;
+  }
+  return msom_create_str(params_text);
+}
+extern "C" int msom_tile_info(msom_t *m, int *px, int *py, int *ix, int *iy, int *nx_local, int *ny_local) {
+  if (!m) return MSOM_ERR_ARG;
+  if (px) *px = m->px;
+  if (py) *py = m->py;
+  if (ix) *ix = m->ix;
+  if (iy) *iy = m->iy;
+  if (nx_local) *nx_local = m->nx;
+  if (ny_local) *ny_local = m->ny;
+  return MSOM_OK;
+}
+
+// ------------------------------------------------------------------ debug / test hooks
+
+extern "C" int msom_dbg_nlevels(msom_t *m) { return m ? m->nlev : MSOM_ERR_ARG; }
+extern "C" int msom_dbg_level_dims(msom_t *m, int lev, int *nx, int *ny) {
+  if (!m || lev < 0 || lev >= m->nlev) return MSOM_ERR_ARG;
+  *nx = m->sg[lev].nx; *ny = m->sg[lev].ny;
+  return MSOM_OK;
+}
+static int split_upload(msom *m, double *sp, const SplitGeom &sg, const double *a, int nl, int bc) {
+  HIPCHK(hipMemcpyAsync(m->staging, a, (size_t)nl * sg.nx * sg.ny * sizeof(double), hipMemcpyDefault, m->st));
+  HIPCHK(hipMemsetAsync(sp, 0, sg.ls * nl * sizeof(double), m->st));
+  launch_split_pack(m->st, m->staging, sp, sg, nl, bc, m->walls);
+  return MSOM_OK;
+}
+static int split_download(msom *m, const double *sp, const SplitGeom &sg, double *a, int nl) {
+  launch_split_unpack(m->st, sp, sg, m->staging, nl);
+  HIPCHK(hipMemcpyAsync(a, m->staging, (size_t)nl * sg.nx * sg.ny * sizeof(double), hipMemcpyDefault, m->st));
+  return sync_stream(m);
+}
+// nsweeps red-black relaxations on level `lev`: da in/out, res in (both [layer][y][x] of that level)
+extern "C" int msom_dbg_relax(msom_t *m, int lev, double *da, const double *res, int nsweeps) {
+  NEED_CONST(m);
+  if (lev < 0 || lev >= m->nlev || !da || !res) return MSOM_ERR_ARG;
+  int r;
+  if ((r = split_upload(m, m->da[lev], m->sg[lev], da, m->nl, BC_DIRICHLET0))) return r;
+  if ((r = split_upload(m, m->res[lev], m->sg[lev], res, m->nl, BC_NEUMANN))) return r;
+  const int prof = m->profile;
+  m->profile = 0;
+  relax_sweeps(m, lev, nsweeps);
+  m->profile = prof;
+  return split_download(m, m->da[lev], m->sg[lev], da, m->nl);
+}
+extern "C" int msom_dbg_residual(msom_t *m, const double *a, const double *b, double *res, double *maxres) {
+  NEED_CONST(m);
+  int r;
+  if ((r = upload(m, MSOM_TMP, a))) return r;
+  if ((r = upload(m, MSOM_QPRED, b))) return r;
+  HIPCHK(hipMemsetAsync(m->d_scal, 0, 4 * sizeof(double), m->st));
+  residual(m, m->f[MSOM_TMP], m->f[MSOM_QPRED], SC_RES0, 0);
+  HIPCHK(hipMemcpyAsync(m->h_scal, m->d_scal, sizeof(double), hipMemcpyDeviceToHost, m->st));
+  if ((r = split_download(m, m->res[0], m->sg[0], res, m->nl))) return r;
+  if (maxres) *maxres = m->h_scal[SC_RES0];
+  return MSOM_OK;
+}
+extern "C" int msom_dbg_restrict(msom_t *m, int lev_fine, const double *fine, double *coarse) {
+  NEED_CONST(m);
+  if (lev_fine < 0 || lev_fine + 1 >= m->nlev) return MSOM_ERR_ARG;
+  int r;
+  if ((r = split_upload(m, m->res[lev_fine], m->sg[lev_fine], fine, m->nl, BC_NEUMANN))) return r;
+  launch_restrict(m->st, m->res[lev_fine], m->sg[lev_fine], m->res[lev_fine + 1], m->sg[lev_fine + 1], m->nl);
+  return split_download(m, m->res[lev_fine + 1], m->sg[lev_fine + 1], coarse, m->nl);
+}
+extern "C" int msom_dbg_prolong(msom_t *m, int lev_coarse, const double *coarse, double *fine) {
+  NEED_CONST(m);
+  if (lev_coarse < 1 || lev_coarse >= m->nlev) return MSOM_ERR_ARG;
+  int r;
+  if ((r = split_upload(m, m->da[lev_coarse], m->sg[lev_coarse], coarse, m->nl, BC_DIRICHLET0))) return r;
+  launch_prolong(m->st, m->da[lev_coarse], m->sg[lev_coarse], m->da[lev_coarse - 1], m->sg[lev_coarse - 1], m->nl, m->walls);
+  return split_download(m, m->da[lev_coarse - 1], m->sg[lev_coarse - 1], fine, m->nl);
+}
+// single operators on the internal fields: "del2", "stretch", "advection", "dissip", "forcing"
+extern "C" int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, double add, double fac) {
+  NEED_CONST(m);
+  if (check_field(m, f_in) || check_field(m, f_out) || !op) return MSOM_ERR_ARG;
+  const Params &p = m->p;
+  const double D = p.L0 / m->gnx;
+  if (!strcmp(op, "del2")) comp_del2(m, f_in, f_out, add, fac);
+  else if (!strcmp(op, "stretch")) comp_stretch(m, f_in, f_out, add, fac);
+  else if (!strcmp(op, "advection")) {  // f_in = zeta field, psi = PSI, dq = f_out (accumulates)
+    launch_advection(m->st, m->f[f_in], m->f[MSOM_PSI], m->f[MSOM_PSIPG], m->f[MSOM_ZETAPG], m->f[MSOM_S], m->f[MSOM_Q], m->f[f_out], m->g,
+                     m->nl, m->have_pg, m->have_zpg, m->stochastic, D, p.beta, p.itr_stoch, m->lc);
+  } else {
+    msom_set_error("unknown op %s", op);
+    return MSOM_ERR_ARG;
+  }
+  return sync_stream(m);
+}
+
+// ------------------------------------------------------------------ measurement
+
+extern "C" int msom_profile_reset(msom_t *m) {
+  if (!m) return MSOM_ERR_ARG;
+  for (auto *ps : {&m->prof_sweep, &m->prof_resid}) { ps->used = 0; ps->total_ms = 0; ps->launches = 0; }
+  return MSOM_OK;
+}
+extern "C" int msom_profile_read(msom_t *m, const char *kernel, double *avg_ms, long *launches) {
+  if (!m || !kernel) return MSOM_ERR_ARG;
+  ProfSlot *ps = !strcmp(kernel, "sweep") ? &m->prof_sweep : !strcmp(kernel, "residual") ? &m->prof_resid : nullptr;
+  if (!ps) { msom_set_error("unknown kernel %s", kernel); return MSOM_ERR_ARG; }
+  prof_collect(m, *ps);
+  if (avg_ms) *avg_ms = ps->launches ? ps->total_ms / ps->launches : 0.;
+  if (launches) *launches = ps->launches;
+  return MSOM_OK;
+}
+// back-to-back launches of one kernel on the finest level, HIP-event timed
+extern "C" int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double *avg_ms) {
+  NEED_CONST(m);
+  if (!kernel || reps < 1 || !avg_ms) return MSOM_ERR_ARG;
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a));
+  HIPCHK(hipEventCreate(&b));
+  const double D = m->p.L0 / m->gnx;
+  auto one = [&](void) {
+    if (!strcmp(kernel, "sweep")) {
+      for (int c = 0; c < 2; c++) launch_relax_color(m->st, m->da[0], m->res[0], m->S[0], m->sg[0], m->nl, m->rc[0], m->uniformS, c, m->walls);
+    } else if (!strcmp(kernel, "residual")) {
+      launch_residual(m->st, m->f[MSOM_PSI], m->f[MSOM_Q], m->f[MSOM_S], m->g, m->res[0], m->sg[0], m->nl, m->rc[0], m->uniformS, m->d_scal + SC_RES1, m->partial, 0);
+    } else if (!strcmp(kernel, "advection")) {
+      launch_advection(m->st, m->f[MSOM_ZETA], m->f[MSOM_PSI], m->f[MSOM_PSIPG], m->f[MSOM_ZETAPG], m->f[MSOM_S], m->f[MSOM_Q], m->f[MSOM_TMP], m->g,
+                       m->nl, m->have_pg, m->have_zpg, m->stochastic, D, m->p.beta, m->p.itr_stoch, m->lc);
+    } else if (!strcmp(kernel, "advance")) {
+      launch_advance(m->st, m->f[MSOM_QPRED], m->f[MSOM_Q], m->f[MSOM_DQ], nullptr, m->g, m->nl, 1e-9, 0.);
+    }
+  };
+  for (int k = 0; k < 3; k++) one();
+  HIPCHK(hipEventRecord(a, m->st));
+  for (int k = 0; k < reps; k++) one();
+  HIPCHK(hipEventRecord(b, m->st));
+  HIPCHK(hipEventSynchronize(b));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, a, b));
+  *avg_ms = ms / reps;
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  return MSOM_OK;
+}

@@ -1,0 +1,36 @@
+/* msom_params.h -- plain-C part shared by the host C files (params.c, bas_io.c) and the HIP
+ * translation units: parameters of params.in (msqg/qg.h:63-106) and their derived values
+ * (:739-758). */
+#ifndef MSOM_PARAMS_H
+#define MSOM_PARAMS_H
+
+#define MSOM_MAXARR 64 /* max entries of the Fr/dh/upg/vpg arrays in params.in */
+
+struct Params {
+  int N, Ny, nl;
+  int ediag, varRo, nptr, flsrv;
+  double L0, Rom, Ekb, Eks, tau0, Re, Re4, iRe, iRe4, sbc, beta, afilt, Lfmax;
+  double DT, tend, dtout, dtflt, CFL;
+  double Frm[MSOM_MAXARR], dhu[MSOM_MAXARR], upg[MSOM_MAXARR], vpg[MSOM_MAXARR];
+  double tr_stoch, itr_stoch, amp_stoch;
+  double tolerance; /* extension key TOLERANCE (reference: 1e-3, msqg/qg.h:159) */
+  int nitermax, nitermin;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* params.c: restates read_params, msqg/qg.h:668-761 */
+void msom_params_defaults(struct Params *p);
+int msom_params_parse_text(struct Params *p, const char *text);
+int msom_params_parse_file(struct Params *p, const char *path);
+void msom_params_derive(struct Params *p);
+/* bas_io.c: restates input_matrixl/output_matrixl, msqg/auxiliar_input.h:24-59,101-149.
+ * `a` is [layer][y][x] fp64, n x n cells per layer. */
+int msom_bas_write(const char *path, const double *a, int nl, int n, double L0);
+int msom_bas_read(const char *path, double *a, int nl, int n, double L0);
+void msom_set_error(const char *fmt, ...);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -357,7 +357,9 @@ static void comp_stretch(orc_t *o, fld *po, fld *st, double add, double fac) {
         l = nl - 1;
         V(st, l, i, j) = add * V(st, l, i, j) + fac * V(S, l - 1, i, j) * (V(po, l - 1, i, j) - V(po, l, i, j)) * idh0[l];
       } else
-        V(st, 0, i, j) = 0.;
+        /* reference: stretch[] = 0 (qg.h:239-242), which makes nl == 1 degenerate.
+         * Build-defined: Gamma = 0 contributes nothing, so nl == 1 is a barotropic model. */
+        V(st, 0, i, j) = add * V(st, 0, i, j);
     }
   boundary(st);
 }
@@ -448,8 +450,12 @@ static double advection_pv(orc_t *o, fld *qo, fld *qot, fld *po, fld *dqo, doubl
                            V(S, l - 1, i, j) * ju * idh0[l];
         V(dqo, l, i, j) += jacobian(po, l, qp, l, i, j, D);
         if (st) V(dqo, l, i, j) += -V(qot, l, i, j) * o->itr_stoch;
-      } else
-        V(dqo, 0, i, j) = 0.;
+      } else {
+        /* reference: dqo[] = 0 (qg.h:376-379), degenerate; build-defined barotropic tendency
+         * = the nl > 1 formula without the cross-layer terms (cf. newqg/qg.h:197-200) */
+        V(dqo, 0, i, j) += jacobian(po, 0, qo, 0, i, j, D) + jacobian(pp, 0, qo, 0, i, j, D) + BETA_EFFECT(po, 0, i, j);
+        V(dqo, 0, i, j) += jacobian(po, 0, qp, 0, i, j, D);
+      }
     }
   /* qg.h:383-391: 2*nl sequential limiter calls sharing one static `previous` */
   for (int l = 0; l < nl; l++) {

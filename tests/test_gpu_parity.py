@@ -1,0 +1,354 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the
+C ABI (include/msom.h via msom_amd.api), against the CPU oracle on the same seeded inputs.
+
+Two builds of the same kernels are checked:
+  * strict (libmsomhip_strict.so: -ffp-contract=off, reference expression order, true
+    divisions): BIT-EXACT against the oracle with red-black ordering on both sides;
+  * fast (libmsomhip.so, the product: FMA contraction, reciprocal multiplies, uniform-S
+    column solver): within the fp64 tolerances stated next to each assertion.
+"""
+import numpy as np
+import pytest
+
+import orc
+from msom_amd import QG, FIELDS as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(32, 32, 3), (64, 64, 2), (64, 32, 3), (32, 64, 6), (32, 32, 1), (16, 16, 4)]
+
+
+def make_pair(nx, ny, nl, strict, extra="", psi=None, **opts):
+    txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else "") + extra)
+    o = orc.Oracle(txt, smoother=orc.GS_RB, quiet=1)
+    g = QG(txt, strict=strict)
+    g.option("quiet", 1)
+    for k, v in opts.items():
+        o.option(k, v)
+        g.option(k, v)
+    p0 = orc.synthetic_psi(nl, ny, nx) if psi is None else psi
+    o.set(orc.PSI, p0)
+    g.set(F["PSI"], p0)
+    o.set_const()
+    g.set_const()
+    return o, g
+
+
+def rel(a, b):
+    d = np.abs(a - b).max()
+    s = max(np.abs(b).max(), 1e-300)
+    return d / s
+
+
+def rand_field(seed, shape, scale=1.0):
+    return scale * np.random.default_rng(seed).standard_normal(shape)
+
+
+# ------------------------------------------------------------------ strict build: bit-exact
+
+@pytest.mark.parametrize("nx,ny,nl", CASES)
+def test_strict_operators_bit_exact(nx, ny, nl):
+    o, g = make_pair(nx, ny, nl, strict=True)
+    assert np.array_equal(g.get(F["Q"]), o.get(orc.Q))          # comp_q in set_const
+    assert np.array_equal(g.get(F["S"]), o.get(orc.S))
+    psi = rand_field(1, (nl, ny, nx))
+    # pyp2q = comp_del2 + comp_stretch
+    q_g = np.empty_like(psi)
+    g.pyp2q(psi, q_g)
+    assert np.array_equal(q_g, o.pyp2q(psi))
+    # comp_del2 with add != 0 and comp_stretch alone
+    o.set(orc.ZETA, psi[::-1].copy()); g.set(F["ZETA"], psi[::-1].copy())
+    o.comp_del2(orc.PSI, orc.ZETA, 0.5, -2.0); g.op("del2", F["PSI"], F["ZETA"], 0.5, -2.0)
+    assert np.array_equal(g.get(F["ZETA"]), o.get(orc.ZETA))
+    o.comp_stretch(orc.PSI, orc.ZETA, 1.0, 0.3); g.op("stretch", F["PSI"], F["ZETA"], 1.0, 0.3)
+    assert np.array_equal(g.get(F["ZETA"]), o.get(orc.ZETA))
+
+
+@pytest.mark.parametrize("nx,ny,nl", CASES)
+def test_strict_advection_bit_exact(nx, ny, nl):
+    o, g = make_pair(nx, ny, nl, strict=True)
+    psi, zeta = rand_field(2, (nl, ny, nx)), rand_field(3, (nl, ny, nx))
+    for m, P, Z, D in ((o, orc.PSI, orc.ZETA, orc.DQ), (g, F["PSI"], F["ZETA"], F["DQ"])):
+        m.set(P, psi); m.set(Z, zeta); m.set(D, 0.1 * psi)
+    o.advection_pv(orc.ZETA, orc.Q, orc.PSI, orc.DQ, 1.0)
+    g.op("advection", F["ZETA"], F["DQ"])
+    assert np.array_equal(g.get(F["DQ"]), o.get(orc.DQ))
+
+
+def test_strict_advection_with_background_flow_bit_exact():
+    nx = ny = 32; nl = 3
+    o, g = make_pair(nx, ny, nl, strict=True, extra="upg = [0.3,0.1,0.0]\nvpg = [0.0,-0.2,0.05]\nflsrv = 1\n")
+    assert np.array_equal(g.get(F["PSIPG"]), o.get(orc.PSIPG))
+    assert np.array_equal(g.get(F["ZETAPG"]), o.get(orc.ZETAPG))
+    psi, zeta = rand_field(4, (nl, ny, nx)), rand_field(5, (nl, ny, nx))
+    for m, P, Z, D in ((o, orc.PSI, orc.ZETA, orc.DQ), (g, F["PSI"], F["ZETA"], F["DQ"])):
+        m.set(P, psi); m.set(Z, zeta); m.set(D, np.zeros_like(psi))
+    o.reset_limiter()
+    dt_o = o.advection_pv(orc.ZETA, orc.Q, orc.PSI, orc.DQ, 1e10)
+    g.op("advection", F["ZETA"], F["DQ"])
+    assert np.array_equal(g.get(F["DQ"]), o.get(orc.DQ))
+    # full update incl. the 2*nl limiter calls with the cached background-flow velocity
+    o2, g2 = make_pair(nx, ny, nl, strict=True, extra="upg = [0.3,0.1,0.0]\nvpg = [0.0,-0.2,0.05]\nflsrv = 1\n", TOLERANCE=1e-9)
+    d_o = o2.update()
+    dq_g, d_g = g2.update(want=True)
+    assert d_g == d_o
+    assert np.array_equal(dq_g, o2.get(orc.DQ))
+
+
+@pytest.mark.parametrize("nx,ny,nl", CASES)
+def test_strict_multigrid_pieces_bit_exact(nx, ny, nl):
+    o, g = make_pair(nx, ny, nl, strict=True)
+    assert g.nlevels() == o.nlevels()
+    a, b = rand_field(6, (nl, ny, nx)), rand_field(7, (nl, ny, nx))
+    r_o, m_o = o.residual(a, b)
+    r_g, m_g = g.residual(a, b)
+    assert np.array_equal(r_g, r_o) and m_g == m_o
+    for lev in range(g.nlevels()):
+        lx, ly = g.level_dims(lev)
+        assert (lx, ly) == o.level_dims(lev)
+        da, res = rand_field(8 + lev, (nl, ly, lx)), rand_field(20 + lev, (nl, ly, lx))
+        for ns in (1, 3):
+            assert np.array_equal(g.relax(lev, da, res, ns), o.relax(lev, da, res, ns)), (lev, ns)
+        if lev + 1 < g.nlevels():
+            assert np.array_equal(g.restrict(lev, res), o.restrict(lev, res))
+        if lev >= 1:
+            assert np.array_equal(g.prolong(lev, da), o.prolong(lev, da))
+
+
+@pytest.mark.parametrize("nx,ny,nl", CASES)
+@pytest.mark.parametrize("tol", [1e-3, 1e-11])
+def test_strict_invertq_bit_exact(nx, ny, nl, tol):
+    o, g = make_pair(nx, ny, nl, strict=True, TOLERANCE=tol)
+    q = o.get(orc.Q) + rand_field(9, (nl, ny, nx), 1e-6)
+    p_o = o.pyq2p(q)
+    p_g = np.empty_like(q)
+    g.pyq2p(p_g, q)
+    so, sg = o.mgstats(), g.mgstats()
+    assert (sg.i, sg.nrelax) == (so.i, so.nrelax)
+    assert sg.resb == so.resb and sg.resa == so.resa
+    assert sg.sum == pytest.approx(so.sum, rel=1e-12, abs=1e-18)   # summation order differs
+    assert np.array_equal(p_g, p_o)
+
+
+@pytest.mark.parametrize("nx,ny,nl", [(32, 32, 3), (64, 32, 2), (32, 32, 6), (32, 32, 1)])
+def test_strict_ten_steps_bit_exact(nx, ny, nl):
+    o, g = make_pair(nx, ny, nl, strict=True)
+    o.set_tnext(1.0); g.set_tnext(1.0)
+    for k in range(10):
+        o.step()
+        dt = g.step()
+        assert dt == o.dt, k
+        assert g.t == o.t
+    assert np.array_equal(g.get(F["Q"]), o.get(orc.Q))
+    assert np.array_equal(g.get(F["PSI"]), o.get(orc.PSI))
+    # KE line of msqg/qg.c:108: summation order differs between CPU and GPU -> 1e-13 relative
+    assert g.ke() == pytest.approx(o.ke(), rel=1e-13)
+
+
+def test_strict_topography_qforcing_and_slip():
+    nx = ny = 32; nl = 3
+    o, g = make_pair(nx, ny, nl, strict=True, extra="sbc = 2.0\nEks = 0.001\nRe = 500\n", TOLERANCE=1e-9)
+    x = (np.arange(nx) + 0.5) / nx
+    topo = 0.01 * np.exp(-((x[None, :] - 0.5) ** 2 + (x[:, None] - 0.5) ** 2) * 30)[None]
+    qf = rand_field(11, (nl, ny, nx), 1e-7)
+    o.set(orc.TOPO, topo); g.set(F["TOPO"], topo)
+    o.option("flag_topo", 1)
+    o.set(orc.QFORC, qf); g.set(F["QFORC"], qf)
+    d_o = o.update()
+    dq_g, d_g = g.update()
+    assert d_g == d_o
+    assert np.array_equal(dq_g, o.get(orc.DQ))
+
+
+def test_strict_pystep_bfn_both_directions():
+    nx = ny = 32; nl = 3
+    o, g = make_pair(nx, ny, nl, strict=True, TOLERANCE=1e-9)
+    q = o.get(orc.Q)
+    for direction in (1.0, -1.0, 1.0):
+        tend = np.empty_like(q)
+        g.pystep_bfn(q, tend, direction, 1)
+        assert np.array_equal(tend, o.pystep_bfn(q, direction))
+
+
+def test_strict_stochastic_variant_bit_exact():
+    """-D_STOCHASTIC path (msqg/qg_stochastic.h) with the reference-exact serial rand() noise."""
+    nx = ny = 16; nl = 3
+    o, g = make_pair(nx, ny, nl, strict=True, extra="tr_stoch = 50\namp_stoch = 1e-5\n", stochastic=1)
+    sig = np.abs(rand_field(12, (nl, ny, nx)))
+    o.set(orc.SIGMA, sig); g.set(F["SIGMA"], sig)
+    import ctypes
+    libc = ctypes.CDLL(None)
+    for m in (o, g):
+        libc.srand(7)
+        m.set_tnext(1e30)
+        for _ in range(3):
+            m.step()
+        m.q_end = m.get(orc.Q if m is o else F["Q"])
+    assert np.array_equal(g.q_end, o.q_end)
+
+
+# ------------------------------------------------------------------ fast (product) build: tolerances
+
+@pytest.mark.parametrize("nx,ny,nl", CASES)
+def test_fast_operators_within_tolerance(nx, ny, nl):
+    o, g = make_pair(nx, ny, nl, strict=False)
+    assert g.param("uniform_S") == (1.0 if nl > 1 else 0.0)
+    psi, zeta = rand_field(2, (nl, ny, nx)), rand_field(3, (nl, ny, nx))
+    q_g = np.empty_like(psi)
+    g.pyp2q(psi, q_g)
+    assert rel(q_g, o.pyp2q(psi)) <= 1e-13     # per-kernel parity gate of SURVEY 8d
+    for m, P, Z, D in ((o, orc.PSI, orc.ZETA, orc.DQ), (g, F["PSI"], F["ZETA"], F["DQ"])):
+        m.set(P, psi); m.set(Z, zeta); m.set(D, np.zeros_like(psi))
+    o.advection_pv(orc.ZETA, orc.Q, orc.PSI, orc.DQ, 1.0)
+    g.op("advection", F["ZETA"], F["DQ"])
+    assert rel(g.get(F["DQ"]), o.get(orc.DQ)) <= 1e-13
+    a, b = rand_field(6, (nl, ny, nx)), rand_field(7, (nl, ny, nx))
+    r_o, m_o = o.residual(a, b)
+    r_g, m_g = g.residual(a, b)
+    assert rel(r_g, r_o) <= 1e-13 and m_g == pytest.approx(m_o, rel=1e-13)
+    for lev in range(g.nlevels()):
+        lx, ly = g.level_dims(lev)
+        da, res = rand_field(8 + lev, (nl, ly, lx)), rand_field(20 + lev, (nl, ly, lx))
+        assert rel(g.relax(lev, da, res, 2), o.relax(lev, da, res, 2)) <= 1e-13, lev
+        if lev >= 1:
+            assert rel(g.prolong(lev, da), o.prolong(lev, da)) <= 1e-15
+
+
+@pytest.mark.parametrize("uniform", [0, 1])
+def test_fast_general_S_field_path(uniform):
+    """Spatially varying Froude number (frpg file in the reference) uses the S-field kernels."""
+    nx = ny = 32; nl = 3
+    o, g = make_pair(nx, ny, nl, strict=False)
+    x = (np.arange(nx) + 0.5) / nx
+    fr = np.stack([0.0023669 * (1 + 0.3 * np.sin(2 * np.pi * x[None, :]) * np.ones((ny, 1))),
+                   0.0076173 * (1 + 0.2 * np.cos(2 * np.pi * x[:, None]) * np.ones((1, nx)))])
+    if uniform == 0:
+        o.set(orc.FR, fr); g.set(F["FR"], fr)
+    o.set_const(); g.set_const()
+    assert g.param("uniform_S") == float(uniform)
+    lx, ly = g.level_dims(1)
+    da, res = rand_field(1, (nl, ly, lx)), rand_field(2, (nl, ly, lx))
+    assert rel(g.relax(1, da, res, 2), o.relax(1, da, res, 2)) <= 1e-13
+    q = o.get(orc.Q)
+    o.option("TOLERANCE", 1e-11); g.option("TOLERANCE", 1e-11)
+    p_g = np.empty_like(q)
+    g.pyq2p(p_g, q)
+    assert rel(p_g, o.pyq2p(q)) <= 1e-9
+
+
+@pytest.mark.parametrize("nx,ny,nl", [(64, 64, 3), (64, 32, 6), (32, 32, 1)])
+def test_fast_ten_steps_tight_tolerance(nx, ny, nl):
+    """10-step run with TOLERANCE = 1e-12: <= 1e-10 relative on psi and q."""
+    o, g = make_pair(nx, ny, nl, strict=False, TOLERANCE=1e-12)
+    o.set_tnext(1.0); g.set_tnext(1.0)
+    for _ in range(10):
+        o.step()
+        g.step()
+    assert g.t == pytest.approx(o.t, rel=1e-12)
+    assert rel(g.get(F["Q"]), o.get(orc.Q)) <= 1e-10
+    assert rel(g.get(F["PSI"]), o.get(orc.PSI)) <= 1e-10
+    assert g.ke() == pytest.approx(o.ke(), rel=1e-9)
+
+
+def test_fast_hundred_steps_reference_tolerance_ke():
+    """At the reference TOLERANCE = 1e-3 (1 cycle per solve): ke_1 within 1e-4 after 100 steps."""
+    nx = ny = 64; nl = 3
+    o, g = make_pair(nx, ny, nl, strict=False)
+    o.set_tnext(1e30); g.set_tnext(1e30)
+    for _ in range(100):
+        o.step()
+        g.step()
+    assert g.ke() == pytest.approx(o.ke(), rel=1e-4)
+    assert g.mgstats().i == o.mgstats().i
+
+
+def test_lex_reference_ordering_vs_gpu_red_black():
+    """Reference-faithful lexicographic GS (CPU) vs red-black (GPU): same discrete solution
+    once both are converged (TOLERANCE 1e-12), SURVEY section 7 hard part 2(b)."""
+    nx = ny = 64; nl = 3
+    txt = orc.double_gyre_params(nx, nl)
+    o = orc.Oracle(txt, smoother=orc.GS_LEX, quiet=1, TOLERANCE=1e-12)
+    o.set(orc.PSI, orc.synthetic_psi(nl, ny, nx)); o.set_const()
+    g = QG(txt); g.option("quiet", 1); g.option("TOLERANCE", 1e-12)
+    g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx)); g.set_const()
+    q = o.get(orc.Q)
+    p_g = np.empty_like(q)
+    g.pyq2p(p_g, q)
+    assert rel(p_g, o.pyq2p(q)) <= 1e-8     # 1e-12 residual x |A^-1| ~ (L0/pi)^2 ~ 650
+
+
+def test_bas_files_byte_identical(tmp_path):
+    nx = ny = 32; nl = 3
+    o, g = make_pair(nx, ny, nl, strict=True)
+    po, pg = str(tmp_path / "o.bas"), str(tmp_path / "g.bas")
+    o.write_bas(orc.Q, po)
+    g.write_bas(F["Q"], pg)
+    assert open(po, "rb").read() == open(pg, "rb").read()
+    g2 = QG(orc.double_gyre_params(nx, nl), strict=True)
+    g2.read_bas(F["PSI"], pg)
+    assert np.array_equal(g2.get(F["PSI"]), g.get(F["Q"]).astype(np.float32).astype(np.float64))
+
+
+def test_error_convention():
+    from msom_amd import MsomError
+    with pytest.raises(MsomError):
+        QG("N = 48\nnl = 2\n")            # not a power of two
+    with pytest.raises(MsomError):
+        QG("N = 32\nnl = 9\n")            # more layers than the column solver supports
+    g = QG("N = 32\nnl = 2\nFr = [0.1]\ndh = [0.5,0.0]\nRom = 0.1\n")
+    with pytest.raises(MsomError, match="thickness"):
+        g.set_const()                      # reference: "thickness = 0: aborting", qg.h:990-996
+    g = QG("N = 32\nnl = 2\nFr = [0.1]\ndh = [0.5,0.5]\n")
+    with pytest.raises(MsomError, match="Rom"):
+        g.set_const()                      # reference: "Rom <= 0: aborting", qg.h:1009-1012
+    with pytest.raises(MsomError):
+        QG(path="/nonexistent/params.in")
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE config)
+
+@pytest.mark.parametrize("N,nl", [(2048, 3), (4096, 6)])
+def test_full_size_properties(N, nl):
+    """Size-independent properties at BASELINE.json's sizes, where the oracle is too slow:
+    analytic eigenfunction of lap + Gamma (closed-form q and closed-form inverse), linearity
+    of comp_q, and self-consistency of the reported residual."""
+    txt = orc.double_gyre_params(N, nl)
+    g = QG(txt)
+    g.option("quiet", 1)
+    g.set_const()
+    S = [(g.param(f"Fr_{l}") / g.param("Rom")) ** 2 for l in range(nl - 1)]
+    G = np.zeros((nl, nl))
+    for l in range(nl):
+        if l > 0:
+            c = S[l - 1] * g.param(f"idh0_{l}"); G[l, l - 1] += c; G[l, l] -= c
+        if l < nl - 1:
+            c = S[l] * g.param(f"idh1_{l}"); G[l, l + 1] += c; G[l, l] -= c
+    gam, vec = np.linalg.eig(G)
+    D = 80.0 / N
+    x = (np.arange(N) + 0.5) / N
+    k, m_, iv = 3, 5, 1
+    h = np.outer(np.sin(m_ * np.pi * x), np.sin(k * np.pi * x))
+    psi = 1e-3 * vec[:, iv].real[:, None, None] * h[None]
+    lam = -(4 / D**2) * (np.sin(k * np.pi / (2 * N)) ** 2 + np.sin(m_ * np.pi / (2 * N)) ** 2)
+    q_exact = (lam + gam[iv].real) * psi
+    q = np.empty_like(psi)
+    g.pyp2q(psi, q)
+    # conditioning of the 5-point stencil on a smooth field: eps * |psi| * 8/D^2
+    assert np.abs(q - q_exact).max() <= 4e-16 * np.abs(psi).max() * 8 / D**2 * 4
+    # linearity
+    psi2 = np.roll(psi, 1, axis=0)
+    qa, qb = np.empty_like(psi), np.empty_like(psi)
+    g.pyp2q(psi2, qa)
+    g.pyp2q(psi + 2 * psi2, qb)
+    assert np.abs(qb - (q + 2 * qa)).max() <= 1e-12 * np.abs(qb).max() + 4e-16 * np.abs(psi).max() * 8 / D**2 * 8
+    del qa, qb, psi2
+    # inverse: tight tolerance recovers psi
+    g.option("TOLERANCE", 1e-7 * np.abs(q_exact).max())
+    p = np.empty_like(psi)
+    g.pyq2p(p, q_exact)
+    st = g.mgstats()
+    assert st.resa <= 1e-7 * np.abs(q_exact).max() and st.i < 30
+    assert np.abs(p - psi).max() <= 1e-5 * np.abs(psi).max()
+    # reported residual == recomputed residual
+    _, mres = g.residual(p, q_exact)
+    assert mres == pytest.approx(st.resa, rel=1e-12)
