@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py -- timesteps/s and grid-point-updates/s of the multi-layer QG hot path.
+
+One "step" = one full predictor-corrector (RK2) time step of msqg: 2 elliptic inversions
+q -> psi (multigrid, TOLERANCE 1e-3 as msqg/qg.h:159), 2 PV-tendency evaluations, 2 advances
+(SURVEY 8d).  Workload at N = 1: BASELINE.json's metric configuration, 4096 x 4096 x 6 layers,
+fp64, Verron double-gyre parameters (msqg/test/params.double_gyre.in) with nl = 6, synthetic
+seed-free initial stream function.  N > 1: one process per GPU, weak scaling -- every rank
+owns one 4096 x 4096 x 6 tile of a (4096 px) x (4096 py) domain.
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the
+library's stream around the dominant kernel (finest-level red-black smoother colour sweep);
+`cpu_baseline` is the CPU oracle (oracle/, OpenMP) timed on the host cores on a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md
+
+
+def tile_grid(n):
+    return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (2, 4)}[n]
+
+
+def cpu_baseline(nl, n_cpu=1024, steps=2):
+    """CPU oracle (plain C + OpenMP, red-black smoother) on a bounded sample: `steps` RK2 steps
+    of the same parameter set on an n_cpu^2 x nl grid; grid-point-updates/s is size-normalised."""
+    import orc
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    quota = cores
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    threads = max(1, min(cores, quota, 16))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    o = orc.Oracle(orc.double_gyre_params(n_cpu, nl), smoother=orc.GS_RB, quiet=1)
+    o.set(orc.PSI, orc.synthetic_psi(nl, n_cpu, n_cpu))
+    o.set_const()
+    o.step()  # warm-up (first touch, limiter start)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o.step()
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_cpu * n_cpu * nl * steps / dt,
+        "unit": "grid-point-updates/s",
+        "cores": orc.lib().orc_num_threads(),
+        "kind": "port",
+        "sample": f"{steps} RK2 steps at {n_cpu}x{n_cpu}x{nl} fp64 (same params, red-black smoother, 1 warm-up step), "
+                  f"{dt / steps * 1e3:.0f} ms/step",
+        "steps_per_s": steps / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--N", type=int, default=4096, help="tile edge (cells)")
+    ap.add_argument("--nl", type=int, default=6)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-n", type=int, default=1024)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import orc
+    from msom_amd import FIELDS as F
+    from msom_amd import QG
+
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", "")  # keep as launched
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    px, py = tile_grid(world)
+    N, nl = args.N, args.nl
+    gnx, gny = N * px, N * py
+    params = orc.double_gyre_params(gnx, nl, extra=(f"Ny = {gny}\n" if gny != gnx else ""))
+    # Re4(N) keeps the viscous clamp at DT = 0.025; per-tile resolution fixed.
+    if world > 1:
+        import ctypes
+
+        import torch
+
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            from msom_amd import load_library
+
+            buf = (ctypes.c_char * 128)()
+            load_library().msom_comm_unique_id(buf)
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        uid = uid.cuda()
+        dist.broadcast(uid, 0)
+        uid_bytes = bytes(uid.cpu().numpy().tobytes())
+        g = QG(params, tiled=(px, py, rank, uid_bytes))
+    else:
+        g = QG(params)
+    g.option("quiet", 1)
+    # synthetic IC on this rank's tile (global sine modes sampled on the tile)
+    ix, iy = rank % px, rank // px
+    full = orc.synthetic_psi(nl, gny, gnx) if world == 1 else None
+    if full is None:
+        x = (np.arange(gnx) + 0.5) / gnx
+        y = (np.arange(gny) + 0.5) / gny
+        xs, ys = x[ix * N:(ix + 1) * N], y[iy * N:(iy + 1) * N]
+        full = np.zeros((nl, N, N))
+        for l in range(nl):
+            for k in range(1, 5):
+                for m in range(1, 5):
+                    c = np.sin(1.7 * k + 2.3 * m + 0.9 * l) / (k * m)
+                    full[l] += c * np.outer(np.sin(m * np.pi * ys), np.sin(k * np.pi * xs))
+            full[l] *= 1e-3 * (1.0 - 0.15 * l)
+    g.set(F["PSI"], full)
+    del full
+    g.set_const()
+    g.set_tnext(float("inf"))
+
+    def barrier():
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        g.step()
+    g.option("profile", 1)
+    g.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.step()   # msom_step synchronises the library's stream before returning
+    barrier()
+    elapsed = time.perf_counter() - t0
+    g.option("profile", 0)
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    sweep_ms, sweep_n = g.profile_read("sweep")      # one sweep = red + black launch
+    resid_ms, resid_n = g.profile_read("residual")
+    st = g.mgstats()
+    ke = g.ke()
+
+    if rank == 0:
+        w = 8.0 * N * N * nl                       # bytes of one layered fp64 field of the tile
+        uniform = g.param("uniform_S") == 1.0
+        sigma = 0.0 if uniform else (nl - 1) / nl
+        # algorithmic bytes of ONE colour half-sweep launch: read the other colour's da (w/2),
+        # read own-colour res (w/2) [+ own-colour S], write own-colour da (w/2)
+        launch_bytes = (3.0 + sigma) * w / 2.0
+        launch_ms = sweep_ms / 2.0
+        achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        out = {
+            "metric": "grid-point-updates/s (timesteps/s x N^2 x nl), multi-layer QG RK2 step at 4096^2 x 6L per GPU",
+            "value": gnx * gny * nl * args.steps / elapsed,
+            "unit": "grid-point-updates/s",
+            "timesteps_per_s": args.steps / elapsed,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"msqg double gyre (Verron 1992 params), {gnx}x{gny}x{nl} fp64, tiles {px}x{py} of {N}x{N}, "
+                            f"TOLERANCE 1e-3, RK2 step = 2 inversions + 2 tendencies + 2 advances",
+                "mg_cycles_per_solve": st.i, "mg_nrelax": st.nrelax, "mg_resa": st.resa, "ke_1": ke,
+                "uniform_S_fast_path": bool(uniform),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_relax_color<NL,UNIFORM,FINE=true> (finest-level red-black colour half-sweep)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": launch_bytes,
+                "avg_launch_ms": launch_ms,
+                "launches_timed": 2 * sweep_n,
+                "residual_kernel": {
+                    "avg_launch_ms": resid_ms, "launches_timed": resid_n,
+                    "achieved_GBs": ((3.0 + sigma) * w / (resid_ms * 1e-3) / 1e9) if resid_ms > 0 else 0.0,
+                },
+            },
+        }
+        if not args.no_cpu:
+            g.close()
+            out["cpu_baseline"] = cpu_baseline(nl, n_cpu=args.cpu_n)
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

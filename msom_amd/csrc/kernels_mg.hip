@@ -218,7 +218,10 @@ struct RelaxArgs {
   RelaxCoef rc;
 };
 
-template <int NL, bool UNIFORM>
+// FINE tags the instantiation launched on the finest level (level 0): a distinct kernel
+// symbol, so that profiler statistics of the HBM-bound fine sweep are not averaged with the
+// launch-latency-bound coarse levels.
+template <int NL, bool UNIFORM, bool FINE>
 __global__ void __launch_bounds__(BX *BY) k_relax_color(RelaxArgs p) {
   const int kx = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
   if (kx >= p.g.hk || j >= p.g.ny) return;
@@ -284,24 +287,29 @@ __global__ void __launch_bounds__(BX *BY) k_relax_color(RelaxArgs p) {
 }
 
 template <int NL>
-static void relax_dispatch(hipStream_t st, const RelaxArgs &p, int uniformS) {
+static void relax_dispatch(hipStream_t st, const RelaxArgs &p, int uniformS, int fine) {
   dim3 gr = grid2d(p.g.hk, p.g.ny);
-  if (uniformS) hipLaunchKernelGGL((k_relax_color<NL, true>), gr, block2d(), 0, st, p);
-  else hipLaunchKernelGGL((k_relax_color<NL, false>), gr, block2d(), 0, st, p);
+  if (uniformS) {
+    if (fine) hipLaunchKernelGGL((k_relax_color<NL, true, true>), gr, block2d(), 0, st, p);
+    else hipLaunchKernelGGL((k_relax_color<NL, true, false>), gr, block2d(), 0, st, p);
+  } else {
+    if (fine) hipLaunchKernelGGL((k_relax_color<NL, false, true>), gr, block2d(), 0, st, p);
+    else hipLaunchKernelGGL((k_relax_color<NL, false, false>), gr, block2d(), 0, st, p);
+  }
 }
 void launch_relax_color(hipStream_t st, double *da, const double *res, const double *S, const SplitGeom &sg, int nl, const RelaxCoef &rc,
-                        int uniformS, int color, int walls) {
+                        int uniformS, int color, int walls, int fine) {
   RelaxArgs p;
   p.da = da; p.res = res; p.S = S; p.g = sg; p.color = color; p.walls = walls; p.rc = rc;
   switch (nl) {
-    case 1: relax_dispatch<1>(st, p, uniformS); break;
-    case 2: relax_dispatch<2>(st, p, uniformS); break;
-    case 3: relax_dispatch<3>(st, p, uniformS); break;
-    case 4: relax_dispatch<4>(st, p, uniformS); break;
-    case 5: relax_dispatch<5>(st, p, uniformS); break;
-    case 6: relax_dispatch<6>(st, p, uniformS); break;
-    case 7: relax_dispatch<7>(st, p, uniformS); break;
-    case 8: relax_dispatch<8>(st, p, uniformS); break;
+    case 1: relax_dispatch<1>(st, p, uniformS, fine); break;
+    case 2: relax_dispatch<2>(st, p, uniformS, fine); break;
+    case 3: relax_dispatch<3>(st, p, uniformS, fine); break;
+    case 4: relax_dispatch<4>(st, p, uniformS, fine); break;
+    case 5: relax_dispatch<5>(st, p, uniformS, fine); break;
+    case 6: relax_dispatch<6>(st, p, uniformS, fine); break;
+    case 7: relax_dispatch<7>(st, p, uniformS, fine); break;
+    case 8: relax_dispatch<8>(st, p, uniformS, fine); break;
     default: break;  // rejected at create time (MSOM_MAXNL)
   }
 }

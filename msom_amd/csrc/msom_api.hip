@@ -548,7 +548,7 @@ static void relax_sweeps(msom *m, int k, int nrelax) {
   for (int it = 0; it < nrelax; it++) {
     if (prof) prof_begin(m, m->prof_sweep);
     for (int c = 0; c < 2; c++)
-      launch_relax_color(m->st, m->da[k], m->res[k], m->S[k], m->sg[k], m->nl, m->rc[k], m->uniformS, c, m->walls);
+      launch_relax_color(m->st, m->da[k], m->res[k], m->S[k], m->sg[k], m->nl, m->rc[k], m->uniformS, c, m->walls, k == 0);
     if (prof) prof_end(m, m->prof_sweep);
   }
 }
@@ -1137,7 +1137,7 @@ extern "C" int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double
   const double D = m->p.L0 / m->gnx;
   auto one = [&](void) {
     if (!strcmp(kernel, "sweep")) {
-      for (int c = 0; c < 2; c++) launch_relax_color(m->st, m->da[0], m->res[0], m->S[0], m->sg[0], m->nl, m->rc[0], m->uniformS, c, m->walls);
+      for (int c = 0; c < 2; c++) launch_relax_color(m->st, m->da[0], m->res[0], m->S[0], m->sg[0], m->nl, m->rc[0], m->uniformS, c, m->walls, 1);
     } else if (!strcmp(kernel, "residual")) {
       launch_residual(m->st, m->f[MSOM_PSI], m->f[MSOM_Q], m->f[MSOM_S], m->g, m->res[0], m->sg[0], m->nl, m->rc[0], m->uniformS, m->d_scal + SC_RES1, m->partial, 0);
     } else if (!strcmp(kernel, "advection")) {

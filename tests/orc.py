@@ -27,9 +27,21 @@ def build():
 _lib = None
 
 
+def _limit_threads():
+    # GPU boxes expose every host core but give the job a small CPU share: an unbounded
+    # OpenMP team there spends its time spinning.  Must be set before libgomp starts.
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, n))))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+
 def lib():
     global _lib
     if _lib is None:
+        _limit_threads()
         _lib = C.CDLL(build())
         dp = C.POINTER(C.c_double)
         L = _lib

@@ -180,7 +180,7 @@ def test_strict_stochastic_variant_bit_exact():
     libc = ctypes.CDLL(None)
     for m in (o, g):
         libc.srand(7)
-        m.set_tnext(1e30)
+        m.set_tnext(float('inf'))
         for _ in range(3):
             m.step()
         m.q_end = m.get(orc.Q if m is o else F["Q"])
@@ -254,7 +254,7 @@ def test_fast_hundred_steps_reference_tolerance_ke():
     """At the reference TOLERANCE = 1e-3 (1 cycle per solve): ke_1 within 1e-4 after 100 steps."""
     nx = ny = 64; nl = 3
     o, g = make_pair(nx, ny, nl, strict=False)
-    o.set_tnext(1e30); g.set_tnext(1e30)
+    o.set_tnext(float('inf')); g.set_tnext(float('inf'))
     for _ in range(100):
         o.step()
         g.step()
@@ -274,7 +274,7 @@ def test_lex_reference_ordering_vs_gpu_red_black():
     q = o.get(orc.Q)
     p_g = np.empty_like(q)
     g.pyq2p(p_g, q)
-    assert rel(p_g, o.pyq2p(q)) <= 1e-8     # 1e-12 residual x |A^-1| ~ (L0/pi)^2 ~ 650
+    assert rel(p_g, o.pyq2p(q)) <= 1e-6     # 1e-12 residual x |A^-1| ~ (L0/pi)^2 ~ 650, / max|psi| ~ 1.6e-3
 
 
 def test_bas_files_byte_identical(tmp_path):
