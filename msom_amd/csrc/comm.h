@@ -1,0 +1,38 @@
+// comm.h -- tile-to-tile transport of libmsomhip (internal).  See comm.hip.
+#ifndef MSOM_COMM_H
+#define MSOM_COMM_H
+
+#include <string.h>
+
+#include "msom_internal.h"
+
+enum { COMM_NONE = 0, COMM_RCCL = 1, COMM_LOCAL = 2 };
+enum { RED_MAX = 0, RED_MIN = 1, RED_SUM = 2 };
+// directions of the 8 neighbours (buffer slots)
+enum { DIR_W = 0, DIR_E = 1, DIR_S = 2, DIR_N = 3, DIR_SW = 4, DIR_SE = 5, DIR_NW = 6, DIR_NE = 7 };
+
+struct Xfer {
+  int peer;        // rank of the neighbour
+  int tag;         // direction of travel, so that the two ends pair up (sender dir d <-> receiver dir opposite(d))
+  double *send, *recv;
+  size_t count;    // doubles (same in both directions)
+};
+
+struct Comm;
+int comm_unique_id(void *id128);
+int comm_create(Comm **out, int rank, int n, const void *id128, hipStream_t st, size_t max_count);
+void comm_destroy(Comm *c);
+int comm_kind(const Comm *c);
+double *comm_sendbuf(Comm *c, int dir);
+double *comm_recvbuf(Comm *c, int dir);
+size_t comm_bufcount(const Comm *c);
+int comm_exchange(Comm *c, const Xfer *x, int nx);
+int comm_allreduce(Comm *c, double *dvals, double *hout, int n, int op);
+
+void launch_nat_pack_strip(hipStream_t st, const double *f, const NatGeom &g, int nl, int i0, int j0, int w, int h, double *buf);
+void launch_nat_unpack_strip(hipStream_t st, double *f, const NatGeom &g, int nl, int i0, int j0, int w, int h, const double *buf);
+void launch_split_pack_strip(hipStream_t st, const double *f, const SplitGeom &g, int nl, int i0, int j0, int w, int h, double *buf);
+void launch_split_unpack_strip(hipStream_t st, double *f, const SplitGeom &g, int nl, int i0, int j0, int w, int h, const double *buf);
+void launch_split_wall_corners(hipStream_t st, double *f, const SplitGeom &g, int nl, int walls);
+
+#endif

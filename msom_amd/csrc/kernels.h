@@ -32,7 +32,7 @@ void launch_stretch(hipStream_t st, const double *po, double *out, const double 
 void launch_advection(hipStream_t st, const double *zeta, const double *psi, const double *psipg, const double *zetapg, const double *S,
                       const double *qot, double *dq, const NatGeom &g, int nl, int have_pg, int have_zpg, int stochastic, double D,
                       double beta, double itr_stoch, const LayerCoef &lc);
-void launch_umax(hipStream_t st, const double *f0, const double *f1, int nf, double *out, const NatGeom &g, int nl, double D);
+void launch_umax(hipStream_t st, const double *f, double *partial, double *out, const NatGeom &g, int nl, double D);
 void launch_axpy(hipStream_t st, double *dq, const double *x, const NatGeom &g, int nl, double c);
 void launch_forcing(hipStream_t st, const double *zeta, const double *psi, const double *qforc, const double *topo, const double *Ro,
                     const double *wind, double *dq, const NatGeom &g, int nl, int have_qforc, int flag_topo, double cs, double cb,

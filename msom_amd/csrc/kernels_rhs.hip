@@ -233,43 +233,75 @@ __global__ void k_advection(AdvArgs a) {
 
 // ------------------------------------------------------------------ K4 comp_vel: max |u| on faces
 
-// one launch handles `nf` layered fields; result max|u| per (field, layer) in out[f*nl + l]
+// max |u| over the faces of every layer of one layered field -> out[l].  Persistent-style
+// grid (<= 2048 blocks, row-strided): each thread keeps its nl running maxima in registers,
+// one block reduction per layer at the end, per-block partials, then a 1-block final pass.
+#define UMAX_MAXBLOCKS 2048
 struct UmaxArgs {
-  const double *f[2];
-  double *out;
+  const double *f;
+  double *partial;  // [gridDim.x][nl]
   NatGeom g;
-  int nl, nf;
+  int nl;
   double D;
 };
-__global__ void k_umax(UmaxArgs a) {
-  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
-  const bool in = i <= a.g.nx && j <= a.g.ny;
+__global__ void __launch_bounds__(256) k_umax(UmaxArgs a) {
   const double rD = 1. / a.D;
-  for (int f = 0; f < a.nf; f++)
-    for (int l = 0; l < a.nl; l++) {
-      double m = 0.;
-      if (in) {
-        const double *p = a.f[f];
-        const size_t c = nat_idx(a.g, l, j, i);
-        const int pitch = a.g.pitch;
-        if (j < a.g.ny) {  // x-face between (i-1,j) and (i,j), msqg/qg.h:280
-          const double u = DIVC(0.25 * (p[c + pitch] - p[c - pitch] + p[c - 1 + pitch] - p[c - 1 - pitch]), a.D, rD);
-          m = fabs(u);
-        }
-        if (i < a.g.nx) {  // y-face between (i,j-1) and (i,j)
-          const double v = DIVC(0.25 * (p[c + 1] - p[c - 1] + p[c + 1 - pitch] - p[c - 1 - pitch]), a.D, rD);
-          m = fmax(m, fabs(v));
+  const int pitch = a.g.pitch;
+  double m[MSOM_MAXNL];
+#pragma unroll
+  for (int l = 0; l < MSOM_MAXNL; l++) m[l] = 0.;
+  // rows j in [0, ny], columns i in [0, nx]: x-face (i,j) needs j < ny, y-face (i,j) needs i < nx
+  for (int j = blockIdx.x; j <= a.g.ny; j += gridDim.x)
+    for (int i = threadIdx.x; i <= a.g.nx; i += blockDim.x) {
+      size_t c = nat_idx(a.g, 0, j, i);
+#pragma unroll
+      for (int l = 0; l < MSOM_MAXNL; l++) {
+        if (l < a.nl) {
+          const double *p = a.f;
+          double v = 0.;
+          if (j < a.g.ny)  // msqg/qg.h:280
+            v = fabs(DIVC(0.25 * (p[c + pitch] - p[c - pitch] + p[c - 1 + pitch] - p[c - 1 - pitch]), a.D, rD));
+          if (i < a.g.nx)
+            v = fmax(v, fabs(DIVC(0.25 * (p[c + 1] - p[c - 1] + p[c + 1 - pitch] - p[c - 1 - pitch]), a.D, rD)));
+          m[l] = fmax(m[l], v);
+          c += a.g.ls;
         }
       }
-      block_max_to(&a.out[f * a.nl + l], m);
-      __syncthreads();
     }
+  __shared__ double sm[4][MSOM_MAXNL];
+  const int w = threadIdx.x >> 6;
+#pragma unroll
+  for (int l = 0; l < MSOM_MAXNL; l++) {
+    if (l < a.nl) {
+      const double v = wave_max(m[l]);
+      if ((threadIdx.x & 63) == 0) sm[w][l] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < a.nl)
+    a.partial[(size_t)blockIdx.x * a.nl + threadIdx.x] =
+        fmax(fmax(sm[0][threadIdx.x], sm[1][threadIdx.x]), fmax(sm[2][threadIdx.x], sm[3][threadIdx.x]));
 }
-
-void launch_umax(hipStream_t st, const double *f0, const double *f1, int nf, double *out, const NatGeom &g, int nl, double D) {
+// out[l] = max_b partial[b][l]
+__global__ void k_max_final(const double *partial, double *out, int nb, int nl) {
+  __shared__ double sm[256];
+  const int l = blockIdx.x;
+  double v = 0.;
+  for (int b = threadIdx.x; b < nb; b += 256) v = fmax(v, partial[(size_t)b * nl + l]);
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[l] = sm[0];
+}
+void launch_umax(hipStream_t st, const double *f, double *partial, double *out, const NatGeom &g, int nl, double D) {
   UmaxArgs a;
-  a.f[0] = f0; a.f[1] = f1; a.out = out; a.g = g; a.nl = nl; a.nf = nf; a.D = D;
-  hipLaunchKernelGGL(k_umax, grid2d(g.nx + 1, g.ny + 1), block2d(), 0, st, a);
+  a.f = f; a.partial = partial; a.g = g; a.nl = nl; a.D = D;
+  const int nb = g.ny + 1 < UMAX_MAXBLOCKS ? g.ny + 1 : UMAX_MAXBLOCKS;
+  hipLaunchKernelGGL(k_umax, dim3(nb), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_max_final, dim3(nl), dim3(256), 0, st, partial, out, nb, nl);
 }
 
 void launch_advection(hipStream_t st, const double *zeta, const double *psi, const double *psipg, const double *zetapg, const double *S,

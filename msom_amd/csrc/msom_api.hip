@@ -16,6 +16,7 @@
 
 #include <vector>
 
+#include "comm.h"
 #include "kernels.h"
 
 #define HIPCHK(x)                                                                          \
@@ -44,6 +45,9 @@ struct msom {
   int gnx = 0, gny = 0;  // global cells
   int nx = 0, ny = 0;    // local cells
   int walls = WALL_ALL;
+  Comm *comm = nullptr;
+  int sticky = MSOM_OK;  // first error of a void helper (exchange inside fill_bc / mg_cycle)
+  int nb[8];  // neighbour ranks by direction (DIR_*), -1 = none
   int nl = 1, nlm = 1;
   int bc = BC_DIRICHLET0;
   // layer metrics (msqg/qg.h:1017-1027)
@@ -63,6 +67,7 @@ struct msom {
   // scratch
   double *staging = nullptr;   // contiguous nl*ny*nx
   double *partial = nullptr;   // per-block partial sums
+  double *partial_umax = nullptr;  // per-block partial maxima of k_umax
   double *d_scal = nullptr, *h_scal = nullptr;
   double *d_wind = nullptr;    // per-row surface forcing profile
   double umax_pg[MSOM_MAXNL];
@@ -113,8 +118,13 @@ static SplitGeom make_split(int nx, int ny) {
 
 static int sync_stream(msom *m) {
   HIPCHK(hipStreamSynchronize(m->st));
-  return MSOM_OK;
+  return m->sticky;
 }
+#define STICKY(m, call)                                  \
+  do {                                                   \
+    int r__ = (call);                                    \
+    if (r__ && !(m)->sticky) (m)->sticky = r__;          \
+  } while (0)
 
 static void prof_begin(msom *m, ProfSlot &ps) {
   if (!m->profile) return;
@@ -141,6 +151,100 @@ static void prof_collect(msom *m, ProfSlot &ps) {
 
 static int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
+
+// ------------------------------------------------------------------ tile halo exchange / reductions
+
+static const int OPP[8] = {DIR_E, DIR_W, DIR_N, DIR_S, DIR_NE, DIR_NW, DIR_SE, DIR_SW};
+// both ends of a neighbour pair label their message with the same axis id
+#define AXIS(dir) ((dir) < OPP[dir] ? (dir) : OPP[dir])
+
+// all-reduce n device scalars starting at `slot` over the tiles; result in h_scal (and d_scal)
+static int reduce_scal(msom *m, int slot, int n, int op) {
+  if (m->nranks > 1) return comm_allreduce(m->comm, m->d_scal + slot, m->h_scal + slot, n, op);
+  HIPCHK(hipMemcpyAsync(m->h_scal + slot, m->d_scal + slot, n * sizeof(double), hipMemcpyDeviceToHost, m->st));
+  HIPCHK(hipStreamSynchronize(m->st));
+  return MSOM_OK;
+}
+
+// halo exchange of a natural field, `depth` ghost columns/rows, corners included: two phases
+// (x, then y over the x-ghost columns) with the wall BCs applied in between, exactly the
+// order of Basilisk's boundary() (x direction first).
+static int exch_nat(msom *m, double *f, int nl, int bc, int depth) {
+  const NatGeom &g = m->g;
+  const int d = depth;
+  if (m->nranks > 1) {
+    Xfer x[2];
+    int n = 0;
+    for (int dir : {DIR_W, DIR_E}) {
+      if (m->nb[dir] < 0) continue;
+      launch_nat_pack_strip(m->st, f, g, nl, dir == DIR_W ? 0 : g.nx - d, 0, d, g.ny, comm_sendbuf(m->comm, dir));
+      x[n++] = {m->nb[dir], AXIS(dir), comm_sendbuf(m->comm, dir), comm_recvbuf(m->comm, dir), (size_t)d * g.ny * nl};
+    }
+    int r = comm_exchange(m->comm, x, n);
+    if (r) return r;
+    for (int dir : {DIR_W, DIR_E}) {
+      if (m->nb[dir] < 0) continue;
+      launch_nat_unpack_strip(m->st, f, g, nl, dir == DIR_W ? -d : g.nx, 0, d, g.ny, comm_recvbuf(m->comm, dir));
+    }
+  }
+  launch_fill_ghost(m->st, f, g, nl, bc, m->walls);
+  if (m->nranks > 1) {
+    Xfer x[2];
+    int n = 0;
+    const int w = g.nx + 2 * d;
+    for (int dir : {DIR_S, DIR_N}) {
+      if (m->nb[dir] < 0) continue;
+      launch_nat_pack_strip(m->st, f, g, nl, -d, dir == DIR_S ? 0 : g.ny - d, w, d, comm_sendbuf(m->comm, dir));
+      x[n++] = {m->nb[dir], AXIS(dir), comm_sendbuf(m->comm, dir), comm_recvbuf(m->comm, dir), (size_t)d * w * nl};
+    }
+    int r = comm_exchange(m->comm, x, n);
+    if (r) return r;
+    for (int dir : {DIR_S, DIR_N}) {
+      if (m->nb[dir] < 0) continue;
+      launch_nat_unpack_strip(m->st, f, g, nl, -d, dir == DIR_S ? -d : g.ny, w, d, comm_recvbuf(m->comm, dir));
+    }
+  }
+  return MSOM_OK;
+}
+
+// halo exchange (depth 1) of a multigrid field in split layout.  corners = 0: the 4 face
+// neighbours in one phase (enough for the 5-point smoother); corners = 1: two phases so that
+// the corner ghosts needed by the bilinear prolongation are valid.
+static int exch_split(msom *m, double *f, const SplitGeom &sg, int nl, int corners) {
+  if (m->nranks == 1) return MSOM_OK;
+  Xfer x[4];
+  int n = 0;
+  auto pack = [&](int dir, int i0, int j0, int w, int h) {
+    launch_split_pack_strip(m->st, f, sg, nl, i0, j0, w, h, comm_sendbuf(m->comm, dir));
+    x[n++] = {m->nb[dir], AXIS(dir), comm_sendbuf(m->comm, dir), comm_recvbuf(m->comm, dir), (size_t)w * h * nl};
+  };
+  const int x0 = corners ? -1 : 0, xw = corners ? sg.nx + 2 : sg.nx;
+  if (m->nb[DIR_W] >= 0) pack(DIR_W, 0, 0, 1, sg.ny);
+  if (m->nb[DIR_E] >= 0) pack(DIR_E, sg.nx - 1, 0, 1, sg.ny);
+  if (!corners) {
+    if (m->nb[DIR_S] >= 0) pack(DIR_S, 0, 0, sg.nx, 1);
+    if (m->nb[DIR_N] >= 0) pack(DIR_N, 0, sg.ny - 1, sg.nx, 1);
+  }
+  int r = comm_exchange(m->comm, x, n);
+  if (r) return r;
+  if (m->nb[DIR_W] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, -1, 0, 1, sg.ny, comm_recvbuf(m->comm, DIR_W));
+  if (m->nb[DIR_E] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, sg.nx, 0, 1, sg.ny, comm_recvbuf(m->comm, DIR_E));
+  if (!corners) {
+    if (m->nb[DIR_S] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, 0, -1, sg.nx, 1, comm_recvbuf(m->comm, DIR_S));
+    if (m->nb[DIR_N] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, 0, sg.ny, sg.nx, 1, comm_recvbuf(m->comm, DIR_N));
+    return MSOM_OK;
+  }
+  launch_split_wall_corners(m->st, f, sg, nl, m->walls);
+  n = 0;
+  if (m->nb[DIR_S] >= 0) pack(DIR_S, x0, 0, xw, 1);
+  if (m->nb[DIR_N] >= 0) pack(DIR_N, x0, sg.ny - 1, xw, 1);
+  if ((r = comm_exchange(m->comm, x, n))) return r;
+  if (m->nb[DIR_S] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, x0, -1, xw, 1, comm_recvbuf(m->comm, DIR_S));
+  if (m->nb[DIR_N] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, x0, sg.ny, xw, 1, comm_recvbuf(m->comm, DIR_N));
+  launch_split_wall_corners(m->st, f, sg, nl, m->walls);
+  return MSOM_OK;
+}
+
 // ------------------------------------------------------------------ lifecycle
 
 static int alloc_all(msom *m) {
@@ -164,6 +268,7 @@ static int alloc_all(msom *m) {
   // on its short side
   int n = 0;
   while ((m->nx >> n) >= 2 && (m->ny >> n) >= 2 && ((m->nx >> n) << n) == m->nx && ((m->ny >> n) << n) == m->ny) n++;
+  if (m->p.mglevels > 0 && m->p.mglevels < n) n = m->p.mglevels;
   m->nlev = n;
   m->sg.resize(n); m->da.resize(n); m->res.resize(n); m->S.resize(n); m->rc.resize(n);
   for (int k = 0; k < n; k++) {
@@ -178,6 +283,7 @@ static int alloc_all(msom *m) {
   }
   HIPCHK(hipMalloc(&m->staging, (size_t)m->nl * m->nx * m->ny * sizeof(double)));
   HIPCHK(hipMalloc(&m->partial, (size_t)partial_count(m->g) * m->nl * sizeof(double)));
+  HIPCHK(hipMalloc(&m->partial_umax, (size_t)2048 * MSOM_MAXNL * sizeof(double)));
   HIPCHK(hipMalloc(&m->d_scal, SC_COUNT * sizeof(double)));
   HIPCHK(hipMemsetAsync(m->d_scal, 0, SC_COUNT * sizeof(double), m->st));
   HIPCHK(hipHostMalloc(&m->h_scal, SC_COUNT * sizeof(double)));
@@ -218,7 +324,7 @@ static int set_vars(msom *m) {
   return r;
 }
 
-static msom *create_common(const Params &p0, int px, int py, int rank) {
+static msom *create_common(const Params &p0, int px, int py, int rank, const void *id128) {
   Params p = p0;
   if (p.Ny <= 0) p.Ny = p.N;
   msom_params_derive(&p);
@@ -251,7 +357,19 @@ static msom *create_common(const Params &p0, int px, int py, int rank) {
   if (m->ix == px - 1) m->walls |= WALL_E;
   if (m->iy == 0) m->walls |= WALL_S;
   if (m->iy == py - 1) m->walls |= WALL_N;
-  if (alloc_all(m) != MSOM_OK || set_vars(m) != MSOM_OK) {
+  // neighbour ranks
+  for (int d = 0; d < 8; d++) m->nb[d] = -1;
+  {
+    const int dx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, dy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+    for (int d = 0; d < 8; d++) {
+      const int jx = m->ix + dx[d], jy = m->iy + dy[d];
+      if (jx >= 0 && jx < px && jy >= 0 && jy < py) m->nb[d] = jy * px + jx;
+    }
+  }
+  if (alloc_all(m) != MSOM_OK ||
+      (m->nranks > 1 && comm_create(&m->comm, rank, m->nranks, id128, m->st,
+                                    (size_t)3 * ((m->nx > m->ny ? m->nx : m->ny) + 6) * m->nl) != MSOM_OK) ||
+      set_vars(m) != MSOM_OK) {
     msom_destroy(m);
     return nullptr;
   }
@@ -263,13 +381,13 @@ extern "C" msom_t *msom_create_str(const char *text) {
   Params p;
   msom_params_defaults(&p);
   msom_params_parse_text(&p, text);
-  return create_common(p, 1, 1, 0);
+  return create_common(p, 1, 1, 0, nullptr);
 }
 extern "C" msom_t *msom_create(const char *path) {
   Params p;
   msom_params_defaults(&p);
   if (msom_params_parse_file(&p, path ? path : "params.in")) return nullptr;
-  return create_common(p, 1, 1, 0);
+  return create_common(p, 1, 1, 0, nullptr);
 }
 
 extern "C" int msom_destroy(msom_t *m) {
@@ -284,11 +402,13 @@ extern "C" int msom_destroy(msom_t *m) {
   }
   if (m->staging) hipFree(m->staging);
   if (m->partial) hipFree(m->partial);
+  if (m->partial_umax) hipFree(m->partial_umax);
   if (m->d_scal) hipFree(m->d_scal);
   if (m->h_scal) hipHostFree(m->h_scal);
   if (m->d_wind) hipFree(m->d_wind);
   for (auto *ps : {&m->prof_sweep, &m->prof_resid})
     for (auto e : ps->ev) hipEventDestroy(e);
+  if (m->comm) comm_destroy(m->comm);
   if (m->st) hipStreamDestroy(m->st);
   delete m;
   return MSOM_OK;
@@ -366,8 +486,14 @@ static int check_field(msom *m, int field) {
   return MSOM_OK;
 }
 
-static void fill_bc(msom *m, int field) {
+// boundary(): wall BCs + halo exchange with the neighbour tiles.  The ghosts of q, dq and the
+// predictor are never read (b enters the solver at cell centres only), so those fields skip
+// the exchange.
+static int fill_bc(msom *m, int field) {
+  if (m->nranks > 1 && field != MSOM_Q && field != MSOM_DQ && field != MSOM_QPRED && field != MSOM_NOISE && field != MSOM_SIGMA)
+    return exch_nat(m, m->f[field], m->flayers[field], m->fbc[field], 1);
   launch_fill_ghost(m->st, m->f[field], m->g, m->flayers[field], m->fbc[field], m->walls);
+  return MSOM_OK;
 }
 
 // host or device pointer -> natural field (+ boundary())
@@ -409,9 +535,12 @@ extern "C" int msom_get_field(msom_t *m, int field, double *a) {
 // msqg/qg.c:65-70: po[] -= s.sum/s.volume per layer
 extern "C" int msom_remove_mean(msom_t *m, int field) {
   if (check_field(m, field)) return MSOM_ERR_ARG;
-  if (m->nranks > 1) { msom_set_error("remove_mean: tiled mode not implemented"); return MSOM_ERR_STATE; }
   const int nl = m->flayers[field];
   launch_sum_layers(m->st, m->f[field], m->partial, m->d_scal + SC_LSUM, m->g, nl);
+  if (m->nranks > 1) {
+    int r = reduce_scal(m, SC_LSUM, nl, RED_SUM);
+    if (r) return r;
+  }
   launch_sub_layer_const(m->st, m->f[field], m->d_scal + SC_LSUM, m->g, nl, 1. / ((double)m->gnx * m->gny));
   fill_bc(m, field);
   return sync_stream(m);
@@ -531,10 +660,9 @@ extern "C" int msom_set_const(msom_t *m) {
   // max |u| of the large-scale flow is constant in time: cache it for the dt limiter
   for (int l = 0; l < MSOM_MAXNL; l++) m->umax_pg[l] = 0.;
   if (m->have_pg) {
-    HIPCHK(hipMemsetAsync(m->d_scal + SC_UMAX, 0, 2 * MSOM_MAXNL * sizeof(double), m->st));
-    launch_umax(m->st, m->f[MSOM_PSIPG], nullptr, 1, m->d_scal + SC_UMAX, m->g, nl, D);
-    HIPCHK(hipMemcpyAsync(m->h_scal + SC_UMAX, m->d_scal + SC_UMAX, nl * sizeof(double), hipMemcpyDeviceToHost, m->st));
-    HIPCHK(hipStreamSynchronize(m->st));
+    launch_umax(m->st, m->f[MSOM_PSIPG], m->partial_umax, m->d_scal + SC_UMAX, m->g, nl, D);
+    int r = reduce_scal(m, SC_UMAX, nl, RED_MAX);
+    if (r) return r;
     for (int l = 0; l < nl; l++) m->umax_pg[l] = m->h_scal[SC_UMAX + l];
   }
   m->const_set = 1;
@@ -543,12 +671,16 @@ extern "C" int msom_set_const(msom_t *m) {
 
 // ------------------------------------------------------------------ elliptic solver
 
-static void relax_sweeps(msom *m, int k, int nrelax) {
+static void relax_sweeps(msom *m, int k, int nrelax, int last_level_exchange_corners = 0) {
   const bool prof = m->profile && k == 0;
   for (int it = 0; it < nrelax; it++) {
     if (prof) prof_begin(m, m->prof_sweep);
-    for (int c = 0; c < 2; c++)
+    for (int c = 0; c < 2; c++) {
       launch_relax_color(m->st, m->da[k], m->res[k], m->S[k], m->sg[k], m->nl, m->rc[k], m->uniformS, c, m->walls, k == 0);
+      // boundary_level(da, l): the last exchange of the level also carries the corner ghosts
+      // that the bilinear prolongation to the next finer level reads
+      STICKY(m, exch_split(m, m->da[k], m->sg[k], m->nl, last_level_exchange_corners && it == nrelax - 1 && c == 1));
+    }
     if (prof) prof_end(m, m->prof_sweep);
   }
 }
@@ -558,16 +690,31 @@ static void mg_cycle(msom *m, double *a, int nrelax) {
   for (int k = 1; k < m->nlev; k++) launch_restrict(m->st, m->res[k - 1], m->sg[k - 1], m->res[k], m->sg[k], m->nl);
   for (int k = m->nlev - 1; k >= 0; k--) {
     if (k == m->nlev - 1) hipMemsetAsync(m->da[k], 0, m->sg[k].ls * m->nl * sizeof(double), m->st);
-    else launch_prolong(m->st, m->da[k + 1], m->sg[k + 1], m->da[k], m->sg[k], m->nl, m->walls);
-    relax_sweeps(m, k, nrelax);
+    else {
+      launch_prolong(m->st, m->da[k + 1], m->sg[k + 1], m->da[k], m->sg[k], m->nl, m->walls);
+      STICKY(m, exch_split(m, m->da[k], m->sg[k], m->nl, 0));
+    }
+    relax_sweeps(m, k, nrelax, k > 0);
   }
   launch_correct(m->st, a, m->g, m->da[0], m->sg[0], m->nl, m->walls);
+  if (m->nranks > 1) STICKY(m, exch_nat(m, a, m->nl, m->bc, 1));  // boundary(a)
 }
 
 static void residual(msom *m, const double *a, const double *b, int slot, int want_sum) {
   if (m->profile) prof_begin(m, m->prof_resid);
   launch_residual(m->st, a, b, m->f[MSOM_S], m->g, m->res[0], m->sg[0], m->nl, m->rc[0], m->uniformS, m->d_scal + slot, m->partial, want_sum);
   if (m->profile) prof_end(m, m->prof_resid);
+}
+
+// max-residual slots (RES0, RES1) and the rhs sum (BSUM) -> host, reduced over the tiles
+// (the reference's foreach(reduction(max:maxres)) / reduction(+:sum) are MPI all-reduces)
+static int read_residuals(msom *m) {
+  if (m->nranks > 1) {
+    int r = reduce_scal(m, SC_RES0, 2, RED_MAX);
+    if (r) return r;
+    return reduce_scal(m, SC_BSUM, 1, RED_SUM);
+  }
+  return reduce_scal(m, 0, 4, RED_MAX);
 }
 
 // mg_solve, mspg/elliptic.h:145-229, called as poisson_layer does (msqg/poisson_layer.h:290-303).
@@ -582,8 +729,8 @@ static int mg_solve(msom *m, double *a, const double *b, msom_mgstats *s) {
   bool have_first = false;
   double resb = 0;
   if (p.nitermin < 1) {  // need the initial residual before deciding on the first cycle
-    HIPCHK(hipMemcpyAsync(m->h_scal, m->d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, m->st));
-    HIPCHK(hipStreamSynchronize(m->st));
+    int rr = read_residuals(m);
+    if (rr) return rr;
     resb = s->resb = s->resa = m->h_scal[SC_RES0];
     s->sum = m->h_scal[SC_BSUM];
     have_first = true;
@@ -592,8 +739,8 @@ static int mg_solve(msom *m, double *a, const double *b, msom_mgstats *s) {
     mg_cycle(m, a, s->nrelax);
     HIPCHK(hipMemsetAsync(m->d_scal + SC_RES1, 0, sizeof(double), m->st));
     residual(m, a, b, SC_RES1, 0);
-    HIPCHK(hipMemcpyAsync(m->h_scal, m->d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, m->st));
-    HIPCHK(hipStreamSynchronize(m->st));
+    int rr = read_residuals(m);
+    if (rr) return rr;
     if (!have_first) {
       resb = s->resb = m->h_scal[SC_RES0];
       s->sum = m->h_scal[SC_BSUM];
@@ -607,8 +754,8 @@ static int mg_solve(msom *m, double *a, const double *b, msom_mgstats *s) {
     resb = s->resa;
   }
   if (!have_first) {  // nitermax == 0
-    HIPCHK(hipMemcpyAsync(m->h_scal, m->d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, m->st));
-    HIPCHK(hipStreamSynchronize(m->st));
+    int rr = read_residuals(m);
+    if (rr) return rr;
     s->resb = s->resa = m->h_scal[SC_RES0];
     s->sum = m->h_scal[SC_BSUM];
   }
@@ -658,8 +805,7 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
   comp_del2(m, MSOM_PSI, MSOM_ZETA, 0., 1.0);
   launch_advection(m->st, m->f[MSOM_ZETA], m->f[MSOM_PSI], m->f[MSOM_PSIPG], m->f[MSOM_ZETAPG], m->f[MSOM_S], m->f[qfield], m->f[dqfield],
                    m->g, nl, m->have_pg, m->have_zpg, m->stochastic, D, p.beta, p.itr_stoch, m->lc);
-  HIPCHK(hipMemsetAsync(m->d_scal + SC_UMAX, 0, MSOM_MAXNL * sizeof(double), m->st));
-  launch_umax(m->st, m->f[MSOM_PSI], nullptr, 1, m->d_scal + SC_UMAX, m->g, nl, D);
+  launch_umax(m->st, m->f[MSOM_PSI], m->partial_umax, m->d_scal + SC_UMAX, m->g, nl, D);
   // dissip :407-422 (terms with a zero coefficient add exactly 0 and are skipped)
   if (iRe != 0) comp_stretch(m, MSOM_ZETA, dqfield, 1., iRe);
   if (iRe != 0 || iRe4 != 0) comp_del2(m, MSOM_ZETA, MSOM_TMP, 0., 1.);
@@ -681,8 +827,8 @@ static double update_qg(msom *m, int qfield, int dqfield, double dtmax) {
   if (hipMemsetAsync(m->f[dqfield], 0, m->g.ls * nl * sizeof(double), m->st) != hipSuccess) return -1;
   if (invertq(m, m->f[MSOM_PSI], m->f[qfield])) return -1;
   if (rhs_terms(m, qfield, dqfield, 1, p.iRe, p.iRe4, p.Eks, p.Ekb)) return -1;
-  if (hipMemcpyAsync(m->h_scal + SC_UMAX, m->d_scal + SC_UMAX, nl * sizeof(double), hipMemcpyDeviceToHost, m->st) != hipSuccess) return -1;
-  if (hipStreamSynchronize(m->st) != hipSuccess) return -1;
+  if (reduce_scal(m, SC_UMAX, nl, RED_MAX)) return -1;
+  if (m->sticky) return -1;
   // :383-391: 2*nl limiter calls (psi_l then psipg_l) sharing one static `previous`
   for (int l = 0; l < nl; l++) {
     dtmax = limiter(m, m->h_scal[SC_UMAX + l], dtmax);
@@ -895,8 +1041,7 @@ extern "C" int msom_iter(msom_t *m) { return m ? m->iter : -1; }
 extern "C" double msom_ke(msom_t *m) {
   if (!m) return NAN;
   launch_ke(m->st, m->f[MSOM_PSI], m->partial, m->d_scal + SC_KE, m->g, m->p.L0 / m->gnx);
-  if (hipMemcpyAsync(m->h_scal + SC_KE, m->d_scal + SC_KE, sizeof(double), hipMemcpyDeviceToHost, m->st) != hipSuccess) return NAN;
-  if (hipStreamSynchronize(m->st) != hipSuccess) return NAN;
+  if (reduce_scal(m, SC_KE, 1, RED_SUM)) return NAN;
   return -m->h_scal[SC_KE];
 }
 
@@ -1011,16 +1156,20 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
 
 extern "C" int msom_comm_unique_id(void *id128) {
   if (!id128) return MSOM_ERR_ARG;
-  memset(id128, 0, 128);
-  return MSOM_OK;
+  return comm_unique_id(id128);
 }
+// One tile of a px x py decomposition.  id128 = ncclUniqueId from msom_comm_unique_id (RCCL
+// transport, one process per GPU), or "MSOMLOCL" + 8-byte key for the in-process test
+// transport (one host thread per tile).
 extern "C" msom_t *msom_create_tiled(const char *params_text, int px, int py, int rank, const void *id128) {
-  (void)id128;
-  if (px != 1 || py != 1 || rank != 0) {
-    msom_set_error("tiled mode (px*py > 1) is not implemented in this build");
+  if (!params_text || px < 1 || py < 1 || rank < 0 || rank >= px * py || (px * py > 1 && !id128)) {
+    msom_set_error("msom_create_tiled: bad arguments");
     return nullptr;
   }
-  return msom_create_str(params_text);
+  Params p;
+  msom_params_defaults(&p);
+  msom_params_parse_text(&p, params_text);
+  return create_common(p, px, py, rank, id128);
 }
 extern "C" int msom_tile_info(msom_t *m, int *px, int *py, int *ix, int *iy, int *nx_local, int *ny_local) {
   if (!m) return MSOM_ERR_ARG;
@@ -1059,6 +1208,7 @@ extern "C" int msom_dbg_relax(msom_t *m, int lev, double *da, const double *res,
   int r;
   if ((r = split_upload(m, m->da[lev], m->sg[lev], da, m->nl, BC_DIRICHLET0))) return r;
   if ((r = split_upload(m, m->res[lev], m->sg[lev], res, m->nl, BC_NEUMANN))) return r;
+  STICKY(m, exch_split(m, m->da[lev], m->sg[lev], m->nl, 0));
   const int prof = m->profile;
   m->profile = 0;
   relax_sweeps(m, lev, nsweeps);
@@ -1090,6 +1240,7 @@ extern "C" int msom_dbg_prolong(msom_t *m, int lev_coarse, const double *coarse,
   if (lev_coarse < 1 || lev_coarse >= m->nlev) return MSOM_ERR_ARG;
   int r;
   if ((r = split_upload(m, m->da[lev_coarse], m->sg[lev_coarse], coarse, m->nl, BC_DIRICHLET0))) return r;
+  STICKY(m, exch_split(m, m->da[lev_coarse], m->sg[lev_coarse], m->nl, 1));
   launch_prolong(m->st, m->da[lev_coarse], m->sg[lev_coarse], m->da[lev_coarse - 1], m->sg[lev_coarse - 1], m->nl, m->walls);
   return split_download(m, m->da[lev_coarse - 1], m->sg[lev_coarse - 1], fine, m->nl);
 }

@@ -15,6 +15,7 @@ struct Params {
   double tr_stoch, itr_stoch, amp_stoch;
   double tolerance; /* extension key TOLERANCE (reference: 1e-3, msqg/qg.h:159) */
   int nitermax, nitermin;
+  int mglevels; /* extension key MGLEVELS: cap on the number of multigrid levels (0 = all) */
 };
 
 #ifdef __cplusplus

@@ -40,7 +40,7 @@ static const keydef KEYS[] = {
   K("amp_stoch", T_DBL, amp_stoch),
   /* extension keys, unknown to (hence ignored by) the reference parser */
   K("Ny", T_INT, Ny), K("TOLERANCE", T_DBL, tolerance), K("NITERMAX", T_INT, nitermax),
-  K("NITERMIN", T_INT, nitermin),
+  K("NITERMIN", T_INT, nitermin), K("MGLEVELS", T_INT, mglevels),
 };
 
 /* defaults: msqg/qg.h:63-106; N, L0, DT, CFL are Basilisk globals (64, 1, 1e10, 0.5) */

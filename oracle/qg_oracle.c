@@ -47,7 +47,7 @@ struct orc {
   double tr_stoch, itr_stoch, amp_stoch;
   /* solver controls, mspg/elliptic.h:111-112, msqg/qg.h:159 */
   double tolerance;
-  int nitermax, nitermin, smoother, quiet;
+  int nitermax, nitermin, smoother, quiet, mglevels;
   /* fields */
   fld f[ORC_NFIELDS];
   /* multigrid hierarchy: level 0 = finest */
@@ -168,12 +168,14 @@ static void parse_line(orc_t *o, char *buf, int *N, int *Ny) {
   else if (!strcmp(k, "vpg")) str2array(v, o->vpg);
   else if (!strcmp(k, "tr_stoch")) o->tr_stoch = atof(v);
   else if (!strcmp(k, "amp_stoch")) o->amp_stoch = atof(v);
+  else if (!strcmp(k, "MGLEVELS")) o->mglevels = atoi(v); /* extension: cap on MG levels */
 }
 
 static void build_levels(orc_t *o) {
   int n = 0, nx = o->nx, ny = o->ny;
   /* minlevel = 1 (msqg/poisson_layer.h:296-297): coarsest grid has 2 cells on its short side */
   while ((nx >> n) >= 2 && (ny >> n) >= 2 && ((nx >> n) << n) == nx && ((ny >> n) << n) == ny) n++;
+  if (o->mglevels > 0 && o->mglevels < n) n = o->mglevels;
   o->nlev = n;
   o->da = (fld *)calloc(n, sizeof(fld));
   o->res = (fld *)calloc(n, sizeof(fld));

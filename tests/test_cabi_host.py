@@ -22,7 +22,7 @@ class Params(C.Structure):
                                               "afilt", "Lfmax", "DT", "tend", "dtout", "dtflt", "CFL")]
                 + [(k, C.c_double * MAXARR) for k in ("Frm", "dhu", "upg", "vpg")]
                 + [(k, C.c_double) for k in ("tr_stoch", "itr_stoch", "amp_stoch", "tolerance")]
-                + [("nitermax", C.c_int), ("nitermin", C.c_int)])
+                + [("nitermax", C.c_int), ("nitermin", C.c_int), ("mglevels", C.c_int)])
 
 
 def declared_symbols():

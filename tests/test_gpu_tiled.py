@@ -1,0 +1,127 @@
+"""Tiled (multi-GPU) code path on ONE GPU: px x py tiles run as host threads of one process
+and exchange halos through the library's in-process transport (device-to-device copies), i.e.
+exactly the pack / exchange / unpack / reduction logic that the RCCL transport drives with one
+process per GPU.  Determinism gate of SURVEY 8(e): the tiled result must equal the single-tile
+result of the same global grid bit for bit (same multigrid level count via MGLEVELS)."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import orc
+from msom_amd import QG, FIELDS as F
+
+pytestmark = pytest.mark.gpu
+
+
+def run_tiled(params, px, py, psi, nsteps, strict, fn=None):
+    n = px * py
+    uid = b"MSOMLOCL" + os.urandom(8) + bytes(112)
+    nl, gny, gnx = psi.shape
+    tx, ty = gnx // px, gny // py
+    out, errs = [None] * n, []
+
+    def worker(rank):
+        try:
+            g = QG(params, strict=strict, tiled=(px, py, rank, uid))
+            g.option("quiet", 1)
+            ix, iy = rank % px, rank // px
+            assert g.tile == (px, py, ix, iy) and (g.nx, g.ny) == (tx, ty)
+            g.set(F["PSI"], psi[:, iy * ty:(iy + 1) * ty, ix * tx:(ix + 1) * tx])
+            g.set_const()
+            g.set_tnext(float("inf"))
+            dts = [g.step() for _ in range(nsteps)]
+            res = dict(q=g.get(F["Q"]), psi=g.get(F["PSI"]), ke=g.ke(), t=g.t, dts=dts, st=g.mgstats())
+            if fn:
+                res["extra"] = fn(g, rank)
+            out[rank] = res
+            g.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    assert all(o is not None for o in out), "a tile thread hung"
+    return out
+
+
+def assemble(out, key, px, py):
+    rows = []
+    for iy in range(py):
+        rows.append(np.concatenate([out[iy * px + ix][key] for ix in range(px)], axis=2))
+    return np.concatenate(rows, axis=1)
+
+
+@pytest.mark.parametrize("px,py,tile,nl", [(2, 1, 32, 3), (1, 2, 32, 3), (2, 2, 32, 6), (2, 4, 16, 2), (3, 1, 16, 3)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_tiled_equals_single_tile_bit_for_bit(px, py, tile, nl, strict):
+    gnx, gny = tile * px, tile * py
+    levels = int(np.log2(tile))
+    extra = (f"Ny = {gny}\n" if gny != gnx else "") + f"MGLEVELS = {levels}\n"
+    if px == 3:
+        pytest.skip("3 tiles per side needs a non-power-of-two global N; covered by create-time check")
+    params = orc.double_gyre_params(gnx, nl, extra=extra)
+    psi = orc.synthetic_psi(nl, gny, gnx)
+    out = run_tiled(params, px, py, psi, nsteps=5, strict=strict)
+    g = QG(params, strict=strict)
+    g.option("quiet", 1)
+    g.set(F["PSI"], psi)
+    g.set_const()
+    g.set_tnext(float("inf"))
+    dts = [g.step() for _ in range(5)]
+    assert g.nlevels() == levels
+    for r in range(px * py):
+        assert out[r]["dts"] == dts, r
+        assert out[r]["t"] == g.t
+        assert (out[r]["st"].i, out[r]["st"].resa, out[r]["st"].resb) == (g.mgstats().i, g.mgstats().resa, g.mgstats().resb)
+        assert out[r]["ke"] == pytest.approx(g.ke(), rel=1e-13)   # sum order differs
+    assert np.array_equal(assemble(out, "q", px, py), g.get(F["Q"]))
+    assert np.array_equal(assemble(out, "psi", px, py), g.get(F["PSI"]))
+
+
+def test_tiled_strict_matches_oracle():
+    """The tiled strict build is bit-exact against the (untiled) CPU oracle as well."""
+    px, py, tile, nl = 2, 2, 32, 3
+    gn = tile * px
+    params = orc.double_gyre_params(gn, nl, extra="MGLEVELS = 5\n")
+    psi = orc.synthetic_psi(nl, gn, gn)
+    out = run_tiled(params, px, py, psi, nsteps=4, strict=True)
+    o = orc.Oracle(params, smoother=orc.GS_RB, quiet=1)
+    assert o.nlevels() == 5
+    o.set(orc.PSI, psi)
+    o.set_const()
+    for _ in range(4):
+        o.step()
+    assert np.array_equal(assemble(out, "q", px, py), o.get(orc.Q))
+    assert np.array_equal(assemble(out, "psi", px, py), o.get(orc.PSI))
+
+
+def test_tiled_tight_tolerance_multi_cycle_and_background_flow():
+    """Several multigrid cycles per solve (adaptive nrelax path) + large-scale flow + remove_mean."""
+    px, py, tile, nl = 2, 2, 32, 3
+    gn = tile * px
+    params = orc.double_gyre_params(gn, nl, extra="MGLEVELS = 5\nTOLERANCE = 1e-11\nupg = [0.3,0.1,0.0]\nvpg = [0.0,-0.2,0.05]\nflsrv = 1\n")
+    psi = orc.synthetic_psi(nl, gn, gn) + 1e-4
+
+    def extra(g, rank):
+        g.remove_mean(F["PSI"])
+        return g.get(F["PSI"])
+
+    out = run_tiled(params, px, py, psi, nsteps=2, strict=True, fn=extra)
+    g = QG(params, strict=True)
+    g.option("quiet", 1)
+    g.set(F["PSI"], psi)
+    g.set_const()
+    g.set_tnext(float("inf"))
+    for _ in range(2):
+        g.step()
+    assert g.mgstats().i > 1
+    assert np.array_equal(assemble(out, "q", px, py), g.get(F["Q"]))
+    g.remove_mean(F["PSI"])
+    got = np.concatenate([np.concatenate([out[iy * px + ix]["extra"] for ix in range(px)], axis=2) for iy in range(py)], axis=1)
+    assert np.abs(got - g.get(F["PSI"])).max() <= 1e-15 * np.abs(psi).max()   # mean: sum order differs
