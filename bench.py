@@ -28,10 +28,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 
 
-def tile_grid(n):
-    return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (2, 4)}[n]
-
-
 def cpu_baseline(nl, n_cpu=1024, steps=2):
     """CPU oracle (plain C + OpenMP, red-black smoother) on a bounded sample: `steps` RK2 steps
     of the same parameter set on an n_cpu^2 x nl grid; grid-point-updates/s is size-normalised."""
@@ -94,53 +90,38 @@ def main():
     dist = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", "")  # keep as launched
         import torch
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    px, py = tile_grid(world)
+    from msom_amd import load_library, tiling
+
+    px, py = tiling.tile_grid(world)
     N, nl = args.N, args.nl
     gnx, gny = N * px, N * py
-    params = orc.double_gyre_params(gnx, nl, extra=(f"Ny = {gny}\n" if gny != gnx else ""))
-    # Re4(N) keeps the viscous clamp at DT = 0.025; per-tile resolution fixed.
+    # weak scaling: the tile (N x N x nl, Delta = 80/N) is fixed, the domain grows with the tile grid
+    params = orc.double_gyre_params(gnx, nl, extra=(f"Ny = {gny}\n" if gny != gnx else ""), L0=80.0 * px)
+    lib = load_library()
+    if lib.msom_set_device(local_rank) != 0:
+        raise SystemExit(lib.msom_last_error().decode())
     if world > 1:
-        import ctypes
-
-        import torch
-
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            from msom_amd import load_library
-
-            buf = (ctypes.c_char * 128)()
-            load_library().msom_comm_unique_id(buf)
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-        uid = uid.cuda()
-        dist.broadcast(uid, 0)
-        uid_bytes = bytes(uid.cpu().numpy().tobytes())
-        g = QG(params, tiled=(px, py, rank, uid_bytes))
+        uid = tiling.broadcast_unique_id(dist, lambda: tiling.rccl_unique_id(lib), device="cuda")
+        g = QG(params, tiled=(px, py, rank, uid))
     else:
         g = QG(params)
     g.option("quiet", 1)
-    # synthetic IC on this rank's tile (global sine modes sampled on the tile)
-    ix, iy = rank % px, rank // px
-    full = orc.synthetic_psi(nl, gny, gnx) if world == 1 else None
-    if full is None:
-        x = (np.arange(gnx) + 0.5) / gnx
-        y = (np.arange(gny) + 0.5) / gny
-        xs, ys = x[ix * N:(ix + 1) * N], y[iy * N:(iy + 1) * N]
-        full = np.zeros((nl, N, N))
-        for l in range(nl):
-            for k in range(1, 5):
-                for m in range(1, 5):
-                    c = np.sin(1.7 * k + 2.3 * m + 0.9 * l) / (k * m)
-                    full[l] += c * np.outer(np.sin(m * np.pi * ys), np.sin(k * np.pi * xs))
-            full[l] *= 1e-3 * (1.0 - 0.15 * l)
-    g.set(F["PSI"], full)
-    del full
+
+    # synthetic seed-free IC: global sine modes sampled on this rank's tile
+    def psi_fn(l, y, x):
+        f = np.zeros((y.size, x.size))
+        for k in range(1, 5):
+            for m in range(1, 5):
+                f += np.sin(1.7 * k + 2.3 * m + 0.9 * l) / (k * m) * np.outer(np.sin(m * np.pi * y), np.sin(k * np.pi * x))
+        return 1e-3 * (1.0 - 0.15 * l) * f
+
+    g.set(F["PSI"], tiling.synthetic_tile(psi_fn, rank, px, py, nl, N, N))
     g.set_const()
     g.set_tnext(float("inf"))
 

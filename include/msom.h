@@ -134,6 +134,10 @@ int msom_run(msom_t *m, const char *workdir, long nsteps_max);
 int msom_write_bas(msom_t *m, int field, const char *path);
 int msom_read_bas(msom_t *m, int field, const char *path);
 
+/* select the HIP device of the calling thread before msom_create* (one process per GPU:
+ * device = LOCAL_RANK) */
+int msom_set_device(int device);
+
 /* ---- multi-GPU tiling (replaces Basilisk's MPI layer: boundary() halo exchange and
  * foreach(reduction)).  One process per GPU; the 2-D domain is a px x py grid of
  * equal tiles; rank r owns tile (r % px, r / px).  id128 is the 128-byte ncclUniqueId made by

@@ -70,6 +70,7 @@ def load_library(strict=False):
         "msom_run": (ci, [vp, cs, C.c_long]),
         "msom_write_bas": (ci, [vp, ci, cs]),
         "msom_read_bas": (ci, [vp, ci, cs]),
+        "msom_set_device": (ci, [ci]),
         "msom_comm_unique_id": (ci, [vp]),
         "msom_create_tiled": (vp, [cs, ci, ci, ci, vp]),
         "msom_tile_info": (ci, [vp] + [C.POINTER(ci)] * 6),

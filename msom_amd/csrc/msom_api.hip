@@ -1154,6 +1154,11 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
 
 // ------------------------------------------------------------------ tiling (single tile for now)
 
+extern "C" int msom_set_device(int device) {
+  HIPCHK(hipSetDevice(device));
+  return MSOM_OK;
+}
+
 extern "C" int msom_comm_unique_id(void *id128) {
   if (!id128) return MSOM_ERR_ARG;
   return comm_unique_id(id128);

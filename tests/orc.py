@@ -295,9 +295,12 @@ LAYERS = {
 }
 
 
-def double_gyre_params(N, nl, extra=""):
+def double_gyre_params(N, nl, extra="", L0=80.0):
+    """Verron double gyre with N, nl overridden; Re4 ~ Delta^-4 keeps the viscous
+    clamp of msqg/qg.h:746 at DT = 0.025 for every resolution."""
     Fr, dh = LAYERS[nl]
-    return DOUBLE_GYRE.format(N=N, nl=nl, Re4=1563.0 * (N / 256.0) ** 4, Fr=Fr, dh=dh) + extra
+    delta_ratio = (80.0 / 256.0) / (L0 / N)
+    return DOUBLE_GYRE.format(N=N, nl=nl, Re4=1563.0 * delta_ratio ** 4, Fr=Fr, dh=dh).replace("L0 = 80", f"L0 = {L0}") + extra
 
 
 def synthetic_psi(nl, ny, nx, amp=1e-3):

@@ -125,3 +125,15 @@ def test_tiled_tight_tolerance_multi_cycle_and_background_flow():
     g.remove_mean(F["PSI"])
     got = np.concatenate([np.concatenate([out[iy * px + ix]["extra"] for ix in range(px)], axis=2) for iy in range(py)], axis=1)
     assert np.abs(got - g.get(F["PSI"])).max() <= 1e-15 * np.abs(psi).max()   # mean: sum order differs
+
+
+def test_rccl_library_resolves():
+    """dlopen(librccl) + symbol table + ncclGetUniqueId through the C ABI (the N > 1 RCCL
+    transport itself needs one GPU per rank and is exercised by bench.py --gpus N)."""
+    import ctypes
+    from msom_amd import load_library
+    L = load_library()
+    buf = (ctypes.c_char * 128)()
+    assert L.msom_comm_unique_id(buf) == 0, L.msom_last_error()
+    assert any(b != 0 for b in buf.raw)
+    assert L.msom_set_device(0) == 0
