@@ -46,6 +46,13 @@ void launch_sum_layers(hipStream_t st, const double *f, double *partial, double 
 void launch_sub_layer_const(hipStream_t st, double *f, const double *sums, const NatGeom &g, int nl, double inv_count);
 void launch_make_S(hipStream_t st, const double *Fr, const double *Ro, double *S, const NatGeom &g, int nlm);
 
+// ---- kernels_fused.hip
+int rhs_fused_blocks(const NatGeom &g);
+void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq,
+                      double *umax_partial, double *umax_out, const NatGeom &g, int nl, int walls, int uniformS, const double *Su,
+                      int have_qforc, double D, double beta, double iRe, double iRe4, double cs, double cb, double slip_c,
+                      const LayerCoef &lc);
+
 // ---- kernels_mg.hip
 void launch_nat_to_split(hipStream_t st, const double *nat, const NatGeom &g, double *sp, const SplitGeom &sg, int nl);
 void launch_split_to_nat(hipStream_t st, const double *sp, const SplitGeom &sg, double *nat, const NatGeom &g, int nl);

@@ -76,6 +76,7 @@ struct msom {
   int const_set = 0, flag_topo = 0, have_pg = 0, have_zpg = 0, have_qforc = 0;
   int fr_uniform = 1, uniformS = 0, uniform_opt = -1 /* auto */;
   int stochastic = 0, corrector_step = 0, noise_mode = 0;
+  int fused = 1;  // one-pass PV tendency kernel (kernels_fused.hip) when the configuration allows
   unsigned seed = 1;
   int quiet = 0;
   // time loop
@@ -283,7 +284,11 @@ static int alloc_all(msom *m) {
   }
   HIPCHK(hipMalloc(&m->staging, (size_t)m->nl * m->nx * m->ny * sizeof(double)));
   HIPCHK(hipMalloc(&m->partial, (size_t)partial_count(m->g) * m->nl * sizeof(double)));
-  HIPCHK(hipMalloc(&m->partial_umax, (size_t)2048 * MSOM_MAXNL * sizeof(double)));
+  {
+    size_t nb = (size_t)rhs_fused_blocks(m->g);
+    if (nb < 2048) nb = 2048;
+    HIPCHK(hipMalloc(&m->partial_umax, nb * MSOM_MAXNL * sizeof(double)));
+  }
   HIPCHK(hipMalloc(&m->d_scal, SC_COUNT * sizeof(double)));
   HIPCHK(hipMemsetAsync(m->d_scal, 0, SC_COUNT * sizeof(double), m->st));
   HIPCHK(hipHostMalloc(&m->h_scal, SC_COUNT * sizeof(double)));
@@ -429,6 +434,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
     if (m->const_set) return build_coefs(m);
   }
   else if (!strcmp(key, "profile")) m->profile = (int)v;
+  else if (!strcmp(key, "fused")) m->fused = (int)v;
   else if (!strcmp(key, "seed")) { m->seed = (unsigned)v; srand(m->seed); }
   else if (!strcmp(key, "noise_mode")) m->noise_mode = (int)v;
   else if (!strcmp(key, "stochastic")) {
@@ -802,6 +808,15 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
   const Params &p = m->p;
   const double D = p.L0 / m->gnx;
   const int nl = m->nl;
+  if (m->fused && !m->have_pg && !m->have_zpg && !m->flag_topo && !m->stochastic && m->nranks == 1) {
+    // one pass over psi: zeta, Jacobians, beta, dissipation, drag, forcing, max|u| (kernels_fused.hip)
+    launch_rhs_fused(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, m->f[dqfield], m->partial_umax,
+                     m->d_scal + SC_UMAX, m->g, nl, m->walls, m->uniformS, m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe,
+                     iRe4, Eks / (p.Rom * 2 * m->dhf[0]), Ekb / (p.Rom * 2 * m->dhf[nl - 1]),
+                     p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc);
+    return MSOM_OK;
+  }
+  HIPCHK(hipMemsetAsync(m->f[dqfield], 0, m->g.ls * nl * sizeof(double), m->st));  // updates = 0, msqg/qg.h:611-613
   comp_del2(m, MSOM_PSI, MSOM_ZETA, 0., 1.0);
   launch_advection(m->st, m->f[MSOM_ZETA], m->f[MSOM_PSI], m->f[MSOM_PSIPG], m->f[MSOM_ZETAPG], m->f[MSOM_S], m->f[qfield], m->f[dqfield],
                    m->g, nl, m->have_pg, m->have_zpg, m->stochastic, D, p.beta, p.itr_stoch, m->lc);
@@ -824,7 +839,6 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
 static double update_qg(msom *m, int qfield, int dqfield, double dtmax) {
   const Params &p = m->p;
   const int nl = m->nl;
-  if (hipMemsetAsync(m->f[dqfield], 0, m->g.ls * nl * sizeof(double), m->st) != hipSuccess) return -1;
   if (invertq(m, m->f[MSOM_PSI], m->f[qfield])) return -1;
   if (rhs_terms(m, qfield, dqfield, 1, p.iRe, p.iRe4, p.Eks, p.Ekb)) return -1;
   if (reduce_scal(m, SC_UMAX, nl, RED_MAX)) return -1;
@@ -967,7 +981,7 @@ extern "C" int pystep_bfn(msom_t *m, double *varin_py, int len1, int len2, int l
     p.iRe4 = p.Re4 == 0 ? 0. : 1 / p.Re4;
     p.Eks = -fabs(p.Eks); p.Ekb = -fabs(p.Ekb);
   }
-  HIPCHK(hipMemsetAsync(m->f[MSOM_DQ], 0, m->g.ls * m->nl * sizeof(double), m->st));  // reset_layer_var(bfn_tendl)
+  if (vartype != 1) HIPCHK(hipMemsetAsync(m->f[MSOM_DQ], 0, m->g.ls * m->nl * sizeof(double), m->st));  // reset_layer_var(bfn_tendl)
   if (vartype == 1) {
     if ((r = upload(m, MSOM_Q, varin_py))) return r;
     if ((r = invertq(m, m->f[MSOM_PSI], m->f[MSOM_Q]))) return r;

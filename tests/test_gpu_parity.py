@@ -352,3 +352,26 @@ def test_full_size_properties(N, nl):
     # reported residual == recomputed residual
     _, mres = g.residual(p, q_exact)
     assert mres == pytest.approx(st.resa, rel=1e-12)
+
+
+@pytest.mark.parametrize("nx,ny,nl", [(64, 64, 3), (128, 32, 6), (32, 32, 1), (16, 16, 2), (256, 128, 4)])
+@pytest.mark.parametrize("extra", ["", "sbc = 1.5\nRe = 300\nEks = 0.001\n"])
+def test_fused_tendency_equals_unfused_chain(nx, ny, nl, extra):
+    """kernels_fused.hip (one pass over psi) against the kernel-per-reference-loop chain:
+    bit-exact in the strict build, and both bit-exact against the oracle."""
+    o, g = make_pair(nx, ny, nl, strict=True, extra=extra, TOLERANCE=1e-9)
+    qf = rand_field(31, (nl, ny, nx), 1e-7)
+    o.set(orc.QFORC, qf); g.set(F["QFORC"], qf)
+    q = o.get(orc.Q)
+    d_o = o.update()
+    g.option("fused", 1)
+    dq1, d1 = g.update()
+    g.option("fused", 0)
+    g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx)); 
+    g2 = make_pair(nx, ny, nl, strict=True, extra=extra, TOLERANCE=1e-9)[1]
+    g2.set(F["QFORC"], qf)
+    g2.option("fused", 0)
+    dq0, d0 = g2.update()
+    assert d1 == d0 == d_o
+    assert np.array_equal(dq1, dq0)
+    assert np.array_equal(dq1, o.get(orc.DQ))
