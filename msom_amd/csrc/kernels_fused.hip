@@ -26,16 +26,17 @@
 #define DIVC(x, c, rc) ((x) * (rc))
 #endif
 
-#define FTX 64
-#define FTY 16
-#define FNT 256
-#define NPT (FTX * FTY / FNT)
+#define FTX 64            // tile width  = one wavefront
+#define FTY 32            // tile height
+#define FNT 512           // threads per workgroup (8 waves)
+#define RPT (FTX * FTY / FNT)   // consecutive rows per thread (sliding 3x3 windows)
 #define PW (FTX + 6)
 #define PH (FTY + 6)
 #define ZW (FTX + 4)
 #define ZH (FTY + 4)
 #define TW (FTX + 2)
 #define TH (FTY + 2)
+#define NPF ((PW * PH + FNT - 1) / FNT)   // prefetch registers per thread
 
 struct RhsArgs {
   const double *psi, *S, *qforc, *wind;
@@ -65,31 +66,43 @@ __device__ __forceinline__ double mjac9(const double (&p)[3][3], const double (&
   return DIVC(s, D12, rD12);
 }
 
-// Dirichlet ghost fill of an LDS tile `t` (width W, height H, halo h around the FTX x FTY
-// block at (x0, y0)): every position that lies outside a wall gets sign * t[mirror];
-// with partial slip the edge ghosts are c * (src[mirror] - src[ghost]) instead, where src is
-// the field the Laplacian was taken of (halo hs, width SW).
+// lap(src) into an LDS tile `dst` (W x H, halo h around the block at (x0, y0)); src is an LDS
+// tile of width SW and halo hs = h + 1.  Positions outside a wall are the ghost cells of
+// boundary(): sign * lap(src)(mirror) (edges -, corners +), or the partial-slip value
+// c * (src(mirror) - src(ghost)) on the first ghost line (msqg/qg.h:185-198).
 template <int W, int H, int h, int SW, int hs>
-__device__ __forceinline__ void lds_wall_ghosts(double *t, const double *src, int x0, int y0, int nx, int ny, int walls, double slip_c) {
+__device__ __forceinline__ void lds_lap_bc(double *dst, const double *src, int x0, int y0, int nx, int ny, int walls, double slip_c,
+                                           double D2, double rD2) {
   for (int idx = threadIdx.x; idx < W * H; idx += FNT) {
     const int li = idx % W, lj = idx / W;
     const int gi = x0 + li - h, gj = y0 + lj - h;
     const bool ox = (gi < 0 && (walls & WALL_W)) || (gi >= nx && (walls & WALL_E));
     const bool oy = (gj < 0 && (walls & WALL_S)) || (gj >= ny && (walls & WALL_N));
-    if (!(ox | oy)) continue;
-    const int mi = ox ? (gi < 0 ? -1 - gi : 2 * nx - 1 - gi) : gi;
-    const int mj = oy ? (gj < 0 ? -1 - gj : 2 * ny - 1 - gj) : gj;
-    const int ti = mi - x0 + h, tj = mj - y0 + h;
-    double v = 0.;
-    if (ti >= 0 && ti < W && tj >= 0 && tj < H) {
-      v = t[tj * W + ti];
+    int ci = li + (hs - h), cj = lj + (hs - h);  // same position in src coordinates
+    double sign = 1.;
+    bool slip = false, valid = true;
+    if (ox | oy) {
+      const int mi = ox ? (gi < 0 ? -1 - gi : 2 * nx - 1 - gi) : gi;
+      const int mj = oy ? (gj < 0 ? -1 - gj : 2 * ny - 1 - gj) : gj;
+      const int ti = mi - x0 + hs, tj = mj - y0 + hs;
+      valid = ti >= 1 && ti < SW - 1 && tj >= 1 && tj < H + 2 * (hs - h) - 1;
       if (ox != oy) {
-        const bool depth1 = ox ? (gi == -1 || gi == nx) : (gj == -1 || gj == ny);
-        if (slip_c > 0. && depth1) v = slip_c * (src[(mj - y0 + hs) * SW + (mi - x0 + hs)] - src[(gj - y0 + hs) * SW + (gi - x0 + hs)]);
-        else v = -v;
+        sign = -1.;
+        slip = slip_c > 0. && (ox ? (gi == -1 || gi == nx) : (gj == -1 || gj == ny));
       }
+      if (slip) {
+        dst[idx] = valid ? slip_c * (src[tj * SW + ti] - src[cj * SW + ci]) : 0.;
+        continue;
+      }
+      ci = ti; cj = tj;
     }
-    t[idx] = v;
+    double v = 0.;
+    if (valid) {
+      const int c = cj * SW + ci;
+      v = DIVC(src[c + 1] + src[c - 1] + src[c + SW] + src[c - SW] - 4 * src[c], D2, rD2);
+      if (sign < 0.) v = -v;
+    }
+    dst[idx] = v;
   }
 }
 
@@ -99,26 +112,38 @@ __global__ void __launch_bounds__(FNT) k_rhs_fused(RhsArgs a) {
   __shared__ double sT[TW * TH];
   __shared__ double sM[FNT / 64][MSOM_MAXNL];
 
-  const int tid = threadIdx.x, tx = tid & (FTX - 1), ty0 = tid / FTX;
+  const int tid = threadIdx.x, tx = tid & (FTX - 1), ly0 = (tid / FTX) * RPT;
   const int x0 = blockIdx.x * FTX, y0 = blockIdx.y * FTY;
   const int nx = a.g.nx, ny = a.g.ny, nl = a.nl, pitch = a.g.pitch;
   const double D = a.D, D2 = D * D, rD2 = 1. / D2, D12 = 12. * D * D, rD12 = 1. / D12, D2x = 2 * D, rD2x = 1. / D2x, rD = 1. / D;
+  const int gi = x0 + tx;
 
   // per-point registers: values of the previous two layers needed to finalise a layer
-  double t_prev[NPT], lapT_prev[NPT], zc0[NPT], zc1[NPT], tc0[NPT], tc1[NPT], jd_prev[NPT];
+  double t_prev[RPT], lapT_prev[RPT], zc0[RPT], zc1[RPT], tc0[RPT], tc1[RPT], jd_prev[RPT];
 #pragma unroll
-  for (int k = 0; k < NPT; k++) t_prev[k] = lapT_prev[k] = zc0[k] = zc1[k] = tc0[k] = tc1[k] = jd_prev[k] = 0.;
+  for (int k = 0; k < RPT; k++) t_prev[k] = lapT_prev[k] = zc0[k] = zc1[k] = tc0[k] = tc1[k] = jd_prev[k] = 0.;
 
-  auto load_psi = [&](double *dst, int l) {
+  // psi tile (3-cell halo) of one layer: global -> registers, registers -> LDS
+  double pf[NPF];
+  auto fetch = [&](int l) {
     const double *p = a.psi + (size_t)l * a.g.ls;
-    for (int idx = tid; idx < PW * PH; idx += FNT) {
+#pragma unroll
+    for (int r = 0; r < NPF; r++) {
+      const int idx = tid + r * FNT;
       const int li = idx % PW, lj = idx / PW;
-      const int gi = x0 + li - 3, gj = y0 + lj - 3;
-      dst[idx] = (gi >= -3 && gi < nx + 3 && gj >= -3 && gj < ny + 3) ? p[(ptrdiff_t)(gj + MSOM_YP) * pitch + (gi + MSOM_XP)] : 0.;
+      const int fi = x0 + li - 3, fj = y0 + lj - 3;
+      pf[r] = (idx < PW * PH && fi >= -3 && fi < nx + 3 && fj >= -3 && fj < ny + 3) ? p[(ptrdiff_t)(fj + MSOM_YP) * pitch + (fi + MSOM_XP)] : 0.;
+    }
+  };
+  auto stash = [&](double *dst) {
+#pragma unroll
+    for (int r = 0; r < NPF; r++) {
+      const int idx = tid + r * FNT;
+      if (idx < PW * PH) dst[idx] = pf[r];
     }
   };
   // finalise layer l (additions in the order of msqg/qg.h:407-473) and store dq_l
-  auto finalize = [&](int l, int k, int gi, int gj, double t, double lapT, double zm, double zc, double zp, double tm, double tc, double tp) {
+  auto finalize = [&](int l, int gj, double t, double lapT, double zm, double zc, double zp, double tm, double tc, double tp) {
     double dq = t;
     const size_t c = nat_idx(a.g, l, gj, gi);
     double s0 = 0., s1 = 0.;
@@ -127,7 +152,6 @@ __global__ void __launch_bounds__(FNT) k_rhs_fused(RhsArgs a) {
       if (l < nl - 1) s1 = a.uniformS ? a.Su[l] : a.S[c];
     }
     auto stretch = [&](double fac, double pm, double pc, double pp) -> double {
-      if (nl == 1) return 0.;
       if (l == 0) return fac * s1 * (pp - pc) * a.lc.idh1[l];
       if (l < nl - 1) return fac * (s0 * (pm - pc) * a.lc.idh0[l] + s1 * (pp - pc) * a.lc.idh1[l]);
       return fac * s0 * (pm - pc) * a.lc.idh0[l];
@@ -147,60 +171,53 @@ __global__ void __launch_bounds__(FNT) k_rhs_fused(RhsArgs a) {
     a.dq[c] = dq;
   };
 
-  load_psi(sP[0], 0);
+  fetch(0);
+  stash(sP[0]);
+  if (nl > 1) fetch(1);
   for (int l = 0; l < nl; l++) {
-    double *P0 = sP[l & 1], *P1 = sP[(l + 1) & 1];
-    if (l + 1 < nl) load_psi(P1, l + 1);
+    const double *P0 = sP[l & 1], *P1 = sP[(l + 1) & 1];
+    // psi_{l+1} -> LDS (its buffer was last read as P0 of layer l-1, before the closing barrier
+    // of that iteration); then start the global loads of psi_{l+2}, hidden behind this layer
+    if (l + 1 < nl) stash(sP[(l + 1) & 1]);
+    if (l + 2 < nl) fetch(l + 2);
     __syncthreads();
-    // zeta_l on the 2-cell halo
-    for (int idx = tid; idx < ZW * ZH; idx += FNT) {
-      const int li = idx % ZW, lj = idx / ZW;
-      const int c = (lj + 1) * PW + (li + 1);
-      sZ[idx] = DIVC(P0[c + 1] + P0[c - 1] + P0[c + PW] + P0[c - PW] - 4 * P0[c], D2, rD2);
-    }
+    lds_lap_bc<ZW, ZH, 2, PW, 3>(sZ, P0, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);   // zeta_l
     __syncthreads();
-    if (a.walls) lds_wall_ghosts<ZW, ZH, 2, PW, 3>(sZ, P0, x0, y0, nx, ny, a.walls, a.slip_c);
+    lds_lap_bc<TW, TH, 1, ZW, 2>(sT, sZ, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);   // tmp_l = lap(zeta_l)
     __syncthreads();
-    // tmp_l = lap(zeta_l) on the 1-cell halo
-    for (int idx = tid; idx < TW * TH; idx += FNT) {
-      const int li = idx % TW, lj = idx / TW;
-      const int c = (lj + 1) * ZW + (li + 1);
-      sT[idx] = DIVC(sZ[c + 1] + sZ[c - 1] + sZ[c + ZW] + sZ[c - ZW] - 4 * sZ[c], D2, rD2);
-    }
-    __syncthreads();
-    if (a.walls) lds_wall_ghosts<TW, TH, 1, ZW, 2>(sT, sZ, x0, y0, nx, ny, a.walls, a.slip_c);
-    __syncthreads();
-    // centre points
+    // centre points: RPT consecutive rows per thread, 3x3 windows slide down the column
     double um = 0.;
+    double p[3][3], z[3][3], p1[3][3], tcol[3];
 #pragma unroll
-    for (int k = 0; k < NPT; k++) {
-      const int ly = ty0 + k * (FNT / FTX);
-      const int gi = x0 + tx, gj = y0 + ly;
+    for (int b = 0; b < 2; b++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        p[b + 1][c] = P0[(ly0 + 2 + b) * PW + (tx + 2 + c)];
+        z[b + 1][c] = sZ[(ly0 + 1 + b) * ZW + (tx + 1 + c)];
+        p1[b + 1][c] = P1[(ly0 + 2 + b) * PW + (tx + 2 + c)];
+      }
+      tcol[b + 1] = sT[(ly0 + b) * TW + (tx + 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int ly = ly0 + k, gj = y0 + ly;
       const bool in = gi < nx && gj < ny;
-      double p[3][3], q[3][3];
 #pragma unroll
-      for (int b = 0; b < 3; b++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          p[b][c] = P0[(ly + 2 + b) * PW + (tx + 2 + c)];
-          q[b][c] = sZ[(ly + 1 + b) * ZW + (tx + 1 + c)];
-        }
+      for (int c = 0; c < 3; c++) {
+        p[0][c] = p[1][c]; p[1][c] = p[2][c]; p[2][c] = P0[(ly + 4) * PW + (tx + 2 + c)];
+        z[0][c] = z[1][c]; z[1][c] = z[2][c]; z[2][c] = sZ[(ly + 3) * ZW + (tx + 1 + c)];
+        p1[0][c] = p1[1][c]; p1[1][c] = p1[2][c]; p1[2][c] = P1[(ly + 4) * PW + (tx + 2 + c)];
+      }
+      tcol[0] = tcol[1]; tcol[1] = tcol[2]; tcol[2] = sT[(ly + 2) * TW + (tx + 1)];
       // face velocities, msqg/qg.h:276-283 (west and south face of this cell)
       {
         const double u = fabs(DIVC(0.25 * (p[2][1] - p[0][1] + p[2][0] - p[0][0]), D, rD));
         const double v = fabs(DIVC(0.25 * (p[1][2] - p[1][0] + p[0][2] - p[0][0]), D, rD));
         if (in) um = fmax(um, fmax(u, v));
       }
-      const double adv = mjac9(p, q, D12, rD12);
+      const double adv = mjac9(p, z, D12, rD12);
       const double be = DIVC(a.beta * (p[1][0] - p[1][2]), D2x, rD2x);
-      double jd = 0.;
-      if (l + 1 < nl) {
-#pragma unroll
-        for (int b = 0; b < 3; b++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) q[b][c] = P1[(ly + 2 + b) * PW + (tx + 2 + c)];
-        jd = mjac9(p, q, D12, rD12);
-      }
+      const double jd = l + 1 < nl ? mjac9(p, p1, D12, rD12) : 0.;
       const double ju = -jd_prev[k];
       double t = adv + be;
       if (in && nl > 1) {
@@ -208,14 +225,14 @@ __global__ void __launch_bounds__(FNT) k_rhs_fused(RhsArgs a) {
         if (l > 0) t = t + (a.uniformS ? a.Su[l - 1] : a.S[c - a.g.ls]) * ju * a.lc.idh0[l];
         if (l < nl - 1) t = t + (a.uniformS ? a.Su[l] : a.S[c]) * jd * a.lc.idh1[l];
       }
-      const double zc = sZ[(ly + 2) * ZW + (tx + 2)];
+      t = 0. + t;  // updates were zeroed, then += (msqg/qg.h:611-613, 315)
+      const double zc = z[1][1], tc = tcol[1];
       const int ct = (ly + 1) * TW + (tx + 1);
-      const double tc = sT[ct];
-      const double lapT = DIVC(sT[ct + 1] + sT[ct - 1] + sT[ct + TW] + sT[ct - TW] - 4 * tc, D2, rD2);
+      const double lapT = DIVC(sT[ct + 1] + sT[ct - 1] + tcol[2] + tcol[0] - 4 * tc, D2, rD2);
       // layer l-1 is complete now that zeta_l, tmp_l are known
-      if (in && l > 0) finalize(l - 1, k, gi, gj, t_prev[k], lapT_prev[k], zc0[k], zc1[k], zc, tc0[k], tc1[k], tc);
-      if (in && l == nl - 1) finalize(l, k, gi, gj, 0. + t, lapT, zc1[k], zc, 0., tc1[k], tc, 0.);
-      t_prev[k] = 0. + t; lapT_prev[k] = lapT; jd_prev[k] = jd;
+      if (in && l > 0) finalize(l - 1, gj, t_prev[k], lapT_prev[k], zc0[k], zc1[k], zc, tc0[k], tc1[k], tc);
+      if (in && l == nl - 1) finalize(l, gj, t, lapT, zc1[k], zc, 0., tc1[k], tc, 0.);
+      t_prev[k] = t; lapT_prev[k] = lapT; jd_prev[k] = jd;
       zc0[k] = zc1[k]; zc1[k] = zc; tc0[k] = tc1[k]; tc1[k] = tc;
     }
     // per-wave maximum of |u| of this layer

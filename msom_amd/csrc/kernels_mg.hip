@@ -171,6 +171,151 @@ void launch_residual(hipStream_t st, const double *a, const double *b, const dou
   hipLaunchKernelGGL(k_residual, grid2d(g.nx, g.ny), block2d(), 0, st, p);
 }
 
+// ------------------------------------------------------------------ fused residual variants
+
+// Two adjacent cells (x = 2kx, 2kx+1) per thread: 16-byte loads from the natural arrays and
+// fully coalesced stores into the two halves of the split layout.  Template flags fuse the
+// neighbouring steps of the cycle into the same pass:
+//   CORRECT  : a_new = a + da (mg_cycle's "a += da; boundary(a)", mspg/elliptic.h:92-98) is
+//              applied on the fly; a_new goes to a second buffer (no in-place race with the
+//              neighbours' reads) and the residual is that of a_new;
+//   WRITE    : store the residual (split layout);  without it only max|res| is produced
+//              (the post-cycle convergence check needs nothing else when it passes);
+//   RESTRICT : also store the residual restricted to the next coarser level (mean of the 4
+//              children in foreach_child order), saving the first restriction pass.
+struct Res2Args {
+  const double *a, *b, *S, *da;
+  double *a_out, *res, *res_c, *maxres, *sum_partial;
+  NatGeom g;
+  SplitGeom sg, cg;
+  int nl, uniformS, want_sum, walls;
+  RelaxCoef rc;
+};
+
+template <bool CORRECT, bool WRITE, bool RESTRICT>
+__global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
+  __shared__ double sr[RESTRICT ? MSOM_MAXNL : 1][BY][BX][2];
+  __shared__ double smm[BY], sms[BY];
+  const int kx = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  const bool in = kx < p.sg.hk && j < p.g.ny;
+  const int nl = p.nl;
+  double m = 0., bs = 0.;
+  if (in) {
+    const int pitch = p.g.pitch, i = 2 * kx;
+    const double D = p.rc.D, rD = 1. / D;
+    size_t c = nat_idx(p.g, 0, j, i);
+    // split-layout offsets of da: even/odd half entries of this pair and their neighbours
+    const size_t se = split_idx(p.sg, 0, j, i), so = se + p.sg.hp;
+    auto ld2 = [&](const double *f, size_t k, double &x, double &y) {
+      const double2 v = *reinterpret_cast<const double2 *>(f + k);
+      x = v.x; y = v.y;
+    };
+    // value of a (+ da) at layer offset lo: centre pair, W, E, S pair, N pair
+    auto fetch = [&](size_t cl, size_t sl, double &ae, double &ao, double &aw, double &aee, double &se_, double &so_, double &ne_, double &no_) {
+      ld2(p.a, cl, ae, ao);
+      aw = p.a[cl - 1]; aee = p.a[cl + 2];
+      ld2(p.a, cl - pitch, se_, so_);
+      ld2(p.a, cl + pitch, ne_, no_);
+      if (CORRECT) {
+        const double *d = p.da + sl;
+        ae = ae + d[se]; ao = ao + d[so];
+        aw = aw + d[so - 1]; aee = aee + d[se + 1];
+        se_ = se_ + d[se - p.sg.rp]; so_ = so_ + d[so - p.sg.rp];
+        ne_ = ne_ + d[se + p.sg.rp]; no_ = no_ + d[so + p.sg.rp];
+      }
+    };
+    double a0e = 0., a0o = 0., a1e, a1o, a1w, a1ee, a1se, a1so, a1ne, a1no;
+    double a2e = 0., a2o = 0., a2w = 0., a2ee = 0., a2se = 0., a2so = 0., a2ne = 0., a2no = 0.;
+    double s0e = 0., s0o = 0., s1e = 0., s1o = 0.;
+    fetch(c, 0, a1e, a1o, a1w, a1ee, a1se, a1so, a1ne, a1no);
+    for (int l = 0; l < nl; l++, c += p.g.ls) {
+      double be, bo;
+      ld2(p.b, c, be, bo);
+      bs += be + bo;
+      if (l < nl - 1) {
+        fetch(c + p.g.ls, (size_t)(l + 1) * p.sg.ls, a2e, a2o, a2w, a2ee, a2se, a2so, a2ne, a2no);
+        if (p.uniformS) s1e = s1o = p.rc.S[l];
+        else ld2(p.S, c, s1e, s1o);
+      }
+      double re = be, ro = bo;
+      if (nl > 1) {
+        if (l == 0) {
+          re = be + s1e * (a1e - a2e) * p.rc.idh1[l];
+          ro = bo + s1o * (a1o - a2o) * p.rc.idh1[l];
+        } else if (l < nl - 1) {
+          re = be + s0e * (a1e - a0e) * p.rc.idh0[l] - s1e * (a2e - a1e) * p.rc.idh1[l];
+          ro = bo + s0o * (a1o - a0o) * p.rc.idh0[l] - s1o * (a2o - a1o) * p.rc.idh1[l];
+        } else {
+          re = be + s0e * (a1e - a0e) * p.rc.idh0[l];
+          ro = bo + s0o * (a1o - a0o) * p.rc.idh0[l];
+        }
+      }
+      re += DIVC(DIVC(a1e - a1w, D, rD) - DIVC(a1o - a1e, D, rD), D, rD);
+      re += DIVC(DIVC(a1e - a1se, D, rD) - DIVC(a1ne - a1e, D, rD), D, rD);
+      ro += DIVC(DIVC(a1o - a1e, D, rD) - DIVC(a1ee - a1o, D, rD), D, rD);
+      ro += DIVC(DIVC(a1o - a1so, D, rD) - DIVC(a1no - a1o, D, rD), D, rD);
+      if (CORRECT) {
+        *reinterpret_cast<double2 *>(p.a_out + c) = make_double2(a1e, a1o);
+        nat_write_ghosts(p.a_out, p.g, l, j, i, a1e, p.walls);
+        nat_write_ghosts(p.a_out, p.g, l, j, i + 1, a1o, p.walls);
+      }
+      if (WRITE) {
+        p.res[se + (size_t)l * p.sg.ls] = re;
+        p.res[so + (size_t)l * p.sg.ls] = ro;
+      }
+      if (RESTRICT) { sr[l][threadIdx.y][threadIdx.x][0] = re; sr[l][threadIdx.y][threadIdx.x][1] = ro; }
+      m = fmax(m, fmax(fabs(re), fabs(ro)));
+      a0e = a1e; a0o = a1o; s0e = s1e; s0o = s1o;
+      a1e = a2e; a1o = a2o; a1w = a2w; a1ee = a2ee; a1se = a2se; a1so = a2so; a1ne = a2ne; a1no = a2no;
+    }
+  }
+  if (RESTRICT) {
+    __syncthreads();
+    if (in && (threadIdx.y & 1) == 0) {
+      const int J = j >> 1;
+      for (int l = 0; l < nl; l++) {
+        double sum = 0.;
+        sum += sr[l][threadIdx.y][threadIdx.x][0];
+        sum += sr[l][threadIdx.y + 1][threadIdx.x][0];
+        sum += sr[l][threadIdx.y][threadIdx.x][1];
+        sum += sr[l][threadIdx.y + 1][threadIdx.x][1];
+        p.res_c[split_idx(p.cg, l, J, kx)] = sum / 4;
+      }
+    }
+  }
+  m = wave_max(m);
+  if (p.want_sum) bs = wave_sum(bs);
+  if (threadIdx.x == 0) { smm[threadIdx.y] = m; sms[threadIdx.y] = bs; }
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    double mm = smm[0], ss = sms[0];
+    for (int k = 1; k < BY; k++) { mm = fmax(mm, smm[k]); ss += sms[k]; }
+    atomicMax((unsigned long long *)p.maxres, (unsigned long long)__double_as_longlong(mm));
+    if (p.want_sum) p.sum_partial[blockIdx.y * gridDim.x + blockIdx.x] = ss;
+  }
+}
+
+int residual2_blocks(const NatGeom &g) {
+  dim3 gr = grid2d(g.nx / 2, g.ny);
+  return gr.x * gr.y;
+}
+// mode bits: 1 = CORRECT, 2 = WRITE, 4 = RESTRICT
+void launch_residual2(hipStream_t st, int mode, const double *a, const double *da, double *a_out, const double *b, const double *S,
+                      const NatGeom &g, double *res, const SplitGeom &sg, double *res_c, const SplitGeom &cg, int nl, const RelaxCoef &rc,
+                      int uniformS, int walls, double *maxres, double *sum_partial, int want_sum) {
+  Res2Args p;
+  p.a = a; p.b = b; p.S = S; p.da = da; p.a_out = a_out; p.res = res; p.res_c = res_c; p.maxres = maxres; p.sum_partial = sum_partial;
+  p.g = g; p.sg = sg; p.cg = cg; p.nl = nl; p.uniformS = uniformS; p.want_sum = want_sum; p.walls = walls; p.rc = rc;
+  dim3 gr = grid2d(g.nx / 2, g.ny);
+  switch (mode) {
+    case 1: hipLaunchKernelGGL((k_residual2<true, false, false>), gr, block2d(), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((k_residual2<false, true, false>), gr, block2d(), 0, st, p); break;
+    case 6: hipLaunchKernelGGL((k_residual2<false, true, true>), gr, block2d(), 0, st, p); break;
+    case 0: hipLaunchKernelGGL((k_residual2<false, false, false>), gr, block2d(), 0, st, p); break;
+    default: break;
+  }
+}
+
 // ------------------------------------------------------------------ K10 restriction, K11 prolongation
 
 // coarse = mean of the 4 children, summed in Basilisk's foreach_child order

@@ -14,6 +14,7 @@
 #include <sys/stat.h>
 #include <sys/types.h>
 
+#include <utility>
 #include <vector>
 
 #include "comm.h"
@@ -76,6 +77,8 @@ struct msom {
   int const_set = 0, flag_topo = 0, have_pg = 0, have_zpg = 0, have_qforc = 0;
   int fr_uniform = 1, uniformS = 0, uniform_opt = -1 /* auto */;
   int stochastic = 0, corrector_step = 0, noise_mode = 0;
+  int mg_fused = 1;  // fused residual+restriction and correction+residual passes of the multigrid cycle
+  double *psi_alt = nullptr;  // second psi buffer (the fused correction writes out of place)
   int fused = 1;  // one-pass PV tendency kernel (kernels_fused.hip) when the configuration allows
   unsigned seed = 1;
   int quiet = 0;
@@ -282,6 +285,8 @@ static int alloc_all(msom *m) {
     HIPCHK(hipMemsetAsync(m->res[k], 0, bytes, m->st));
     HIPCHK(hipMemsetAsync(m->S[k], 0, m->sg[k].ls * m->nlm * sizeof(double), m->st));
   }
+  HIPCHK(hipMalloc(&m->psi_alt, m->g.ls * m->nl * sizeof(double)));
+  HIPCHK(hipMemsetAsync(m->psi_alt, 0, m->g.ls * m->nl * sizeof(double), m->st));
   HIPCHK(hipMalloc(&m->staging, (size_t)m->nl * m->nx * m->ny * sizeof(double)));
   HIPCHK(hipMalloc(&m->partial, (size_t)partial_count(m->g) * m->nl * sizeof(double)));
   {
@@ -405,6 +410,7 @@ extern "C" int msom_destroy(msom_t *m) {
     if (m->res[k]) hipFree(m->res[k]);
     if (m->S[k]) hipFree(m->S[k]);
   }
+  if (m->psi_alt) hipFree(m->psi_alt);
   if (m->staging) hipFree(m->staging);
   if (m->partial) hipFree(m->partial);
   if (m->partial_umax) hipFree(m->partial_umax);
@@ -435,6 +441,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   }
   else if (!strcmp(key, "profile")) m->profile = (int)v;
   else if (!strcmp(key, "fused")) m->fused = (int)v;
+  else if (!strcmp(key, "mg_fused")) m->mg_fused = (int)v;
   else if (!strcmp(key, "seed")) { m->seed = (unsigned)v; srand(m->seed); }
   else if (!strcmp(key, "noise_mode")) m->noise_mode = (int)v;
   else if (!strcmp(key, "stochastic")) {
@@ -691,9 +698,11 @@ static void relax_sweeps(msom *m, int k, int nrelax, int last_level_exchange_cor
   }
 }
 
-// mg_cycle, mspg/elliptic.h:43-99 (minlevel = 1)
-static void mg_cycle(msom *m, double *a, int nrelax) {
-  for (int k = 1; k < m->nlev; k++) launch_restrict(m->st, m->res[k - 1], m->sg[k - 1], m->res[k], m->sg[k], m->nl);
+// coarse-to-fine part of mg_cycle, mspg/elliptic.h:53-89 (minlevel = 1): restriction of the
+// residual to all levels (level 1 may already come out of the fused residual kernel), then
+// prolongation + nrelax relaxations per level
+static void mg_cycle_levels(msom *m, int nrelax, int first_restrict) {
+  for (int k = first_restrict; k < m->nlev; k++) launch_restrict(m->st, m->res[k - 1], m->sg[k - 1], m->res[k], m->sg[k], m->nl);
   for (int k = m->nlev - 1; k >= 0; k--) {
     if (k == m->nlev - 1) hipMemsetAsync(m->da[k], 0, m->sg[k].ls * m->nl * sizeof(double), m->st);
     else {
@@ -702,13 +711,19 @@ static void mg_cycle(msom *m, double *a, int nrelax) {
     }
     relax_sweeps(m, k, nrelax, k > 0);
   }
-  launch_correct(m->st, a, m->g, m->da[0], m->sg[0], m->nl, m->walls);
-  if (m->nranks > 1) STICKY(m, exch_nat(m, a, m->nl, m->bc, 1));  // boundary(a)
 }
 
 static void residual(msom *m, const double *a, const double *b, int slot, int want_sum) {
   if (m->profile) prof_begin(m, m->prof_resid);
   launch_residual(m->st, a, b, m->f[MSOM_S], m->g, m->res[0], m->sg[0], m->nl, m->rc[0], m->uniformS, m->d_scal + slot, m->partial, want_sum);
+  if (m->profile) prof_end(m, m->prof_resid);
+}
+// fused variants (kernels_mg.hip k_residual2); mode bits 1 = CORRECT, 2 = WRITE, 4 = RESTRICT
+static void residual2(msom *m, int mode, const double *b, int slot, int want_sum) {
+  if (m->profile) prof_begin(m, m->prof_resid);
+  launch_residual2(m->st, mode, m->f[MSOM_PSI], m->da[0], m->psi_alt, b, m->f[MSOM_S], m->g, m->res[0], m->sg[0],
+                   m->nlev > 1 ? m->res[1] : nullptr, m->sg[m->nlev > 1 ? 1 : 0], m->nl, m->rc[0], m->uniformS, m->walls, m->d_scal + slot,
+                   m->partial, want_sum);
   if (m->profile) prof_end(m, m->prof_resid);
 }
 
@@ -723,15 +738,24 @@ static int read_residuals(msom *m) {
   return reduce_scal(m, 0, 4, RED_MAX);
 }
 
-// mg_solve, mspg/elliptic.h:145-229, called as poisson_layer does (msqg/poisson_layer.h:290-303).
-// a: natural field with valid ghosts (warm start), b: natural field.
-static int mg_solve(msom *m, double *a, const double *b, msom_mgstats *s) {
+// mg_solve, mspg/elliptic.h:145-229, called as poisson_layer does (msqg/poisson_layer.h:290-303)
+// on a = psi (natural field with valid ghosts, warm start) and b (natural field).
+// Fused path (default): the pre-cycle residual also produces the level-1 restriction, the
+// correction a += da is folded into the post-cycle residual (written to a second psi buffer
+// that then becomes psi), and the post-cycle pass only produces max|res|; the residual field
+// is regenerated only if another cycle turns out to be needed.
+static int mg_solve(msom *m, const double *b, msom_mgstats *s) {
   const Params &p = m->p;
+  const bool fused = m->mg_fused && m->nlev > 1;
   s->i = 0; s->nrelax = 4;
   HIPCHK(hipMemsetAsync(m->d_scal, 0, 4 * sizeof(double), m->st));
-  residual(m, a, b, SC_RES0, 1);
-  // sum of the right-hand side (mgstats.sum), deterministic order
-  launch_sum_final(m->st, m->partial, m->d_scal + SC_BSUM, partial_count(m->g));
+  if (fused) {
+    residual2(m, 2 | 4, b, SC_RES0, 1);
+    launch_sum_final(m->st, m->partial, m->d_scal + SC_BSUM, residual2_blocks(m->g));
+  } else {
+    residual(m, m->f[MSOM_PSI], b, SC_RES0, 1);
+    launch_sum_final(m->st, m->partial, m->d_scal + SC_BSUM, partial_count(m->g));
+  }
   bool have_first = false;
   double resb = 0;
   if (p.nitermin < 1) {  // need the initial residual before deciding on the first cycle
@@ -742,9 +766,17 @@ static int mg_solve(msom *m, double *a, const double *b, msom_mgstats *s) {
     have_first = true;
   }
   for (s->i = 0; s->i < p.nitermax && (s->i < p.nitermin || s->resa > p.tolerance); s->i++) {
-    mg_cycle(m, a, s->nrelax);
+    mg_cycle_levels(m, s->nrelax, fused ? 2 : 1);
     HIPCHK(hipMemsetAsync(m->d_scal + SC_RES1, 0, sizeof(double), m->st));
-    residual(m, a, b, SC_RES1, 0);
+    if (fused) {
+      residual2(m, 1, b, SC_RES1, 0);            // a_new = a + da -> psi_alt, max |res(a_new)|
+      std::swap(m->f[MSOM_PSI], m->psi_alt);
+      if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], m->nl, m->bc, 1));
+    } else {
+      launch_correct(m->st, m->f[MSOM_PSI], m->g, m->da[0], m->sg[0], m->nl, m->walls);
+      if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], m->nl, m->bc, 1));  // boundary(a)
+      residual(m, m->f[MSOM_PSI], b, SC_RES1, 0);
+    }
     int rr = read_residuals(m);
     if (rr) return rr;
     if (!have_first) {
@@ -758,6 +790,8 @@ static int mg_solve(msom *m, double *a, const double *b, msom_mgstats *s) {
       else if (resb / s->resa > 10 && s->nrelax > 2) s->nrelax--;
     }
     resb = s->resa;
+    // another cycle follows: it needs the residual field of the corrected a on levels 0 and 1
+    if (fused && s->i + 1 < p.nitermax && (s->i + 1 < p.nitermin || s->resa > p.tolerance)) residual2(m, 2 | 4, b, SC_KE, 0);
   }
   if (!have_first) {  // nitermax == 0
     int rr = read_residuals(m);
@@ -770,9 +804,9 @@ static int mg_solve(msom *m, double *a, const double *b, msom_mgstats *s) {
   return MSOM_OK;
 }
 
-// invertq, msqg/qg.h:114-163 (the trailing boundary(pol) is already done by the correction kernel)
-static int invertq(msom *m, double *psi, const double *q) {
-  return mg_solve(m, psi, q, &m->mg);
+// invertq, msqg/qg.h:114-163 (the trailing boundary(pol) is already done by the correction)
+static int invertq(msom *m, const double *q) {
+  return mg_solve(m, q, &m->mg);
 }
 
 // ------------------------------------------------------------------ RHS
@@ -839,7 +873,7 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
 static double update_qg(msom *m, int qfield, int dqfield, double dtmax) {
   const Params &p = m->p;
   const int nl = m->nl;
-  if (invertq(m, m->f[MSOM_PSI], m->f[qfield])) return -1;
+  if (invertq(m, m->f[qfield])) return -1;
   if (rhs_terms(m, qfield, dqfield, 1, p.iRe, p.iRe4, p.Eks, p.Ekb)) return -1;
   if (reduce_scal(m, SC_UMAX, nl, RED_MAX)) return -1;
   if (m->sticky) return -1;
@@ -933,7 +967,7 @@ extern "C" int msom_invertq(msom_t *m, const double *q, double *psi, msom_mgstat
     qf = MSOM_QPRED;
   }
   if (psi && (r = upload(m, MSOM_PSI, psi))) return r;
-  if ((r = invertq(m, m->f[MSOM_PSI], m->f[qf]))) return r;
+  if ((r = invertq(m, m->f[qf]))) return r;
   if (st) *st = m->mg;
   if (psi) return download(m, MSOM_PSI, psi);
   return sync_stream(m);
@@ -984,7 +1018,7 @@ extern "C" int pystep_bfn(msom_t *m, double *varin_py, int len1, int len2, int l
   if (vartype != 1) HIPCHK(hipMemsetAsync(m->f[MSOM_DQ], 0, m->g.ls * m->nl * sizeof(double), m->st));  // reset_layer_var(bfn_tendl)
   if (vartype == 1) {
     if ((r = upload(m, MSOM_Q, varin_py))) return r;
-    if ((r = invertq(m, m->f[MSOM_PSI], m->f[MSOM_Q]))) return r;
+    if ((r = invertq(m, m->f[MSOM_Q]))) return r;
     if ((r = rhs_terms(m, MSOM_Q, MSOM_DQ, 0, p.iRe, p.iRe4, p.Eks, p.Ekb))) return r;
   } else if (!m->quiet)
     fprintf(stdout, "temporary disabled psi tendency\n");  // msqg/qg_bfn.h:48
@@ -997,7 +1031,7 @@ extern "C" int pyq2p(msom_t *m, double *po_py, int len7, int len8, int len9, dou
   int r;
   HIPCHK(hipMemsetAsync(m->f[MSOM_PSI], 0, m->g.ls * m->nl * sizeof(double), m->st));
   if ((r = upload(m, MSOM_Q, qo_py))) return r;
-  if ((r = invertq(m, m->f[MSOM_PSI], m->f[MSOM_Q]))) return r;
+  if ((r = invertq(m, m->f[MSOM_Q]))) return r;
   return download(m, MSOM_PSI, po_py);
 }
 // msqg/qg_bfn.h:95-103
@@ -1148,7 +1182,7 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
     bool out_pending = tout <= p.tend + 1e-10;
     if (out_pending && m->t >= tout - 1e-12 * fmax(1., fabs(tout))) {
       fprintf(stdout, "write file\n");
-      if ((r = invertq(m, m->f[MSOM_PSI], m->f[MSOM_Q]))) return r;
+      if ((r = invertq(m, m->f[MSOM_Q]))) return r;
       snprintf(name, sizeof name, "%spo%09d.bas", dpath, m->iter);
       if ((r = msom_write_bas(m, MSOM_PSI, name))) return r;
       snprintf(name, sizeof name, "%sqo%09d.bas", dpath, m->iter);
