@@ -22,7 +22,7 @@ struct RelaxCoef {
 };
 
 // ---- kernels_rhs.hip
-void launch_fill_ghost(hipStream_t st, double *f, const NatGeom &g, int nl, int bc, int walls);
+void launch_fill_ghost(hipStream_t st, double *f, const NatGeom &g, int nl, int bc, int walls, int depth = 1);
 void launch_slip_bc(hipStream_t st, const double *po, double *zeta, const NatGeom &g, int nl, double c, int walls);
 void launch_pack(hipStream_t st, const double *src, double *dst, const NatGeom &g, int nl);
 void launch_unpack(hipStream_t st, const double *src, double *dst, const NatGeom &g, int nl);
@@ -51,7 +51,7 @@ int rhs_fused_blocks(const NatGeom &g);
 void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq,
                       double *umax_partial, double *umax_out, const NatGeom &g, int nl, int walls, int uniformS, const double *Su,
                       int have_qforc, double D, double beta, double iRe, double iRe4, double cs, double cb, double slip_c,
-                      const LayerCoef &lc);
+                      const LayerCoef &lc, int variant, const double *q_in = nullptr, double *q_out = nullptr, double dt = 0.);
 
 // ---- kernels_mg.hip
 void launch_nat_to_split(hipStream_t st, const double *nat, const NatGeom &g, double *sp, const SplitGeom &sg, int nl);

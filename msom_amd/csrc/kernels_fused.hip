@@ -27,20 +27,15 @@
 #endif
 
 #define FTX 64            // tile width  = one wavefront
-#define FTY 32            // tile height
-#define FNT 512           // threads per workgroup (8 waves)
-#define RPT (FTX * FTY / FNT)   // consecutive rows per thread (sliding 3x3 windows)
+// FTY = tile height, FNT = threads per workgroup are template parameters (tuning variants)
 #define PW (FTX + 6)
-#define PH (FTY + 6)
 #define ZW (FTX + 4)
-#define ZH (FTY + 4)
 #define TW (FTX + 2)
-#define TH (FTY + 2)
-#define NPF ((PW * PH + FNT - 1) / FNT)   // prefetch registers per thread
 
 struct RhsArgs {
-  const double *psi, *S, *qforc, *wind;
-  double *dq, *umax_partial;
+  const double *psi, *S, *qforc, *wind, *q_in;
+  double *dq, *umax_partial, *q_out;  // q_out != 0: advance fused, q_out = q_in + dt * dq (msqg/qg.h:602), dq not stored
+  double dt;
   NatGeom g;
   int nl, walls, uniformS, have_qforc;
   double D, beta, iRe, iRe4, cs, cb, slip_c;
@@ -66,47 +61,67 @@ __device__ __forceinline__ double mjac9(const double (&p)[3][3], const double (&
   return DIVC(s, D12, rD12);
 }
 
-// lap(src) into an LDS tile `dst` (W x H, halo h around the block at (x0, y0)); src is an LDS
-// tile of width SW and halo hs = h + 1.  Positions outside a wall are the ghost cells of
-// boundary(): sign * lap(src)(mirror) (edges -, corners +), or the partial-slip value
+// One element of lap(src) -> dst with the wall boundary conditions.  dst is a W x H LDS tile
+// with halo h around the block at (x0, y0); src is an LDS tile of width SW and halo
+// hs = h + 1.  Positions outside a wall are the ghost cells of boundary():
+// sign * lap(src)(mirror) (edges -, corners +), or the partial-slip value
 // c * (src(mirror) - src(ghost)) on the first ghost line (msqg/qg.h:185-198).
 template <int W, int H, int h, int SW, int hs>
-__device__ __forceinline__ void lds_lap_bc(double *dst, const double *src, int x0, int y0, int nx, int ny, int walls, double slip_c,
-                                           double D2, double rD2) {
-  for (int idx = threadIdx.x; idx < W * H; idx += FNT) {
-    const int li = idx % W, lj = idx / W;
-    const int gi = x0 + li - h, gj = y0 + lj - h;
-    const bool ox = (gi < 0 && (walls & WALL_W)) || (gi >= nx && (walls & WALL_E));
-    const bool oy = (gj < 0 && (walls & WALL_S)) || (gj >= ny && (walls & WALL_N));
-    int ci = li + (hs - h), cj = lj + (hs - h);  // same position in src coordinates
-    double sign = 1.;
-    bool slip = false, valid = true;
-    if (ox | oy) {
-      const int mi = ox ? (gi < 0 ? -1 - gi : 2 * nx - 1 - gi) : gi;
-      const int mj = oy ? (gj < 0 ? -1 - gj : 2 * ny - 1 - gj) : gj;
-      const int ti = mi - x0 + hs, tj = mj - y0 + hs;
-      valid = ti >= 1 && ti < SW - 1 && tj >= 1 && tj < H + 2 * (hs - h) - 1;
-      if (ox != oy) {
-        sign = -1.;
-        slip = slip_c > 0. && (ox ? (gi == -1 || gi == nx) : (gj == -1 || gj == ny));
-      }
-      if (slip) {
-        dst[idx] = valid ? slip_c * (src[tj * SW + ti] - src[cj * SW + ci]) : 0.;
-        continue;
-      }
-      ci = ti; cj = tj;
+__device__ __forceinline__ double lap_bc_elem(const double *src, int li, int lj, int x0, int y0, int nx, int ny, int walls, double slip_c,
+                                              double D2, double rD2) {
+  const int gi = x0 + li - h, gj = y0 + lj - h;
+  const bool ox = (gi < 0 && (walls & WALL_W)) || (gi >= nx && (walls & WALL_E));
+  const bool oy = (gj < 0 && (walls & WALL_S)) || (gj >= ny && (walls & WALL_N));
+  int ci = li + (hs - h), cj = lj + (hs - h);  // same position in src coordinates
+  bool neg = false;
+  if (ox | oy) {
+    const int mi = ox ? (gi < 0 ? -1 - gi : 2 * nx - 1 - gi) : gi;
+    const int mj = oy ? (gj < 0 ? -1 - gj : 2 * ny - 1 - gj) : gj;
+    const int ti = mi - x0 + hs, tj = mj - y0 + hs;
+    if (!(ti >= 1 && ti < SW - 1 && tj >= 1 && tj < H + 2 * (hs - h) - 1)) return 0.;
+    if (ox != oy) {
+      neg = true;
+      if (slip_c > 0. && (ox ? (gi == -1 || gi == nx) : (gj == -1 || gj == ny))) return slip_c * (src[tj * SW + ti] - src[cj * SW + ci]);
     }
-    double v = 0.;
-    if (valid) {
-      const int c = cj * SW + ci;
-      v = DIVC(src[c + 1] + src[c - 1] + src[c + SW] + src[c - SW] - 4 * src[c], D2, rD2);
-      if (sign < 0.) v = -v;
+    ci = ti; cj = tj;
+  }
+  const int c = cj * SW + ci;
+  const double v = DIVC(src[c + 1] + src[c - 1] + src[c + SW] + src[c - SW] - 4 * src[c], D2, rD2);
+  return neg ? -v : v;
+}
+
+// lap(src) -> dst for the whole tile.  Row mapping: wave w takes rows w, w + NW, ...; lane =
+// column (the W - 64 extra columns are a second short pass), so there is no index division.
+// `bc` is block-uniform: only workgroups whose halo touches a wall run the BC variant.
+template <int W, int H, int h, int SW, int hs, int FNT>
+__device__ __forceinline__ void lds_lap(double *dst, const double *src, bool bc, int x0, int y0, int nx, int ny, int walls, double slip_c,
+                                        double D2, double rD2) {
+  constexpr int NW = FNT / 64, XE = W - 64, o = hs - h;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (!bc) {
+#pragma unroll
+    for (int lj = w; lj < H; lj += NW) {
+      const int c = (lj + o) * SW + lane + o;
+      dst[lj * W + lane] = DIVC(src[c + 1] + src[c - 1] + src[c + SW] + src[c - SW] - 4 * src[c], D2, rD2);
     }
-    dst[idx] = v;
+    for (int e = threadIdx.x; e < XE * H; e += FNT) {
+      const int lj = e / XE, li = 64 + e % XE;
+      const int c = (lj + o) * SW + li + o;
+      dst[lj * W + li] = DIVC(src[c + 1] + src[c - 1] + src[c + SW] + src[c - SW] - 4 * src[c], D2, rD2);
+    }
+  } else {
+    for (int lj = w; lj < H; lj += NW) dst[lj * W + lane] = lap_bc_elem<W, H, h, SW, hs>(src, lane, lj, x0, y0, nx, ny, walls, slip_c, D2, rD2);
+    for (int e = threadIdx.x; e < XE * H; e += FNT) {
+      const int lj = e / XE, li = 64 + e % XE;
+      dst[lj * W + li] = lap_bc_elem<W, H, h, SW, hs>(src, li, lj, x0, y0, nx, ny, walls, slip_c, D2, rD2);
+    }
   }
 }
 
-__global__ void __launch_bounds__(FNT) k_rhs_fused(RhsArgs a) {
+template <int FTY, int FNT, int MINW>
+__global__ void __launch_bounds__(FNT, MINW) k_rhs_fused(RhsArgs a) {
+  constexpr int RPT = FTX * FTY / FNT;  // consecutive rows per thread (sliding 3x3 windows)
+  constexpr int PH = FTY + 6, ZH = FTY + 4, TH = FTY + 2;
   __shared__ double sP[2][PW * PH];
   __shared__ double sZ[ZW * ZH];
   __shared__ double sT[TW * TH];
@@ -123,23 +138,35 @@ __global__ void __launch_bounds__(FNT) k_rhs_fused(RhsArgs a) {
 #pragma unroll
   for (int k = 0; k < RPT; k++) t_prev[k] = lapT_prev[k] = zc0[k] = zc1[k] = tc0[k] = tc1[k] = jd_prev[k] = 0.;
 
-  // psi tile (3-cell halo) of one layer: global -> registers, registers -> LDS
-  double pf[NPF];
+  // psi tile (3-cell halo) of one layer: global -> registers, registers -> LDS.  Row mapping
+  // like lds_lap: wave w loads rows w, w + NW, ... (64 columns), then the 6 extra columns.
+  constexpr int NW = FNT / 64, NR = (PH + NW - 1) / NW, NE = (6 * PH + FNT - 1) / FNT;
+  const int lane = tid & 63, wv = tid >> 6;
+  const bool whole = x0 + FTX + 3 <= nx + 3 && y0 + FTY + 3 <= ny + 3;  // tile + halo inside the padded array
+  double pf[NR + NE];
   auto fetch = [&](int l) {
-    const double *p = a.psi + (size_t)l * a.g.ls;
+    const double *p = a.psi + (size_t)l * a.g.ls + (ptrdiff_t)(y0 - 3 + MSOM_YP) * pitch + (x0 - 3 + MSOM_XP);
 #pragma unroll
-    for (int r = 0; r < NPF; r++) {
-      const int idx = tid + r * FNT;
-      const int li = idx % PW, lj = idx / PW;
-      const int fi = x0 + li - 3, fj = y0 + lj - 3;
-      pf[r] = (idx < PW * PH && fi >= -3 && fi < nx + 3 && fj >= -3 && fj < ny + 3) ? p[(ptrdiff_t)(fj + MSOM_YP) * pitch + (fi + MSOM_XP)] : 0.;
+    for (int r = 0; r < NR; r++) {
+      const int lj = wv + r * NW;
+      pf[r] = (lj < PH && (whole || (x0 + lane - 3 < nx + 3 && y0 + lj - 3 < ny + 3))) ? p[(ptrdiff_t)lj * pitch + lane] : 0.;
+    }
+#pragma unroll
+    for (int r = 0; r < NE; r++) {
+      const int e = tid + r * FNT, lj = e / 6, li = 64 + e % 6;
+      pf[NR + r] = (e < 6 * PH && (whole || (x0 + li - 3 < nx + 3 && y0 + lj - 3 < ny + 3))) ? p[(ptrdiff_t)lj * pitch + li] : 0.;
     }
   };
   auto stash = [&](double *dst) {
 #pragma unroll
-    for (int r = 0; r < NPF; r++) {
-      const int idx = tid + r * FNT;
-      if (idx < PW * PH) dst[idx] = pf[r];
+    for (int r = 0; r < NR; r++) {
+      const int lj = wv + r * NW;
+      if (lj < PH) dst[lj * PW + lane] = pf[r];
+    }
+#pragma unroll
+    for (int r = 0; r < NE; r++) {
+      const int e = tid + r * FNT;
+      if (e < 6 * PH) dst[(e / 6) * PW + 64 + e % 6] = pf[NR + r];
     }
   };
   // finalise layer l (additions in the order of msqg/qg.h:407-473) and store dq_l
@@ -168,9 +195,13 @@ __global__ void __launch_bounds__(FNT) k_rhs_fused(RhsArgs a) {
     if (l == nl - 1) dq -= a.cb * zc;
     if (l == 0) dq -= a.wind[gj];
     if (a.have_qforc) dq += a.qforc[c];
-    a.dq[c] = dq;
+    if (a.q_out) a.q_out[c] = a.q_in[c] + dq * a.dt;
+    else a.dq[c] = dq;
   };
 
+  // does the 2-cell halo of this block reach a wall?
+  const bool bc = ((a.walls & WALL_W) && x0 - 2 < 0) || ((a.walls & WALL_E) && x0 + FTX + 2 > nx) || ((a.walls & WALL_S) && y0 - 2 < 0) ||
+                  ((a.walls & WALL_N) && y0 + FTY + 2 > ny);
   fetch(0);
   stash(sP[0]);
   if (nl > 1) fetch(1);
@@ -181,9 +212,9 @@ __global__ void __launch_bounds__(FNT) k_rhs_fused(RhsArgs a) {
     if (l + 1 < nl) stash(sP[(l + 1) & 1]);
     if (l + 2 < nl) fetch(l + 2);
     __syncthreads();
-    lds_lap_bc<ZW, ZH, 2, PW, 3>(sZ, P0, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);   // zeta_l
+    lds_lap<ZW, ZH, 2, PW, 3, FNT>(sZ, P0, bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);   // zeta_l
     __syncthreads();
-    lds_lap_bc<TW, TH, 1, ZW, 2>(sT, sZ, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);   // tmp_l = lap(zeta_l)
+    lds_lap<TW, TH, 1, ZW, 2, FNT>(sT, sZ, bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);   // tmp_l = lap(zeta_l)
     __syncthreads();
     // centre points: RPT consecutive rows per thread, 3x3 windows slide down the column
     double um = 0.;
@@ -261,18 +292,27 @@ __global__ void k_max_final2(const double *partial, double *out, int nb, int nl)
   if (threadIdx.x == 0) out[l] = sm[0];
 }
 
-int rhs_fused_blocks(const NatGeom &g) { return ((g.nx + FTX - 1) / FTX) * ((g.ny + FTY - 1) / FTY); }
+int rhs_fused_blocks(const NatGeom &g) { return ((g.nx + FTX - 1) / FTX) * ((g.ny + 7) / 8); }  // upper bound (smallest FTY)
 
 void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq,
                       double *umax_partial, double *umax_out, const NatGeom &g, int nl, int walls, int uniformS, const double *Su,
                       int have_qforc, double D, double beta, double iRe, double iRe4, double cs, double cb, double slip_c,
-                      const LayerCoef &lc) {
+                      const LayerCoef &lc, int variant, const double *q_in, double *q_out, double dt) {
   RhsArgs a;
+  a.q_in = q_in; a.q_out = q_out; a.dt = dt;
   a.psi = psi; a.S = S; a.qforc = qforc; a.wind = wind; a.dq = dq; a.umax_partial = umax_partial;
   a.g = g; a.nl = nl; a.walls = walls; a.uniformS = uniformS; a.have_qforc = have_qforc;
   a.D = D; a.beta = beta; a.iRe = iRe; a.iRe4 = iRe4; a.cs = cs; a.cb = cb; a.slip_c = slip_c; a.lc = lc;
   for (int l = 0; l < MSOM_MAXNL; l++) a.Su[l] = Su ? Su[l] : 0.;
-  dim3 gr((g.nx + FTX - 1) / FTX, (g.ny + FTY - 1) / FTY);
-  hipLaunchKernelGGL(k_rhs_fused, gr, dim3(FNT), 0, st, a);
+  int fty = (variant == 1 || variant == 2 || variant == 4) ? 16 : (variant == 3 || variant == 5) ? 8 : 32;
+  dim3 gr((g.nx + FTX - 1) / FTX, (g.ny + fty - 1) / fty);
+  switch (variant) {
+    case 1: hipLaunchKernelGGL((k_rhs_fused<16, 256, 1>), gr, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_rhs_fused<16, 512, 2>), gr, dim3(512), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((k_rhs_fused<8, 256, 2>), gr, dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((k_rhs_fused<16, 512, 4>), gr, dim3(512), 0, st, a); break;
+    case 5: hipLaunchKernelGGL((k_rhs_fused<8, 256, 4>), gr, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_rhs_fused<32, 512, 2>), gr, dim3(512), 0, st, a); break;
+  }
   hipLaunchKernelGGL(k_max_final2, dim3(nl), dim3(256), 0, st, umax_partial, umax_out, (int)(gr.x * gr.y), nl);
 }

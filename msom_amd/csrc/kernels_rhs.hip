@@ -59,8 +59,8 @@ __device__ __forceinline__ void block_max_to(double *addr, double v) {
 // boundary(): box BCs direction by direction (x walls first, then y walls over the x-ghosts,
 // so corner ghosts are the y-BC applied to the x-ghost column).  Only sides flagged in
 // `walls` are physical walls; the others are tile edges filled by the halo exchange.
-__global__ void k_fill_ghost(double *f, NatGeom g, int nl, int bc, int walls) {
-  const int per = 2 * g.ny + 2 * (g.nx + 2);
+__global__ void k_fill_ghost(double *f, NatGeom g, int nl, int bc, int walls, int d) {
+  const int per = 2 * g.ny + 2 * (g.nx + 2 * d);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= per * nl) return;
   const int l = t / per, r = t % per;
@@ -73,22 +73,27 @@ __global__ void k_fill_ghost(double *f, NatGeom g, int nl, int bc, int walls) {
       if (walls & WALL_W) f[nat_idx(g, l, j, -1)] = bc == BC_PERIODIC ? f[nat_idx(g, l, j, g.nx - 1)] : s * f[nat_idx(g, l, j, 0)];
     }
   } else {
-    const int q = r - 2 * g.ny, i = (q >> 1) - 1, north = q & 1;  // i in [-1, nx]
+    // y walls over i in [-d, nx + d): the x-ghost columns take part (corner ghosts = y-BC of the
+    // x-ghost).  d > 1 only matters on tile edges, where those columns hold exchanged values.
+    const int q = r - 2 * g.ny, i = (q >> 1) - d, north = q & 1;
     if (!(walls & (north ? WALL_N : WALL_S))) return;
-    // value of the x-extended row next to the wall (uses the x-BC for i = -1, nx when that
-    // side is a wall; otherwise the exchanged ghost already stored there)
     const int jsrc = bc == BC_PERIODIC ? (north ? 0 : g.ny - 1) : (north ? g.ny - 1 : 0);
     double v;
-    if (i == -1 && (walls & WALL_W)) v = bc == BC_PERIODIC ? f[nat_idx(g, l, jsrc, g.nx - 1)] : s * f[nat_idx(g, l, jsrc, 0)];
-    else if (i == g.nx && (walls & WALL_E)) v = bc == BC_PERIODIC ? f[nat_idx(g, l, jsrc, 0)] : s * f[nat_idx(g, l, jsrc, g.nx - 1)];
-    else v = f[nat_idx(g, l, jsrc, i)];
+    if (i < 0 && (walls & WALL_W)) {
+      if (i != -1) return;
+      v = bc == BC_PERIODIC ? f[nat_idx(g, l, jsrc, g.nx - 1)] : s * f[nat_idx(g, l, jsrc, 0)];
+    } else if (i >= g.nx && (walls & WALL_E)) {
+      if (i != g.nx) return;
+      v = bc == BC_PERIODIC ? f[nat_idx(g, l, jsrc, 0)] : s * f[nat_idx(g, l, jsrc, g.nx - 1)];
+    } else
+      v = f[nat_idx(g, l, jsrc, i)];
     f[nat_idx(g, l, north ? g.ny : -1, i)] = bc == BC_PERIODIC ? v : s * v;
   }
 }
 
-void launch_fill_ghost(hipStream_t st, double *f, const NatGeom &g, int nl, int bc, int walls) {
-  const int n = (2 * g.ny + 2 * (g.nx + 2)) * nl;
-  hipLaunchKernelGGL(k_fill_ghost, dim3((n + 255) / 256), dim3(256), 0, st, f, g, nl, bc, walls);
+void launch_fill_ghost(hipStream_t st, double *f, const NatGeom &g, int nl, int bc, int walls, int depth) {
+  const int n = (2 * g.ny + 2 * (g.nx + 2 * depth)) * nl;
+  hipLaunchKernelGGL(k_fill_ghost, dim3((n + 255) / 256), dim3(256), 0, st, f, g, nl, bc, walls, depth);
 }
 
 // partial-slip override of the zeta ghosts, msqg/qg.h:185-198

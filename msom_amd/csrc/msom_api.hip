@@ -79,6 +79,7 @@ struct msom {
   int stochastic = 0, corrector_step = 0, noise_mode = 0;
   int mg_fused = 1;  // fused residual+restriction and correction+residual passes of the multigrid cycle
   double *psi_alt = nullptr;  // second psi buffer (the fused correction writes out of place)
+  int rhs_variant = 0;
   int fused = 1;  // one-pass PV tendency kernel (kernels_fused.hip) when the configuration allows
   unsigned seed = 1;
   int quiet = 0;
@@ -191,7 +192,7 @@ static int exch_nat(msom *m, double *f, int nl, int bc, int depth) {
       launch_nat_unpack_strip(m->st, f, g, nl, dir == DIR_W ? -d : g.nx, 0, d, g.ny, comm_recvbuf(m->comm, dir));
     }
   }
-  launch_fill_ghost(m->st, f, g, nl, bc, m->walls);
+  launch_fill_ghost(m->st, f, g, nl, bc, m->walls, d);
   if (m->nranks > 1) {
     Xfer x[2];
     int n = 0;
@@ -442,6 +443,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "profile")) m->profile = (int)v;
   else if (!strcmp(key, "fused")) m->fused = (int)v;
   else if (!strcmp(key, "mg_fused")) m->mg_fused = (int)v;
+  else if (!strcmp(key, "rhs_variant")) m->rhs_variant = (int)v;
   else if (!strcmp(key, "seed")) { m->seed = (unsigned)v; srand(m->seed); }
   else if (!strcmp(key, "noise_mode")) m->noise_mode = (int)v;
   else if (!strcmp(key, "stochastic")) {
@@ -838,16 +840,24 @@ static void comp_stretch(msom *m, int in, int out, double add, double fac) {
 
 // tendency terms after the inversion: comp_del2, advection_pv, dissip, ekman_friction,
 // surface_forcing, [qforcing], [bottom_topography]   (msqg/qg.h:622-630 / qg_bfn.h:67-76)
-static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double iRe, double iRe4, double Eks, double Ekb) {
+// adv_out >= 0 asks for q[adv_out] = q[adv_in] + adv_dt * dq in the same pass (the corrector's
+// advance_qg); *advanced tells the caller whether that happened (fused path) or not.
+static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double iRe, double iRe4, double Eks, double Ekb, int adv_out = -1,
+                     int adv_in = -1, double adv_dt = 0., int *advanced = nullptr) {
+  if (advanced) *advanced = 0;
   const Params &p = m->p;
   const double D = p.L0 / m->gnx;
   const int nl = m->nl;
-  if (m->fused && !m->have_pg && !m->have_zpg && !m->flag_topo && !m->stochastic && m->nranks == 1) {
+  if (m->fused && !m->have_pg && !m->have_zpg && !m->flag_topo && !m->stochastic && (m->nranks == 1 || (m->nx >= 4 && m->ny >= 4))) {
+    // tiles: the fused kernel needs psi on a 3-cell halo (zeta on 2, lap(zeta) on 1)
+    if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], nl, m->bc, 3));
     // one pass over psi: zeta, Jacobians, beta, dissipation, drag, forcing, max|u| (kernels_fused.hip)
     launch_rhs_fused(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, m->f[dqfield], m->partial_umax,
                      m->d_scal + SC_UMAX, m->g, nl, m->walls, m->uniformS, m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe,
                      iRe4, Eks / (p.Rom * 2 * m->dhf[0]), Ekb / (p.Rom * 2 * m->dhf[nl - 1]),
-                     p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc);
+                     p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, m->rhs_variant, adv_out >= 0 ? m->f[adv_in] : nullptr,
+                     adv_out >= 0 ? m->f[adv_out] : nullptr, adv_dt);
+    if (advanced && adv_out >= 0) *advanced = 1;
     return MSOM_OK;
   }
   HIPCHK(hipMemsetAsync(m->f[dqfield], 0, m->g.ls * nl * sizeof(double), m->st));  // updates = 0, msqg/qg.h:611-613
@@ -870,11 +880,12 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
 }
 
 // update_qg, msqg/qg.h:609-650
-static double update_qg(msom *m, int qfield, int dqfield, double dtmax) {
+static double update_qg(msom *m, int qfield, int dqfield, double dtmax, int adv_out = -1, int adv_in = -1, double adv_dt = 0.,
+                        int *advanced = nullptr) {
   const Params &p = m->p;
   const int nl = m->nl;
   if (invertq(m, m->f[qfield])) return -1;
-  if (rhs_terms(m, qfield, dqfield, 1, p.iRe, p.iRe4, p.Eks, p.Ekb)) return -1;
+  if (rhs_terms(m, qfield, dqfield, 1, p.iRe, p.iRe4, p.Eks, p.Ekb, adv_out, adv_in, adv_dt, advanced)) return -1;
   if (reduce_scal(m, SC_UMAX, nl, RED_MAX)) return -1;
   if (m->sticky) return -1;
   // :383-391: 2*nl limiter calls (psi_l then psipg_l) sharing one static `previous`
@@ -1070,8 +1081,10 @@ extern "C" int msom_step(msom_t *m, double *dt_used) {
   m->dt = dtnext(m, d, &tnext);
   int r;
   if ((r = advance_qg(m, MSOM_QPRED, MSOM_Q, MSOM_DQ, m->dt / 2.))) return r;
-  if (update_qg(m, MSOM_QPRED, MSOM_DQ, m->dt) < 0) return MSOM_ERR_HIP;
-  if ((r = advance_qg(m, MSOM_Q, MSOM_Q, MSOM_DQ, m->dt))) return r;
+  // corrector: dt is known, so the advance q += dt * dq rides in the tendency kernel
+  int advanced = 0;
+  if (update_qg(m, MSOM_QPRED, MSOM_DQ, m->dt, MSOM_Q, MSOM_Q, m->dt, &advanced) < 0) return MSOM_ERR_HIP;
+  if (!advanced && (r = advance_qg(m, MSOM_Q, MSOM_Q, MSOM_DQ, m->dt))) return r;
   m->t = tnext;
   m->iter++;
   if (dt_used) *dt_used = m->dt;
@@ -1347,6 +1360,8 @@ extern "C" int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double
     } else if (!strcmp(kernel, "advection")) {
       launch_advection(m->st, m->f[MSOM_ZETA], m->f[MSOM_PSI], m->f[MSOM_PSIPG], m->f[MSOM_ZETAPG], m->f[MSOM_S], m->f[MSOM_Q], m->f[MSOM_TMP], m->g,
                        m->nl, m->have_pg, m->have_zpg, m->stochastic, D, m->p.beta, m->p.itr_stoch, m->lc);
+    } else if (!strcmp(kernel, "rhs")) {
+      rhs_terms(m, MSOM_Q, MSOM_DQ, 1, m->p.iRe, m->p.iRe4, m->p.Eks, m->p.Ekb);
     } else if (!strcmp(kernel, "advance")) {
       launch_advance(m->st, m->f[MSOM_QPRED], m->f[MSOM_Q], m->f[MSOM_DQ], nullptr, m->g, m->nl, 1e-9, 0.);
     }
