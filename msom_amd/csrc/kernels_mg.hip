@@ -431,8 +431,104 @@ __global__ void __launch_bounds__(BX *BY) k_relax_color(RelaxArgs p) {
   }
 }
 
+// Two adjacent same-colour points per thread: every access is a 16-byte load/store
+// (4 x double2 + 1 scalar load and 1 double2 store per layer for two columns), which is what
+// the HBM path of gfx950 wants.  Used on levels whose half rows are even and >= 128 wide.
+template <int NL, bool UNIFORM, bool FINE>
+__global__ void __launch_bounds__(BX *BY) k_relax_color_x2(RelaxArgs p) {
+  const int kx = 2 * (blockIdx.x * BX + threadIdx.x), j = blockIdx.y * BY + threadIdx.y;
+  if (kx >= p.g.hk || j >= p.g.ny) return;
+  const int px = (j + p.color) & 1;
+  const int i = 2 * kx + px;  // x of the first point; the second is i + 2
+  const int hp = p.g.hp, rp = p.g.rp;
+  const size_t ls = p.g.ls;
+  const size_t own = (size_t)(j + 1) * rp + px * hp + MSOM_SP + kx;
+  const size_t oth = (size_t)(j + 1) * rp + (1 - px) * hp + MSOM_SP + kx;
+  const size_t ixs = px ? oth + 2 : oth - 1;
+  const double sqD = p.rc.sqD;
+  double xa[NL], xb[NL];
+  auto ld2 = [&](const double *f, size_t k) { return *reinterpret_cast<const double2 *>(f + k); };
+  if (NL == 1) {
+    const double2 b = ld2(p.res, own), d = ld2(p.da, oth), n = ld2(p.da, own + rp), s = ld2(p.da, own - rp);
+    const double xs = p.da[ixs];
+    const double w1 = px ? d.x : xs, e1 = px ? d.y : d.x, w2 = px ? d.y : d.x, e2 = px ? xs : d.y;
+    double n1 = -sqD * b.x, n2 = -sqD * b.y, dd = 0.;
+    n1 += e1 + w1; n2 += e2 + w2; dd += 2.;
+    n1 += n.x + s.x; n2 += n.y + s.y; dd += 2.;
+    xa[0] = n1 / dd; xb[0] = n2 / dd;
+  } else {
+    double ra[NL], rb[NL], t0a[NL], t1a[NL], t2a[NL], t0b[NL], t1b[NL], t2b[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      const double2 b = ld2(p.res, own + l * ls), d = ld2(p.da, oth + l * ls), n = ld2(p.da, own + rp + l * ls), s = ld2(p.da, own - rp + l * ls);
+      const double xs = p.da[ixs + l * ls];
+      const double w1 = px ? d.x : xs, e1 = px ? d.y : d.x, w2 = px ? d.y : d.x, e2 = px ? xs : d.y;
+      ra[l] = -sqD * b.x; rb[l] = -sqD * b.y;
+      if (!UNIFORM) {
+        double2 sm = make_double2(0., 0.), sc = make_double2(0., 0.);
+        if (l > 0) sm = ld2(p.S, own + (l - 1) * ls);
+        if (l < NL - 1) sc = ld2(p.S, own + l * ls);
+        t0a[l] = l > 0 ? -sqD * sm.x * p.rc.idh0[l] : 0.; t0b[l] = l > 0 ? -sqD * sm.y * p.rc.idh0[l] : 0.;
+        t2a[l] = l < NL - 1 ? -sqD * sc.x * p.rc.idh1[l] : 0.; t2b[l] = l < NL - 1 ? -sqD * sc.y * p.rc.idh1[l] : 0.;
+        t1a[l] = l == 0 ? -t2a[l] : (l < NL - 1 ? -t0a[l] - t2a[l] : -t0a[l]);
+        t1b[l] = l == 0 ? -t2b[l] : (l < NL - 1 ? -t0b[l] - t2b[l] : -t0b[l]);
+        ra[l] += 1. * e1 + 1. * w1; rb[l] += 1. * e2 + 1. * w2;
+        t1a[l] += 1. + 1.; t1b[l] += 1. + 1.;
+        ra[l] += 1. * n.x + 1. * s.x; rb[l] += 1. * n.y + 1. * s.y;
+        t1a[l] += 1. + 1.; t1b[l] += 1. + 1.;
+      } else {
+        ra[l] += e1 + w1; rb[l] += e2 + w2;
+        ra[l] += n.x + s.x; rb[l] += n.y + s.y;
+      }
+    }
+    if (UNIFORM) {
+#pragma unroll
+      for (int l = 1; l < NL; l++) { ra[l] -= p.rc.w[l] * ra[l - 1]; rb[l] -= p.rc.w[l] * rb[l - 1]; }
+      xa[NL - 1] = ra[NL - 1] * p.rc.it1[NL - 1]; xb[NL - 1] = rb[NL - 1] * p.rc.it1[NL - 1];
+#pragma unroll
+      for (int l = NL - 2; l >= 0; l--) {
+        xa[l] = (ra[l] - p.rc.t2[l] * xa[l + 1]) * p.rc.it1[l];
+        xb[l] = (rb[l] - p.rc.t2[l] * xb[l + 1]) * p.rc.it1[l];
+      }
+    } else {
+#pragma unroll
+      for (int l = 1; l < NL; l++) {
+        t1a[l] -= t0a[l] * t2a[l - 1] / t1a[l - 1]; ra[l] -= t0a[l] * ra[l - 1] / t1a[l - 1];
+        t1b[l] -= t0b[l] * t2b[l - 1] / t1b[l - 1]; rb[l] -= t0b[l] * rb[l - 1] / t1b[l - 1];
+      }
+      xa[NL - 1] = ra[NL - 1] / t1a[NL - 1]; xb[NL - 1] = rb[NL - 1] / t1b[NL - 1];
+#pragma unroll
+      for (int l = NL - 2; l >= 0; l--) {
+        xa[l] = (ra[l] - t2a[l] * xa[l + 1]) / t1a[l];
+        xb[l] = (rb[l] - t2b[l] * xb[l + 1]) / t1b[l];
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < NL; l++) *reinterpret_cast<double2 *>(p.da + own + l * ls) = make_double2(xa[l], xb[l]);
+  const bool edge = (i == 0) | (i + 2 >= p.g.nx - 1) | (j == 0) | (j == p.g.ny - 1);
+  if (edge && p.walls) {
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      split_write_ghosts(p.da, p.g, l, j, i, xa[l], p.walls);
+      split_write_ghosts(p.da, p.g, l, j, i + 2, xb[l], p.walls);
+    }
+  }
+}
+
 template <int NL>
 static void relax_dispatch(hipStream_t st, const RelaxArgs &p, int uniformS, int fine) {
+  if (p.g.hk % 2 == 0 && p.g.hk >= 128) {  // wide levels: two points per thread, 16-byte accesses
+    dim3 g2 = grid2d(p.g.hk / 2, p.g.ny);
+    if (uniformS) {
+      if (fine) hipLaunchKernelGGL((k_relax_color_x2<NL, true, true>), g2, block2d(), 0, st, p);
+      else hipLaunchKernelGGL((k_relax_color_x2<NL, true, false>), g2, block2d(), 0, st, p);
+    } else {
+      if (fine) hipLaunchKernelGGL((k_relax_color_x2<NL, false, true>), g2, block2d(), 0, st, p);
+      else hipLaunchKernelGGL((k_relax_color_x2<NL, false, false>), g2, block2d(), 0, st, p);
+    }
+    return;
+  }
   dim3 gr = grid2d(p.g.hk, p.g.ny);
   if (uniformS) {
     if (fine) hipLaunchKernelGGL((k_relax_color<NL, true, true>), gr, block2d(), 0, st, p);

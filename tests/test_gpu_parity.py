@@ -375,3 +375,33 @@ def test_fused_tendency_equals_unfused_chain(nx, ny, nl, extra):
     assert d1 == d0 == d_o
     assert np.array_equal(dq1, dq0)
     assert np.array_equal(dq1, o.get(orc.DQ))
+
+
+@pytest.mark.parametrize("nx,ny,nl,uniform", [(512, 64, 3, 1), (256, 128, 6, 0), (256, 64, 1, 1), (1024, 32, 2, 1)])
+def test_wide_level_two_point_relax_kernel(nx, ny, nl, uniform):
+    """k_relax_color_x2 (two same-colour points per thread, 16-byte accesses) is used when a
+    half row is >= 128 wide: bit-exact in the strict build, 1e-13 in the product build."""
+    for strict in (True, False):
+        o, g = make_pair(nx, ny, nl, strict=strict)
+        if not uniform:
+            x = (np.arange(nx) + 0.5) / nx
+            fr = np.stack([o.param(f"Fr_{l}") * (1 + 0.3 * np.sin(2 * np.pi * (l + 1) * x))[None, :] * np.ones((ny, 1)) for l in range(nl - 1)])
+            o.set(orc.FR, fr); g.set(F["FR"], fr)
+            o.set_const(); g.set_const()
+        for lev in (0, 1):
+            lx, ly = g.level_dims(lev)
+            da, res = rand_field(40 + lev, (nl, ly, lx)), rand_field(50 + lev, (nl, ly, lx))
+            got, ref = g.relax(lev, da, res, 2), o.relax(lev, da, res, 2)
+            if strict:
+                assert np.array_equal(got, ref), (lev, strict)
+            else:
+                assert rel(got, ref) <= 1e-13, (lev, strict)
+        # and through the whole solver
+        q = o.get(orc.Q) + rand_field(9, (nl, ny, nx), 1e-6)
+        p_g = np.empty_like(q)
+        g.pyq2p(p_g, q)
+        p_o = o.pyq2p(q)
+        if strict:
+            assert np.array_equal(p_g, p_o)
+        else:
+            assert rel(p_g, p_o) <= 1e-9
