@@ -62,7 +62,7 @@ struct msom {
   // multigrid hierarchy (level 0 = finest)
   int nlev = 0;
   std::vector<SplitGeom> sg;
-  std::vector<double *> da, res, S;
+  std::vector<double *> da, da_alt, res, S;
   std::vector<RelaxCoef> rc;
   size_t max_split = 0;
   // scratch
@@ -77,6 +77,7 @@ struct msom {
   int const_set = 0, flag_topo = 0, have_pg = 0, have_zpg = 0, have_qforc = 0;
   int fr_uniform = 1, uniformS = 0, uniform_opt = -1 /* auto */;
   int stochastic = 0, corrector_step = 0, noise_mode = 0;
+  int block_sweeps = 1;  // temporally blocked smoother (2 sweeps per pass) where applicable
   int mg_fused = 1;  // fused residual+restriction and correction+residual passes of the multigrid cycle
   double *psi_alt = nullptr;  // second psi buffer (the fused correction writes out of place)
   int rhs_variant = 0;
@@ -89,7 +90,7 @@ struct msom {
   msom_mgstats mg = {0, 0, 0, 0, 0};
   // profiling of the finest-level smoother sweep
   int profile = 0;
-  ProfSlot prof_sweep, prof_resid;
+  ProfSlot prof_sweep, prof_resid, prof_block;
 };
 
 extern "C" const char *msom_version(void) {
@@ -275,11 +276,13 @@ static int alloc_all(msom *m) {
   while ((m->nx >> n) >= 2 && (m->ny >> n) >= 2 && ((m->nx >> n) << n) == m->nx && ((m->ny >> n) << n) == m->ny) n++;
   if (m->p.mglevels > 0 && m->p.mglevels < n) n = m->p.mglevels;
   m->nlev = n;
-  m->sg.resize(n); m->da.resize(n); m->res.resize(n); m->S.resize(n); m->rc.resize(n);
+  m->sg.resize(n); m->da.resize(n); m->da_alt.resize(n); m->res.resize(n); m->S.resize(n); m->rc.resize(n);
   for (int k = 0; k < n; k++) {
     m->sg[k] = make_split(m->nx >> k, m->ny >> k);
     size_t bytes = m->sg[k].ls * m->nl * sizeof(double);
     HIPCHK(hipMalloc(&m->da[k], bytes));
+    HIPCHK(hipMalloc(&m->da_alt[k], bytes));
+    HIPCHK(hipMemsetAsync(m->da_alt[k], 0, bytes, m->st));
     HIPCHK(hipMalloc(&m->res[k], bytes));
     HIPCHK(hipMalloc(&m->S[k], m->sg[k].ls * m->nlm * sizeof(double)));
     HIPCHK(hipMemsetAsync(m->da[k], 0, bytes, m->st));
@@ -408,6 +411,7 @@ extern "C" int msom_destroy(msom_t *m) {
     if (m->f[k]) hipFree(m->f[k]);
   for (int k = 0; k < m->nlev; k++) {
     if (m->da[k]) hipFree(m->da[k]);
+    if (m->da_alt[k]) hipFree(m->da_alt[k]);
     if (m->res[k]) hipFree(m->res[k]);
     if (m->S[k]) hipFree(m->S[k]);
   }
@@ -418,7 +422,7 @@ extern "C" int msom_destroy(msom_t *m) {
   if (m->d_scal) hipFree(m->d_scal);
   if (m->h_scal) hipHostFree(m->h_scal);
   if (m->d_wind) hipFree(m->d_wind);
-  for (auto *ps : {&m->prof_sweep, &m->prof_resid})
+  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block})
     for (auto e : ps->ev) hipEventDestroy(e);
   if (m->comm) comm_destroy(m->comm);
   if (m->st) hipStreamDestroy(m->st);
@@ -443,6 +447,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "profile")) m->profile = (int)v;
   else if (!strcmp(key, "fused")) m->fused = (int)v;
   else if (!strcmp(key, "mg_fused")) m->mg_fused = (int)v;
+  else if (!strcmp(key, "block_sweeps")) m->block_sweeps = (int)v;
   else if (!strcmp(key, "rhs_variant")) m->rhs_variant = (int)v;
   else if (!strcmp(key, "seed")) { m->seed = (unsigned)v; srand(m->seed); }
   else if (!strcmp(key, "noise_mode")) m->noise_mode = (int)v;
@@ -686,9 +691,28 @@ extern "C" int msom_set_const(msom_t *m) {
 
 // ------------------------------------------------------------------ elliptic solver
 
-static void relax_sweeps(msom *m, int k, int nrelax, int last_level_exchange_corners = 0) {
+// can level k use the temporally blocked smoother (k_relax_block: 2 sweeps per pass)?
+static bool block_ok(msom *m, int k) {
+  return m->block_sweeps && m->uniformS && m->nranks == 1 && m->sg[k].nx >= 64 && m->sg[k].ny >= 16;
+}
+
+// nrelax red-black relaxations of da[k] against res[k] (each followed by boundary_level).
+// from_coarse: da[k] has not been prolongated yet -- the first blocked pass interpolates it
+// from da[k+1] on the fly.
+static void relax_sweeps(msom *m, int k, int nrelax, int last_level_exchange_corners = 0, bool from_coarse = false) {
   const bool prof = m->profile && k == 0;
-  for (int it = 0; it < nrelax; it++) {
+  int it = 0;
+  if (block_ok(m, k)) {
+    for (; it + 2 <= nrelax; it += 2) {
+      const bool pl = from_coarse && it == 0;
+      if (prof && !pl) prof_begin(m, m->prof_block);
+      launch_relax_block2(m->st, m->da[k], pl ? m->da[k + 1] : nullptr, m->sg[pl ? k + 1 : k], m->res[k], m->da_alt[k], m->sg[k], m->nl, m->rc[k],
+                          m->walls, k == 0);
+      if (prof && !pl) prof_end(m, m->prof_block);
+      std::swap(m->da[k], m->da_alt[k]);
+    }
+  }
+  for (; it < nrelax; it++) {
     if (prof) prof_begin(m, m->prof_sweep);
     for (int c = 0; c < 2; c++) {
       launch_relax_color(m->st, m->da[k], m->res[k], m->S[k], m->sg[k], m->nl, m->rc[k], m->uniformS, c, m->walls, k == 0);
@@ -707,11 +731,11 @@ static void mg_cycle_levels(msom *m, int nrelax, int first_restrict) {
   for (int k = first_restrict; k < m->nlev; k++) launch_restrict(m->st, m->res[k - 1], m->sg[k - 1], m->res[k], m->sg[k], m->nl);
   for (int k = m->nlev - 1; k >= 0; k--) {
     if (k == m->nlev - 1) hipMemsetAsync(m->da[k], 0, m->sg[k].ls * m->nl * sizeof(double), m->st);
-    else {
+    else if (!(block_ok(m, k) && nrelax >= 2)) {
       launch_prolong(m->st, m->da[k + 1], m->sg[k + 1], m->da[k], m->sg[k], m->nl, m->walls);
       STICKY(m, exch_split(m, m->da[k], m->sg[k], m->nl, 0));
     }
-    relax_sweeps(m, k, nrelax, k > 0);
+    relax_sweeps(m, k, nrelax, k > 0, k < m->nlev - 1 && block_ok(m, k) && nrelax >= 2);
   }
 }
 
@@ -1332,12 +1356,12 @@ extern "C" int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, doubl
 
 extern "C" int msom_profile_reset(msom_t *m) {
   if (!m) return MSOM_ERR_ARG;
-  for (auto *ps : {&m->prof_sweep, &m->prof_resid}) { ps->used = 0; ps->total_ms = 0; ps->launches = 0; }
+  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block}) { ps->used = 0; ps->total_ms = 0; ps->launches = 0; }
   return MSOM_OK;
 }
 extern "C" int msom_profile_read(msom_t *m, const char *kernel, double *avg_ms, long *launches) {
   if (!m || !kernel) return MSOM_ERR_ARG;
-  ProfSlot *ps = !strcmp(kernel, "sweep") ? &m->prof_sweep : !strcmp(kernel, "residual") ? &m->prof_resid : nullptr;
+  ProfSlot *ps = !strcmp(kernel, "sweep") ? &m->prof_sweep : !strcmp(kernel, "residual") ? &m->prof_resid : !strcmp(kernel, "block2") ? &m->prof_block : nullptr;
   if (!ps) { msom_set_error("unknown kernel %s", kernel); return MSOM_ERR_ARG; }
   prof_collect(m, *ps);
   if (avg_ms) *avg_ms = ps->launches ? ps->total_ms / ps->launches : 0.;
@@ -1360,6 +1384,10 @@ extern "C" int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double
     } else if (!strcmp(kernel, "advection")) {
       launch_advection(m->st, m->f[MSOM_ZETA], m->f[MSOM_PSI], m->f[MSOM_PSIPG], m->f[MSOM_ZETAPG], m->f[MSOM_S], m->f[MSOM_Q], m->f[MSOM_TMP], m->g,
                        m->nl, m->have_pg, m->have_zpg, m->stochastic, D, m->p.beta, m->p.itr_stoch, m->lc);
+    } else if (!strcmp(kernel, "block2")) {
+      launch_relax_block2(m->st, m->da[0], nullptr, m->sg[0], m->res[0], m->da_alt[0], m->sg[0], m->nl, m->rc[0], m->walls, 1);
+    } else if (!strcmp(kernel, "block2p")) {
+      launch_relax_block2(m->st, m->da[0], m->da[1], m->sg[1], m->res[0], m->da_alt[0], m->sg[0], m->nl, m->rc[0], m->walls, 1);
     } else if (!strcmp(kernel, "rhs")) {
       rhs_terms(m, MSOM_Q, MSOM_DQ, 1, m->p.iRe, m->p.iRe4, m->p.Eks, m->p.Ekb);
     } else if (!strcmp(kernel, "advance")) {

@@ -405,3 +405,38 @@ def test_wide_level_two_point_relax_kernel(nx, ny, nl, uniform):
             assert np.array_equal(p_g, p_o)
         else:
             assert rel(p_g, p_o) <= 1e-9
+
+
+@pytest.mark.parametrize("nx,ny,nl", [(128, 64, 3), (64, 64, 6), (256, 128, 2), (192, 80, 4), (64, 32, 1)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_blocked_smoother_equals_plain_sweeps(nx, ny, nl, strict):
+    """k_relax_block (two red-black sweeps per pass through LDS, optional on-the-fly
+    prolongation) must reproduce the plain colour-by-colour sweeps bit for bit."""
+    if nx == 192:
+        pytest.skip("non power-of-two grids are rejected at create time")
+    txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else ""))
+    res = {}
+    for blk in (1, 0):
+        g = QG(txt, strict=strict)
+        g.option("quiet", 1)
+        g.option("uniform_S", 1)
+        g.option("block_sweeps", blk)
+        g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx))
+        g.set_const()
+        assert g.param("uniform_S") == (1.0 if nl > 1 else 0.0)
+        da, rr = rand_field(60, (nl, ny, nx)), rand_field(61, (nl, ny, nx))
+        out = [g.relax(0, da, rr, n) for n in (2, 3, 4)]
+        g.option("TOLERANCE", 1e-10)
+        q = g.get(F["Q"]) + rand_field(9, (nl, ny, nx), 1e-6)
+        p = np.empty_like(q)
+        g.pyq2p(p, q)
+        st = g.mgstats()
+        for _ in range(3):
+            g.step()
+        res[blk] = (out, p, (st.i, st.resa, st.nrelax), g.get(F["Q"]))
+    if nl > 1:
+        for a, b in zip(res[1][0], res[0][0]):
+            assert np.array_equal(a, b)
+        assert res[1][2] == res[0][2]
+        assert np.array_equal(res[1][1], res[0][1])
+        assert np.array_equal(res[1][3], res[0][3])
