@@ -516,6 +516,150 @@ __global__ void __launch_bounds__(BX *BY) k_relax_color_x2(RelaxArgs p) {
   }
 }
 
+// First red half-sweep of a level fused with the prolongation: instead of reading the black
+// neighbours from da (which would first have to be written by a prolongation pass), each of
+// them is interpolated on the fly from the 3x3 coarse cells around the red cell (bilinear
+// rule of k_prolong).  In red-black order the interpolated values are needed nowhere else:
+// red values are overwritten without being read, black values are only read here -- except
+// as lagged wall ghosts, which this kernel writes (ghost = -interpolated wall cell).
+// All lanes of a wave share the parities of i and j, so the case analysis is wave-uniform.
+struct RelaxPArgs {
+  double *da;
+  const double *res, *S, *coarse;
+  SplitGeom g, cg;
+  int walls;
+  RelaxCoef rc;
+};
+template <int NL, bool UNIFORM, int PJ>
+__device__ __forceinline__ void relax_red_prolong_body(const RelaxPArgs &p) {
+  // rows of one parity per workgroup half (blockIdx.z): the parities are compile-time, so the
+  // choice of coarse cells is a static register selection
+  const int kx = blockIdx.x * BX + threadIdx.x, j = 2 * (blockIdx.y * BY + threadIdx.y) + PJ;
+  if (kx >= p.g.hk || j >= p.g.ny) return;
+  constexpr int pj = PJ, pi = PJ;  // red: (i + j) even
+  const int i = 2 * kx + pi, I0 = kx, J0 = j >> 1;
+  const int nx = p.g.nx, ny = p.g.ny;
+  const size_t ls = p.g.ls;
+  const size_t own = split_idx(p.g, 0, j, i);
+  // coarse window offsets [dj+1][di+1] (layer 0)
+  size_t cw[3][3];
+#pragma unroll
+  for (int dj = -1; dj <= 1; dj++)
+#pragma unroll
+    for (int di = -1; di <= 1; di++) cw[dj + 1][di + 1] = split_idx(p.cg, 0, J0 + dj, I0 + di);
+  // x columns (near, far) and y rows (near, far) of the four neighbours, window coordinates
+  constexpr int wxn = pi ? 1 : 0, wxf = pi ? 0 : 1;   // W = (i-1, j): columns {I0-1, I0}
+  constexpr int exn = pi ? 2 : 1, exf = pi ? 1 : 2;   // E = (i+1, j): columns {I0, I0+1}
+  constexpr int cxf = pi ? 2 : 0;                     // S, N: x near = I0, far = I0 + (pi ? 1 : -1)
+  constexpr int cyf = pj ? 2 : 0;                     // W, E: y near = J0, far = J0 + (pj ? 1 : -1)
+  constexpr int syn = pj ? 1 : 0, syf = pj ? 0 : 1;   // S = (i, j-1): rows {J0-1, J0}
+  constexpr int nyn = pj ? 2 : 1, nyf = pj ? 1 : 2;   // N = (i, j+1): rows {J0, J0+1}
+  const double sqD = p.rc.sqD;
+  double rhs[NL], x[NL], t0[NL], t1[NL], t2[NL];
+  const bool wl = i - 1 == 0 && (p.walls & WALL_W), el = i + 1 == nx - 1 && (p.walls & WALL_E);
+  const bool sl = j - 1 == 0 && (p.walls & WALL_S), nl_ = j + 1 == ny - 1 && (p.walls & WALL_N);
+  const bool ow = i == 0 && (p.walls & WALL_W), oe = i == nx - 1 && (p.walls & WALL_E);
+  const bool os = j == 0 && (p.walls & WALL_S), on = j == ny - 1 && (p.walls & WALL_N);
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    const double *cc = p.coarse + (size_t)l * p.cg.ls;
+    double c[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) c[a][b] = cc[cw[a][b]];
+#define BIL(yn, yf, xn, xf) ((9. * c[yn][xn] + 3. * (c[yn][xf] + c[yf][xn]) + c[yf][xf]) / 16.)
+    // interpolated neighbours; beyond a wall the ghost is -own interpolated value (lagged ghost)
+    const double vo = (ow | oe | os | on) ? BIL(1, cyf, 1, cxf) : 0.;
+    const double vw = ow ? -vo : BIL(1, cyf, wxn, wxf);
+    const double ve = oe ? -vo : BIL(1, cyf, exn, exf);
+    const double vs = os ? -vo : BIL(syn, syf, 1, cxf);
+    const double vn = on ? -vo : BIL(nyn, nyf, 1, cxf);
+#undef BIL
+    // black wall cells next to this red cell: write their lagged ghosts for the black half-sweep
+    if (wl) p.da[split_idx(p.g, l, j, -1)] = -vw;
+    if (el) p.da[split_idx(p.g, l, j, nx)] = -ve;
+    if (sl) p.da[split_idx(p.g, l, -1, i)] = -vs;
+    if (nl_) p.da[split_idx(p.g, l, ny, i)] = -vn;
+    // black neighbours that touch a wall in the OTHER direction (e.g. W neighbour on the south wall)
+    if (os && !ow) p.da[split_idx(p.g, l, -1, i - 1)] = -vw;
+    if (os && !oe) p.da[split_idx(p.g, l, -1, i + 1)] = -ve;
+    if (on && !ow) p.da[split_idx(p.g, l, ny, i - 1)] = -vw;
+    if (on && !oe) p.da[split_idx(p.g, l, ny, i + 1)] = -ve;
+    if (ow && !os) p.da[split_idx(p.g, l, j - 1, -1)] = -vs;
+    if (ow && !on) p.da[split_idx(p.g, l, j + 1, -1)] = -vn;
+    if (oe && !os) p.da[split_idx(p.g, l, j - 1, nx)] = -vs;
+    if (oe && !on) p.da[split_idx(p.g, l, j + 1, nx)] = -vn;
+    rhs[l] = -sqD * p.res[own + l * ls];
+    if (NL > 1 && !UNIFORM) {
+      t0[l] = l > 0 ? -sqD * p.S[own + (l - 1) * ls] * p.rc.idh0[l] : 0.;
+      t2[l] = l < NL - 1 ? -sqD * p.S[own + l * ls] * p.rc.idh1[l] : 0.;
+      t1[l] = l == 0 ? -t2[l] : (l < NL - 1 ? -t0[l] - t2[l] : -t0[l]);
+      rhs[l] += 1. * ve + 1. * vw;
+      t1[l] += 1. + 1.;
+      rhs[l] += 1. * vn + 1. * vs;
+      t1[l] += 1. + 1.;
+    } else {
+      rhs[l] += ve + vw;
+      rhs[l] += vn + vs;
+    }
+  }
+  if (NL == 1) {
+    double d = 0.;
+    d += 2.; d += 2.;
+    x[0] = rhs[0] / d;
+  } else if (UNIFORM) {
+#pragma unroll
+    for (int l = 1; l < NL; l++) rhs[l] -= p.rc.w[l] * rhs[l - 1];
+    x[NL - 1] = rhs[NL - 1] * p.rc.it1[NL - 1];
+#pragma unroll
+    for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - p.rc.t2[l] * x[l + 1]) * p.rc.it1[l];
+  } else {
+#pragma unroll
+    for (int l = 1; l < NL; l++) {
+      t1[l] -= t0[l] * t2[l - 1] / t1[l - 1];
+      rhs[l] -= t0[l] * rhs[l - 1] / t1[l - 1];
+    }
+    x[NL - 1] = rhs[NL - 1] / t1[NL - 1];
+#pragma unroll
+    for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - t2[l] * x[l + 1]) / t1[l];
+  }
+#pragma unroll
+  for (int l = 0; l < NL; l++) p.da[own + l * ls] = x[l];
+  if ((ow | oe | os | on)) {
+#pragma unroll
+    for (int l = 0; l < NL; l++) split_write_ghosts(p.da, p.g, l, j, i, x[l], p.walls);
+  }
+}
+template <int NL, bool UNIFORM>
+__global__ void __launch_bounds__(BX *BY) k_relax_red_prolong(RelaxPArgs p) {
+  if (blockIdx.z == 0) relax_red_prolong_body<NL, UNIFORM, 0>(p);
+  else relax_red_prolong_body<NL, UNIFORM, 1>(p);
+}
+template <int NL>
+static void relax_red_prolong_dispatch(hipStream_t st, const RelaxPArgs &p, int uniformS) {
+  dim3 gr = grid2d(p.g.hk, (p.g.ny + 1) / 2);
+  gr.z = 2;
+  if (uniformS) hipLaunchKernelGGL((k_relax_red_prolong<NL, true>), gr, block2d(), 0, st, p);
+  else hipLaunchKernelGGL((k_relax_red_prolong<NL, false>), gr, block2d(), 0, st, p);
+}
+void launch_relax_red_prolong(hipStream_t st, double *da, const double *coarse, const SplitGeom &cg, const double *res, const double *S,
+                              const SplitGeom &sg, int nl, const RelaxCoef &rc, int uniformS, int walls) {
+  RelaxPArgs p;
+  p.da = da; p.res = res; p.S = S; p.coarse = coarse; p.g = sg; p.cg = cg; p.walls = walls; p.rc = rc;
+  switch (nl) {
+    case 1: relax_red_prolong_dispatch<1>(st, p, uniformS); break;
+    case 2: relax_red_prolong_dispatch<2>(st, p, uniformS); break;
+    case 3: relax_red_prolong_dispatch<3>(st, p, uniformS); break;
+    case 4: relax_red_prolong_dispatch<4>(st, p, uniformS); break;
+    case 5: relax_red_prolong_dispatch<5>(st, p, uniformS); break;
+    case 6: relax_red_prolong_dispatch<6>(st, p, uniformS); break;
+    case 7: relax_red_prolong_dispatch<7>(st, p, uniformS); break;
+    case 8: relax_red_prolong_dispatch<8>(st, p, uniformS); break;
+    default: break;
+  }
+}
+
 template <int NL>
 static void relax_dispatch(hipStream_t st, const RelaxArgs &p, int uniformS, int fine) {
   if (p.g.hk % 2 == 0 && p.g.hk >= 128) {  // wide levels: two points per thread, 16-byte accesses
@@ -569,7 +713,6 @@ void launch_relax_color(hipStream_t st, double *da, const double *res, const dou
 // Walls: ghost cells lag exactly as in k_relax_color (the owner rewrites its ghost).
 #define BH 4
 #define BTX 64
-#define BNT 512
 struct BlockArgs {
   const double *da_in, *res, *coarse;
   double *da_out;
@@ -578,49 +721,60 @@ struct BlockArgs {
   RelaxCoef rc;
 };
 
-template <int NL, int BTY, bool PROLONG, bool FINE>
+template <int NL, int BTY, int BNT, bool PROLONG, bool FINE>
 __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
-  constexpr int NX = BTX + 2 * BH, NY = BTY + 2 * BH, HX = NX / 2;
+  constexpr int NX = BTX + 2 * BH, NY = BTY + 2 * BH, HX = NX / 2, LS = NY * 2 * HX;
   constexpr int NPOS = (HX * NY + BNT - 1) / BNT;
-  __shared__ double sA[NL * NY * 2 * HX];
+  __shared__ double sA[NL * LS];
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * BTX, y0 = blockIdx.y * BTY;
   const int nx = p.g.nx, ny = p.g.ny;
   const bool wW = (p.walls & WALL_W) && x0 == 0, wE = (p.walls & WALL_E) && x0 + BTX >= nx;
   const bool wS = (p.walls & WALL_S) && y0 == 0, wN = (p.walls & WALL_N) && y0 + BTY >= ny;
+  const bool edge_tile = wW | wE | wS | wN;
   const double sqD = p.rc.sqD;
-  auto lds = [&](int l, int yy, int xx) -> int { return ((l * NY + yy) * 2 + (xx & 1)) * HX + (xx >> 1); };
 
-  // ---- load / interpolate the tile (+ halo), fetch the residual of the owned cells
+  // ---- load / interpolate the tile (+ halo), fetch the residual of the owned cells.
+  // A thread owns NPOS positions (row yy, pair index k) = the cells (yy, 2k) and (yy, 2k+1):
+  // exactly one cell of each colour per position, so every lane works in every half-sweep.
   double rres[NPOS][2][NL];
+  int ob[NPOS];  // LDS index of (layer 0, row yy, parity 0, k)
 #pragma unroll
   for (int n = 0; n < NPOS; n++) {
     const int s = tid + n * BNT;
-    const int yy = s / HX, k = s % HX;
+    const int yy = s / HX, k = s - yy * HX;
     const int gy = y0 - BH + yy;
+    const bool act = s < HX * NY;
+    ob[n] = yy * 2 * HX + k;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       const int xx = 2 * k + c, gx = x0 - BH + xx;
-      const bool act = s < HX * NY;
       const bool inb = act && gx >= -1 && gx <= nx && gy >= -1 && gy <= ny;          // stored cell or ghost line
       const bool ind = act && gx >= 0 && gx < nx && gy >= 0 && gy < ny;               // cell of the domain
+      const size_t gsrc = split_idx(p.g, 0, gy, gx);
+      size_t c00 = 0, c10 = 0, c01 = 0, c11 = 0;
+      bool pv = false;
+      if (PROLONG) {
+        pv = inb && (ind || !((gx < 0 || gx >= nx) && (gy < 0 || gy >= ny)));
+        // ghost line: homogeneous Dirichlet image of the interpolated wall cell
+        const int mx = gx < 0 ? 0 : (gx >= nx ? nx - 1 : gx), my = gy < 0 ? 0 : (gy >= ny ? ny - 1 : gy);
+        const int I = mx >> 1, J = my >> 1, cx = (mx & 1) ? 1 : -1, cy = (my & 1) ? 1 : -1;
+        c00 = split_idx(p.cg, 0, J, I); c10 = split_idx(p.cg, 0, J, I + cx);
+        c01 = split_idx(p.cg, 0, J + cy, I); c11 = split_idx(p.cg, 0, J + cy, I + cx);
+      }
 #pragma unroll
       for (int l = 0; l < NL; l++) {
         double v = 0.;
         if (PROLONG) {
-          if (inb && (ind || !((gx < 0 || gx >= nx) && (gy < 0 || gy >= ny)))) {
-            // ghost line: homogeneous Dirichlet image of the interpolated wall cell
-            const int mx = gx < 0 ? 0 : (gx >= nx ? nx - 1 : gx), my = gy < 0 ? 0 : (gy >= ny ? ny - 1 : gy);
-            const int I = mx >> 1, J = my >> 1, cx = (mx & 1) ? 1 : -1, cy = (my & 1) ? 1 : -1;
-            v = (9. * p.coarse[split_idx(p.cg, l, J, I)] +
-                 3. * (p.coarse[split_idx(p.cg, l, J, I + cx)] + p.coarse[split_idx(p.cg, l, J + cy, I)]) +
-                 p.coarse[split_idx(p.cg, l, J + cy, I + cx)]) / 16.;
+          if (pv) {
+            const double *cc = p.coarse + (size_t)l * p.cg.ls;
+            v = (9. * cc[c00] + 3. * (cc[c10] + cc[c01]) + cc[c11]) / 16.;
             if (!ind) v = -v;
           }
         } else if (inb)
-          v = p.da_in[split_idx(p.g, l, gy, gx)];
-        if (act) sA[lds(l, yy, xx)] = v;
-        rres[n][c][l] = ind ? p.res[split_idx(p.g, l, gy, gx)] : 0.;
+          v = p.da_in[gsrc + (size_t)l * p.g.ls];
+        if (act) sA[l * LS + ob[n] + c * HX] = v;
+        rres[n][c][l] = ind ? p.res[gsrc + (size_t)l * p.g.ls] : 0.;
       }
     }
   }
@@ -633,24 +787,26 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
 #pragma unroll
     for (int n = 0; n < NPOS; n++) {
       const int s = tid + n * BNT;
-      const int yy = s / HX, k = s % HX;
+      const int yy = s / HX, k = s - yy * HX;
       const int c = (yy + col) & 1;  // which of the two owned cells has this colour
       const int xx = 2 * k + c, gx = x0 - BH + xx, gy = y0 - BH + yy;
       const bool ok = s < HX * NY && gx >= 0 && gx < nx && gy >= 0 && gy < ny && (xx >= h || wW) && (NX - 1 - xx >= h || wE) &&
                       (yy >= h || wS) && (NY - 1 - yy >= h || wN);
       if (ok) {
+        const int o = ob[n];
+        const int own = o + c * HX, iw = c ? o : o + HX - 1, ie = c ? o + 1 : o + HX;
         double rhs[NL], x[NL];
         if (NL == 1) {
           double nn = -sqD * (c ? rres[n][1][0] : rres[n][0][0]), d = 0.;
-          nn += sA[lds(0, yy, xx + 1)] + sA[lds(0, yy, xx - 1)]; d += 2.;
-          nn += sA[lds(0, yy + 1, xx)] + sA[lds(0, yy - 1, xx)]; d += 2.;
+          nn += sA[ie] + sA[iw]; d += 2.;
+          nn += sA[own + 2 * HX] + sA[own - 2 * HX]; d += 2.;
           x[0] = nn / d;
         } else {
 #pragma unroll
           for (int l = 0; l < NL; l++) {
             double r = -sqD * (c ? rres[n][1][l] : rres[n][0][l]);
-            r += sA[lds(l, yy, xx + 1)] + sA[lds(l, yy, xx - 1)];
-            r += sA[lds(l, yy + 1, xx)] + sA[lds(l, yy - 1, xx)];
+            r += sA[l * LS + ie] + sA[l * LS + iw];
+            r += sA[l * LS + own + 2 * HX] + sA[l * LS + own - 2 * HX];
             rhs[l] = r;
           }
 #pragma unroll
@@ -660,12 +816,16 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
           for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - p.rc.t2[l] * x[l + 1]) * p.rc.it1[l];
         }
 #pragma unroll
-        for (int l = 0; l < NL; l++) {
-          sA[lds(l, yy, xx)] = x[l];
-          if (gx == 0 && (p.walls & WALL_W)) sA[lds(l, yy, xx - 1)] = -x[l];
-          if (gx == nx - 1 && (p.walls & WALL_E)) sA[lds(l, yy, xx + 1)] = -x[l];
-          if (gy == 0 && (p.walls & WALL_S)) sA[lds(l, yy - 1, xx)] = -x[l];
-          if (gy == ny - 1 && (p.walls & WALL_N)) sA[lds(l, yy + 1, xx)] = -x[l];
+        for (int l = 0; l < NL; l++) sA[l * LS + own] = x[l];
+        if (edge_tile) {  // the owner rewrites the lagged wall ghosts it mirrors
+          const bool gw = gx == 0 && wW, ge = gx == nx - 1 && wE, gs = gy == 0 && wS, gn = gy == ny - 1 && wN;
+#pragma unroll
+          for (int l = 0; l < NL; l++) {
+            if (gw) sA[l * LS + iw] = -x[l];
+            if (ge) sA[l * LS + ie] = -x[l];
+            if (gs) sA[l * LS + own - 2 * HX] = -x[l];
+            if (gn) sA[l * LS + own + 2 * HX] = -x[l];
+          }
         }
       }
     }
@@ -676,7 +836,7 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
 #pragma unroll
   for (int n = 0; n < NPOS; n++) {
     const int s = tid + n * BNT;
-    const int yy = s / HX, k = s % HX;
+    const int yy = s / HX, k = s - yy * HX;
     if (s >= HX * NY || yy < BH || yy >= BH + BTY) continue;
     const int gy = y0 - BH + yy;
     if (gy >= ny) continue;
@@ -684,27 +844,43 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
     for (int c = 0; c < 2; c++) {
       const int xx = 2 * k + c, gx = x0 - BH + xx;
       if (xx < BH || xx >= BH + BTX || gx >= nx) continue;
+      const size_t gdst = split_idx(p.g, 0, gy, gx);
 #pragma unroll
       for (int l = 0; l < NL; l++) {
-        const double v = sA[lds(l, yy, xx)];
-        p.da_out[split_idx(p.g, l, gy, gx)] = v;
-        split_write_ghosts(p.da_out, p.g, l, gy, gx, v, p.walls);
+        const double v = sA[l * LS + ob[n] + c * HX];
+        p.da_out[gdst + (size_t)l * p.g.ls] = v;
+        if (edge_tile) split_write_ghosts(p.da_out, p.g, l, gy, gx, v, p.walls);
       }
     }
   }
 }
 
-template <int NL>
-static void block_dispatch(hipStream_t st, const BlockArgs &p, int prolong, int fine) {
-  constexpr int BTY = NL <= 3 ? 32 : 16;  // LDS: NL * (BTY + 8) * 72 * 8 B <= 160 KiB
+int g_block_variant = 0;  // tuning knob (tools/bench_kernels.py)
+template <int NL, int BTY, int BNT>
+static void block_launch(hipStream_t st, const BlockArgs &p, int prolong, int fine) {
   dim3 gr((p.g.nx + BTX - 1) / BTX, (p.g.ny + BTY - 1) / BTY);
   if (prolong) {
-    if (fine) hipLaunchKernelGGL((k_relax_block<NL, BTY, true, true>), gr, dim3(BNT), 0, st, p);
-    else hipLaunchKernelGGL((k_relax_block<NL, BTY, true, false>), gr, dim3(BNT), 0, st, p);
+    if (fine) hipLaunchKernelGGL((k_relax_block<NL, BTY, BNT, true, true>), gr, dim3(BNT), 0, st, p);
+    else hipLaunchKernelGGL((k_relax_block<NL, BTY, BNT, true, false>), gr, dim3(BNT), 0, st, p);
   } else {
-    if (fine) hipLaunchKernelGGL((k_relax_block<NL, BTY, false, true>), gr, dim3(BNT), 0, st, p);
-    else hipLaunchKernelGGL((k_relax_block<NL, BTY, false, false>), gr, dim3(BNT), 0, st, p);
+    if (fine) hipLaunchKernelGGL((k_relax_block<NL, BTY, BNT, false, true>), gr, dim3(BNT), 0, st, p);
+    else hipLaunchKernelGGL((k_relax_block<NL, BTY, BNT, false, false>), gr, dim3(BNT), 0, st, p);
   }
+}
+template <int NL>
+static void block_dispatch(hipStream_t st, const BlockArgs &p, int prolong, int fine) {
+  // LDS: NL * (BTY + 8) * 72 * 8 B; two workgroups per CU need <= 80 KiB each
+  if (NL == 6) {
+    switch (g_block_variant) {
+      case 1: block_launch<NL, 8, 256>(st, p, prolong, fine); return;
+      case 2: block_launch<NL, 8, 512>(st, p, prolong, fine); return;
+      case 3: block_launch<NL, 16, 1024>(st, p, prolong, fine); return;
+      case 4: block_launch<NL, 4, 256>(st, p, prolong, fine); return;
+      default: break;
+    }
+  }
+  constexpr int BTY = NL <= 3 ? 32 : 16;
+  block_launch<NL, BTY, 512>(st, p, prolong, fine);
 }
 // two full sweeps: da_out = RB^2(da_in or prolong(coarse)); uniform-S constant-coefficient path
 void launch_relax_block2(hipStream_t st, const double *da_in, const double *coarse, const SplitGeom &cg, const double *res, double *da_out,

@@ -77,7 +77,8 @@ struct msom {
   int const_set = 0, flag_topo = 0, have_pg = 0, have_zpg = 0, have_qforc = 0;
   int fr_uniform = 1, uniformS = 0, uniform_opt = -1 /* auto */;
   int stochastic = 0, corrector_step = 0, noise_mode = 0;
-  int block_sweeps = 1;  // temporally blocked smoother (2 sweeps per pass) where applicable
+  int prolong_fused = 1;  // first red half-sweep of a level interpolates its neighbours from the coarser level
+  int block_sweeps = 0;  // experimental temporally blocked smoother (2 sweeps per pass); measured not faster at nl = 6
   int mg_fused = 1;  // fused residual+restriction and correction+residual passes of the multigrid cycle
   double *psi_alt = nullptr;  // second psi buffer (the fused correction writes out of place)
   int rhs_variant = 0;
@@ -448,6 +449,8 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "fused")) m->fused = (int)v;
   else if (!strcmp(key, "mg_fused")) m->mg_fused = (int)v;
   else if (!strcmp(key, "block_sweeps")) m->block_sweeps = (int)v;
+  else if (!strcmp(key, "prolong_fused")) m->prolong_fused = (int)v;
+  else if (!strcmp(key, "block_variant")) { extern int g_block_variant; g_block_variant = (int)v; }
   else if (!strcmp(key, "rhs_variant")) m->rhs_variant = (int)v;
   else if (!strcmp(key, "seed")) { m->seed = (unsigned)v; srand(m->seed); }
   else if (!strcmp(key, "noise_mode")) m->noise_mode = (int)v;
@@ -696,6 +699,12 @@ static bool block_ok(msom *m, int k) {
   return m->block_sweeps && m->uniformS && m->nranks == 1 && m->sg[k].nx >= 64 && m->sg[k].ny >= 16;
 }
 
+// is the prolongation da[k+1] -> da[k] folded into the first smoothing pass of level k?
+static bool fuse_prolong(msom *m, int k, int nrelax) {
+  if (block_ok(m, k) && nrelax >= 2) return true;
+  return m->prolong_fused && nrelax >= 1 && m->sg[k].nx >= 4 && m->sg[k].ny >= 4;
+}
+
 // nrelax red-black relaxations of da[k] against res[k] (each followed by boundary_level).
 // from_coarse: da[k] has not been prolongated yet -- the first blocked pass interpolates it
 // from da[k+1] on the fly.
@@ -713,14 +722,18 @@ static void relax_sweeps(msom *m, int k, int nrelax, int last_level_exchange_cor
     }
   }
   for (; it < nrelax; it++) {
-    if (prof) prof_begin(m, m->prof_sweep);
+    const bool pl = from_coarse && it == 0;  // prolongation rides in the first red half-sweep
+    if (prof && !pl) prof_begin(m, m->prof_sweep);
     for (int c = 0; c < 2; c++) {
-      launch_relax_color(m->st, m->da[k], m->res[k], m->S[k], m->sg[k], m->nl, m->rc[k], m->uniformS, c, m->walls, k == 0);
+      if (pl && c == 0)
+        launch_relax_red_prolong(m->st, m->da[k], m->da[k + 1], m->sg[k + 1], m->res[k], m->S[k], m->sg[k], m->nl, m->rc[k], m->uniformS, m->walls);
+      else
+        launch_relax_color(m->st, m->da[k], m->res[k], m->S[k], m->sg[k], m->nl, m->rc[k], m->uniformS, c, m->walls, k == 0);
       // boundary_level(da, l): the last exchange of the level also carries the corner ghosts
       // that the bilinear prolongation to the next finer level reads
       STICKY(m, exch_split(m, m->da[k], m->sg[k], m->nl, last_level_exchange_corners && it == nrelax - 1 && c == 1));
     }
-    if (prof) prof_end(m, m->prof_sweep);
+    if (prof && !pl) prof_end(m, m->prof_sweep);
   }
 }
 
@@ -731,11 +744,11 @@ static void mg_cycle_levels(msom *m, int nrelax, int first_restrict) {
   for (int k = first_restrict; k < m->nlev; k++) launch_restrict(m->st, m->res[k - 1], m->sg[k - 1], m->res[k], m->sg[k], m->nl);
   for (int k = m->nlev - 1; k >= 0; k--) {
     if (k == m->nlev - 1) hipMemsetAsync(m->da[k], 0, m->sg[k].ls * m->nl * sizeof(double), m->st);
-    else if (!(block_ok(m, k) && nrelax >= 2)) {
+    else if (!fuse_prolong(m, k, nrelax)) {
       launch_prolong(m->st, m->da[k + 1], m->sg[k + 1], m->da[k], m->sg[k], m->nl, m->walls);
       STICKY(m, exch_split(m, m->da[k], m->sg[k], m->nl, 0));
     }
-    relax_sweeps(m, k, nrelax, k > 0, k < m->nlev - 1 && block_ok(m, k) && nrelax >= 2);
+    relax_sweeps(m, k, nrelax, k > 0, k < m->nlev - 1 && fuse_prolong(m, k, nrelax));
   }
 }
 

