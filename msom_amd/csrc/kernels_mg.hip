@@ -27,6 +27,15 @@
 #define DIVC(x, c, rc) ((x) * (rc))
 #endif
 
+// Basilisk's bilinear prolongation weight rule.  The product build pins the FMA contraction
+// so that every kernel that interpolates (k_prolong, k_relax_red_prolong, k_relax_block) and
+// every expansion inside them rounds identically; division by 16 is exact either way.
+#ifdef MSOM_STRICT
+#define BILINEAR(cn, cfx, cfy, cff) ((9. * (cn) + 3. * ((cfx) + (cfy)) + (cff)) / 16.)
+#else
+#define BILINEAR(cn, cfx, cfy, cff) (fma(9., (cn), fma(3., (cfx) + (cfy), (cff))) * 0.0625)
+#endif
+
 #define BX 64
 #define BY 4
 
@@ -342,9 +351,8 @@ __global__ void k_prolong(const double *__restrict__ coarse, SplitGeom cg, doubl
   if (i >= fg.nx || j >= fg.ny) return;
   const int I = i >> 1, J = j >> 1, cx = (i & 1) ? 1 : -1, cy = (j & 1) ? 1 : -1;
   for (int l = 0; l < nl; l++) {
-    const double v = (9. * coarse[split_idx(cg, l, J, I)] +
-                      3. * (coarse[split_idx(cg, l, J, I + cx)] + coarse[split_idx(cg, l, J + cy, I)]) +
-                      coarse[split_idx(cg, l, J + cy, I + cx)]) / 16.;
+    const double v = BILINEAR(coarse[split_idx(cg, l, J, I)], coarse[split_idx(cg, l, J, I + cx)], coarse[split_idx(cg, l, J + cy, I)],
+                              coarse[split_idx(cg, l, J + cy, I + cx)]);
     fine[split_idx(fg, l, j, i)] = v;
     split_write_ghosts(fine, fg, l, j, i, v, walls);
   }
@@ -568,7 +576,7 @@ __device__ __forceinline__ void relax_red_prolong_body(const RelaxPArgs &p) {
     for (int a = 0; a < 3; a++)
 #pragma unroll
       for (int b = 0; b < 3; b++) c[a][b] = cc[cw[a][b]];
-#define BIL(yn, yf, xn, xf) ((9. * c[yn][xn] + 3. * (c[yn][xf] + c[yf][xn]) + c[yf][xf]) / 16.)
+#define BIL(yn, yf, xn, xf) BILINEAR(c[yn][xn], c[yn][xf], c[yf][xn], c[yf][xf])
     // interpolated neighbours; beyond a wall the ghost is -own interpolated value (lagged ghost)
     const double vo = (ow | oe | os | on) ? BIL(1, cyf, 1, cxf) : 0.;
     const double vw = ow ? -vo : BIL(1, cyf, wxn, wxf);
@@ -576,20 +584,12 @@ __device__ __forceinline__ void relax_red_prolong_body(const RelaxPArgs &p) {
     const double vs = os ? -vo : BIL(syn, syf, 1, cxf);
     const double vn = on ? -vo : BIL(nyn, nyf, 1, cxf);
 #undef BIL
-    // black wall cells next to this red cell: write their lagged ghosts for the black half-sweep
+    // black wall cells whose wall-normal interior neighbour is this red cell: write their lagged
+    // ghosts for the black half-sweep (exactly one writer per ghost)
     if (wl) p.da[split_idx(p.g, l, j, -1)] = -vw;
     if (el) p.da[split_idx(p.g, l, j, nx)] = -ve;
     if (sl) p.da[split_idx(p.g, l, -1, i)] = -vs;
     if (nl_) p.da[split_idx(p.g, l, ny, i)] = -vn;
-    // black neighbours that touch a wall in the OTHER direction (e.g. W neighbour on the south wall)
-    if (os && !ow) p.da[split_idx(p.g, l, -1, i - 1)] = -vw;
-    if (os && !oe) p.da[split_idx(p.g, l, -1, i + 1)] = -ve;
-    if (on && !ow) p.da[split_idx(p.g, l, ny, i - 1)] = -vw;
-    if (on && !oe) p.da[split_idx(p.g, l, ny, i + 1)] = -ve;
-    if (ow && !os) p.da[split_idx(p.g, l, j - 1, -1)] = -vs;
-    if (ow && !on) p.da[split_idx(p.g, l, j + 1, -1)] = -vn;
-    if (oe && !os) p.da[split_idx(p.g, l, j - 1, nx)] = -vs;
-    if (oe && !on) p.da[split_idx(p.g, l, j + 1, nx)] = -vn;
     rhs[l] = -sqD * p.res[own + l * ls];
     if (NL > 1 && !UNIFORM) {
       t0[l] = l > 0 ? -sqD * p.S[own + (l - 1) * ls] * p.rc.idh0[l] : 0.;
@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
         if (PROLONG) {
           if (pv) {
             const double *cc = p.coarse + (size_t)l * p.cg.ls;
-            v = (9. * cc[c00] + 3. * (cc[c10] + cc[c01]) + cc[c11]) / 16.;
+            v = BILINEAR(cc[c00], cc[c10], cc[c01], cc[c11]);
             if (!ind) v = -v;
           }
         } else if (inb)
