@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(FNT, MINW) k_rhs_fused(RhsArgs a) {
     if ((tid & 63) == 0) sM[tid >> 6][l] = um;
     __syncthreads();
   }
-  if (tid < nl) {
+  if (a.umax_partial && tid < nl) {
     double v = sM[0][tid];
     for (int w = 1; w < FNT / 64; w++) v = fmax(v, sM[w][tid]);
     a.umax_partial[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * nl + tid] = v;
@@ -314,5 +314,5 @@ void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const 
     case 5: hipLaunchKernelGGL((k_rhs_fused<8, 256, 4>), gr, dim3(256), 0, st, a); break;
     default: hipLaunchKernelGGL((k_rhs_fused<32, 512, 2>), gr, dim3(512), 0, st, a); break;
   }
-  hipLaunchKernelGGL(k_max_final2, dim3(nl), dim3(256), 0, st, umax_partial, umax_out, (int)(gr.x * gr.y), nl);
+  if (umax_partial) hipLaunchKernelGGL(k_max_final2, dim3(nl), dim3(256), 0, st, umax_partial, umax_out, (int)(gr.x * gr.y), nl);
 }

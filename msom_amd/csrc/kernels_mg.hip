@@ -194,7 +194,7 @@ void launch_residual(hipStream_t st, const double *a, const double *b, const dou
 //              children in foreach_child order), saving the first restriction pass.
 struct Res2Args {
   const double *a, *b, *S, *da;
-  double *a_out, *res, *res_c, *maxres, *sum_partial;
+  double *a_out, *res, *res_c, *maxres, *sum_partial, *umax_partial;
   NatGeom g;
   SplitGeom sg, cg;
   int nl, uniformS, want_sum, walls;
@@ -205,10 +205,14 @@ template <bool CORRECT, bool WRITE, bool RESTRICT>
 __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
   __shared__ double sr[RESTRICT ? MSOM_MAXNL : 1][BY][BX][2];
   __shared__ double smm[BY], sms[BY];
+  __shared__ double smu[CORRECT ? MSOM_MAXNL : 1][BY];
   const int kx = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
   const bool in = kx < p.sg.hk && j < p.g.ny;
   const int nl = p.nl;
   double m = 0., bs = 0.;
+  double um[CORRECT ? MSOM_MAXNL : 1];
+#pragma unroll
+  for (int l = 0; l < (CORRECT ? MSOM_MAXNL : 1); l++) um[l] = 0.;
   if (in) {
     const int pitch = p.g.pitch, i = 2 * kx;
     const double D = p.rc.D, rD = 1. / D;
@@ -274,6 +278,19 @@ __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
       }
       if (RESTRICT) { sr[l][threadIdx.y][threadIdx.x][0] = re; sr[l][threadIdx.y][threadIdx.x][1] = ro; }
       m = fmax(m, fmax(fabs(re), fabs(ro)));
+      if (CORRECT) {
+        // face velocities of the corrected psi (comp_vel, msqg/qg.h:276-283): west and south face
+        // of both cells; feeds the dt limiter so that dt is known before the tendency pass
+        const double *d = p.da + (size_t)l * p.sg.ls;
+        const double nw = p.a[c - 1 + pitch] + d[so - 1 + p.sg.rp], sw = p.a[c - 1 - pitch] + d[so - 1 - p.sg.rp];
+        const double se2 = p.a[c + 2 - pitch] + d[se + 1 - p.sg.rp];
+        const double ue = fabs(DIVC(0.25 * (a1ne - a1se + nw - sw), D, rD)), ve = fabs(DIVC(0.25 * (a1o - a1w + a1so - sw), D, rD));
+        const double uo = fabs(DIVC(0.25 * (a1no - a1so + a1ne - a1se), D, rD)), vo = fabs(DIVC(0.25 * (a1ee - a1e + se2 - a1se), D, rD));
+        const double uu = fmax(fmax(ue, ve), fmax(uo, vo));
+#pragma unroll
+        for (int q = 0; q < MSOM_MAXNL; q++)
+          if (q == l) um[q] = uu;
+      }
       a0e = a1e; a0o = a1o; s0e = s1e; s0o = s1o;
       a1e = a2e; a1o = a2o; a1w = a2w; a1ee = a2ee; a1se = a2se; a1so = a2so; a1ne = a2ne; a1no = a2no;
     }
@@ -294,6 +311,14 @@ __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
   }
   m = wave_max(m);
   if (p.want_sum) bs = wave_sum(bs);
+  if (CORRECT) {
+#pragma unroll
+    for (int l = 0; l < MSOM_MAXNL; l++)
+      if (l < nl) {
+        const double v = wave_max(um[l]);
+        if (threadIdx.x == 0) smu[l][threadIdx.y] = v;
+      }
+  }
   if (threadIdx.x == 0) { smm[threadIdx.y] = m; sms[threadIdx.y] = bs; }
   __syncthreads();
   if (threadIdx.x == 0 && threadIdx.y == 0) {
@@ -302,6 +327,26 @@ __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
     atomicMax((unsigned long long *)p.maxres, (unsigned long long)__double_as_longlong(mm));
     if (p.want_sum) p.sum_partial[blockIdx.y * gridDim.x + blockIdx.x] = ss;
   }
+  if (CORRECT && threadIdx.y == 0 && threadIdx.x < nl) {
+    double v = smu[threadIdx.x][0];
+    for (int k = 1; k < BY; k++) v = fmax(v, smu[threadIdx.x][k]);
+    p.umax_partial[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * nl + threadIdx.x] = v;
+  }
+}
+
+// out[l] = max_b partial[b][l]
+__global__ void k_max_final_mg(const double *partial, double *out, int nb, int nl) {
+  __shared__ double sm[256];
+  const int l = blockIdx.x;
+  double v = 0.;
+  for (int b = threadIdx.x; b < nb; b += 256) v = fmax(v, partial[(size_t)b * nl + l]);
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[l] = sm[0];
 }
 
 int residual2_blocks(const NatGeom &g) {
@@ -311,13 +356,17 @@ int residual2_blocks(const NatGeom &g) {
 // mode bits: 1 = CORRECT, 2 = WRITE, 4 = RESTRICT
 void launch_residual2(hipStream_t st, int mode, const double *a, const double *da, double *a_out, const double *b, const double *S,
                       const NatGeom &g, double *res, const SplitGeom &sg, double *res_c, const SplitGeom &cg, int nl, const RelaxCoef &rc,
-                      int uniformS, int walls, double *maxres, double *sum_partial, int want_sum) {
+                      int uniformS, int walls, double *maxres, double *sum_partial, int want_sum, double *umax_partial, double *umax_out) {
   Res2Args p;
+  p.umax_partial = umax_partial;
   p.a = a; p.b = b; p.S = S; p.da = da; p.a_out = a_out; p.res = res; p.res_c = res_c; p.maxres = maxres; p.sum_partial = sum_partial;
   p.g = g; p.sg = sg; p.cg = cg; p.nl = nl; p.uniformS = uniformS; p.want_sum = want_sum; p.walls = walls; p.rc = rc;
   dim3 gr = grid2d(g.nx / 2, g.ny);
   switch (mode) {
-    case 1: hipLaunchKernelGGL((k_residual2<true, false, false>), gr, block2d(), 0, st, p); break;
+    case 1:
+      hipLaunchKernelGGL((k_residual2<true, false, false>), gr, block2d(), 0, st, p);
+      hipLaunchKernelGGL(k_max_final_mg, dim3(nl), dim3(256), 0, st, umax_partial, umax_out, (int)(gr.x * gr.y), nl);
+      break;
     case 2: hipLaunchKernelGGL((k_residual2<false, true, false>), gr, block2d(), 0, st, p); break;
     case 6: hipLaunchKernelGGL((k_residual2<false, true, true>), gr, block2d(), 0, st, p); break;
     case 0: hipLaunchKernelGGL((k_residual2<false, false, false>), gr, block2d(), 0, st, p); break;

@@ -30,7 +30,8 @@
   } while (0)
 
 // device scalar slots
-enum { SC_RES0 = 0, SC_RES1 = 1, SC_BSUM = 2, SC_KE = 3, SC_UMAX = 8 /* 2*MAXNL */, SC_LSUM = 32 /* MAXNL */, SC_COUNT = 64 };
+// RES0, RES1 and UMAX[nl] are contiguous: one max all-reduce / one copy brings them to the host
+enum { SC_BSUM = 2, SC_KE = 3, SC_SCRATCH = 4, SC_RES0 = 6, SC_RES1 = 7, SC_UMAX = 8 /* MAXNL */, SC_LSUM = 32 /* MAXNL */, SC_COUNT = 64 };
 
 struct ProfSlot {
   std::vector<hipEvent_t> ev;  // pairs (start, stop)
@@ -72,6 +73,7 @@ struct msom {
   double *d_scal = nullptr, *h_scal = nullptr;
   double *d_wind = nullptr;    // per-row surface forcing profile
   double umax_pg[MSOM_MAXNL];
+  int umax_ready = 0;  // h_scal[SC_UMAX..] holds max|u| of the current psi (from the last solve)
   hipStream_t st = nullptr;
   // flags
   int const_set = 0, flag_topo = 0, have_pg = 0, have_zpg = 0, have_qforc = 0;
@@ -762,19 +764,16 @@ static void residual2(msom *m, int mode, const double *b, int slot, int want_sum
   if (m->profile) prof_begin(m, m->prof_resid);
   launch_residual2(m->st, mode, m->f[MSOM_PSI], m->da[0], m->psi_alt, b, m->f[MSOM_S], m->g, m->res[0], m->sg[0],
                    m->nlev > 1 ? m->res[1] : nullptr, m->sg[m->nlev > 1 ? 1 : 0], m->nl, m->rc[0], m->uniformS, m->walls, m->d_scal + slot,
-                   m->partial, want_sum);
+                   m->partial, want_sum, m->partial_umax, m->d_scal + SC_UMAX);
   if (m->profile) prof_end(m, m->prof_resid);
 }
 
 // max-residual slots (RES0, RES1) and the rhs sum (BSUM) -> host, reduced over the tiles
 // (the reference's foreach(reduction(max:maxres)) / reduction(+:sum) are MPI all-reduces)
 static int read_residuals(msom *m) {
-  if (m->nranks > 1) {
-    int r = reduce_scal(m, SC_RES0, 2, RED_MAX);
-    if (r) return r;
-    return reduce_scal(m, SC_BSUM, 1, RED_SUM);
-  }
-  return reduce_scal(m, 0, 4, RED_MAX);
+  int r = reduce_scal(m, SC_RES0, 2 + m->nl, RED_MAX);  // RES0, RES1, UMAX[nl]
+  if (r) return r;
+  return reduce_scal(m, SC_BSUM, 1, RED_SUM);
 }
 
 // mg_solve, mspg/elliptic.h:145-229, called as poisson_layer does (msqg/poisson_layer.h:290-303)
@@ -787,7 +786,8 @@ static int mg_solve(msom *m, const double *b, msom_mgstats *s) {
   const Params &p = m->p;
   const bool fused = m->mg_fused && m->nlev > 1;
   s->i = 0; s->nrelax = 4;
-  HIPCHK(hipMemsetAsync(m->d_scal, 0, 4 * sizeof(double), m->st));
+  HIPCHK(hipMemsetAsync(m->d_scal, 0, 8 * sizeof(double), m->st));
+  m->umax_ready = 0;
   if (fused) {
     residual2(m, 2 | 4, b, SC_RES0, 1);
     launch_sum_final(m->st, m->partial, m->d_scal + SC_BSUM, residual2_blocks(m->g));
@@ -808,8 +808,9 @@ static int mg_solve(msom *m, const double *b, msom_mgstats *s) {
     mg_cycle_levels(m, s->nrelax, fused ? 2 : 1);
     HIPCHK(hipMemsetAsync(m->d_scal + SC_RES1, 0, sizeof(double), m->st));
     if (fused) {
-      residual2(m, 1, b, SC_RES1, 0);            // a_new = a + da -> psi_alt, max |res(a_new)|
+      residual2(m, 1, b, SC_RES1, 0);            // a_new = a + da -> psi_alt, max |res(a_new)|, max |u(a_new)|
       std::swap(m->f[MSOM_PSI], m->psi_alt);
+      m->umax_ready = 1;
       if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], m->nl, m->bc, 1));
     } else {
       launch_correct(m->st, m->f[MSOM_PSI], m->g, m->da[0], m->sg[0], m->nl, m->walls);
@@ -830,7 +831,7 @@ static int mg_solve(msom *m, const double *b, msom_mgstats *s) {
     }
     resb = s->resa;
     // another cycle follows: it needs the residual field of the corrected a on levels 0 and 1
-    if (fused && s->i + 1 < p.nitermax && (s->i + 1 < p.nitermin || s->resa > p.tolerance)) residual2(m, 2 | 4, b, SC_KE, 0);
+    if (fused && s->i + 1 < p.nitermax && (s->i + 1 < p.nitermin || s->resa > p.tolerance)) residual2(m, 2 | 4, b, SC_SCRATCH, 0);
   }
   if (!have_first) {  // nitermax == 0
     int rr = read_residuals(m);
@@ -889,8 +890,8 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
     // tiles: the fused kernel needs psi on a 3-cell halo (zeta on 2, lap(zeta) on 1)
     if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], nl, m->bc, 3));
     // one pass over psi: zeta, Jacobians, beta, dissipation, drag, forcing, max|u| (kernels_fused.hip)
-    launch_rhs_fused(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, m->f[dqfield], m->partial_umax,
-                     m->d_scal + SC_UMAX, m->g, nl, m->walls, m->uniformS, m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe,
+    launch_rhs_fused(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, m->f[dqfield], nullptr,
+                     nullptr, m->g, nl, m->walls, m->uniformS, m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe,
                      iRe4, Eks / (p.Rom * 2 * m->dhf[0]), Ekb / (p.Rom * 2 * m->dhf[nl - 1]),
                      p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, m->rhs_variant, adv_out >= 0 ? m->f[adv_in] : nullptr,
                      adv_out >= 0 ? m->f[adv_out] : nullptr, adv_dt);
@@ -901,7 +902,6 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
   comp_del2(m, MSOM_PSI, MSOM_ZETA, 0., 1.0);
   launch_advection(m->st, m->f[MSOM_ZETA], m->f[MSOM_PSI], m->f[MSOM_PSIPG], m->f[MSOM_ZETAPG], m->f[MSOM_S], m->f[qfield], m->f[dqfield],
                    m->g, nl, m->have_pg, m->have_zpg, m->stochastic, D, p.beta, p.itr_stoch, m->lc);
-  launch_umax(m->st, m->f[MSOM_PSI], m->partial_umax, m->d_scal + SC_UMAX, m->g, nl, D);
   // dissip :407-422 (terms with a zero coefficient add exactly 0 and are skipped)
   if (iRe != 0) comp_stretch(m, MSOM_ZETA, dqfield, 1., iRe);
   if (iRe != 0 || iRe4 != 0) comp_del2(m, MSOM_ZETA, MSOM_TMP, 0., 1.);
@@ -916,20 +916,31 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
   return MSOM_OK;
 }
 
-// update_qg, msqg/qg.h:609-650
-static double update_qg(msom *m, int qfield, int dqfield, double dtmax, int adv_out = -1, int adv_in = -1, double adv_dt = 0.,
-                        int *advanced = nullptr) {
-  const Params &p = m->p;
+// first half of update_qg (msqg/qg.h:621-623): invert q -> psi, then the CFL part of
+// advection_pv (:383-391): 2*nl limiter calls (psi_l then psipg_l) sharing one static
+// `previous`.  max|u| of psi comes out of the solver's last pass (k_residual2<CORRECT>), so dt
+// is known BEFORE the tendency pass and the advance can ride in it.
+static double solve_and_dt(msom *m, int qfield, double dtmax) {
   const int nl = m->nl;
   if (invertq(m, m->f[qfield])) return -1;
-  if (rhs_terms(m, qfield, dqfield, 1, p.iRe, p.iRe4, p.Eks, p.Ekb, adv_out, adv_in, adv_dt, advanced)) return -1;
-  if (reduce_scal(m, SC_UMAX, nl, RED_MAX)) return -1;
+  if (!m->umax_ready) {
+    launch_umax(m->st, m->f[MSOM_PSI], m->partial_umax, m->d_scal + SC_UMAX, m->g, nl, m->p.L0 / m->gnx);
+    if (reduce_scal(m, SC_UMAX, nl, RED_MAX)) return -1;
+  }
   if (m->sticky) return -1;
-  // :383-391: 2*nl limiter calls (psi_l then psipg_l) sharing one static `previous`
   for (int l = 0; l < nl; l++) {
     dtmax = limiter(m, m->h_scal[SC_UMAX + l], dtmax);
     dtmax = limiter(m, m->umax_pg[l], dtmax);
   }
+  return dtmax;
+}
+
+// update_qg, msqg/qg.h:609-650
+static double update_qg(msom *m, int qfield, int dqfield, double dtmax) {
+  const Params &p = m->p;
+  dtmax = solve_and_dt(m, qfield, dtmax);
+  if (dtmax < 0) return -1;
+  if (rhs_terms(m, qfield, dqfield, 1, p.iRe, p.iRe4, p.Eks, p.Ekb)) return -1;
   return dtmax;
 }
 
@@ -1066,7 +1077,7 @@ extern "C" int pystep_bfn(msom_t *m, double *varin_py, int len1, int len2, int l
   if (vartype != 1) HIPCHK(hipMemsetAsync(m->f[MSOM_DQ], 0, m->g.ls * m->nl * sizeof(double), m->st));  // reset_layer_var(bfn_tendl)
   if (vartype == 1) {
     if ((r = upload(m, MSOM_Q, varin_py))) return r;
-    if ((r = invertq(m, m->f[MSOM_Q]))) return r;
+    if (solve_and_dt(m, MSOM_Q, p.DT) < 0) return MSOM_ERR_HIP;  // invertq + the dt limiter inside advection_pv
     if ((r = rhs_terms(m, MSOM_Q, MSOM_DQ, 0, p.iRe, p.iRe4, p.Eks, p.Ekb))) return r;
   } else if (!m->quiet)
     fprintf(stdout, "temporary disabled psi tendency\n");  // msqg/qg_bfn.h:48
@@ -1109,19 +1120,25 @@ static double dtnext(msom *m, double dt, double *tnext_out) {
   return dt;
 }
 
-// one iteration of run() [Basilisk predictor-corrector.h]
+// one iteration of run() [Basilisk predictor-corrector.h]:
+//   dt = dtnext(update(evolving, updates, DT)); advance(predictor, evolving, updates, dt/2);
+//   update(predictor, updates, dt); advance(evolving, evolving, updates, dt)
+// dt is known right after each inversion, so both advances ride in the tendency kernel
+// (q_out = q_in + dt * dq) whenever the fused kernel applies; dq is then never stored.
 extern "C" int msom_step(msom_t *m, double *dt_used) {
   NEED_CONST(m);
+  const Params &p = m->p;
   double tnext;
-  double d = update_qg(m, MSOM_Q, MSOM_DQ, m->p.DT);
-  if (d < 0) return MSOM_ERR_HIP;
+  int r, advanced = 0;
+  const double d = solve_and_dt(m, MSOM_Q, p.DT);
+  if (d < 0) return m->sticky ? m->sticky : MSOM_ERR_HIP;
   m->dt = dtnext(m, d, &tnext);
-  int r;
-  if ((r = advance_qg(m, MSOM_QPRED, MSOM_Q, MSOM_DQ, m->dt / 2.))) return r;
-  // corrector: dt is known, so the advance q += dt * dq rides in the tendency kernel
-  int advanced = 0;
-  if (update_qg(m, MSOM_QPRED, MSOM_DQ, m->dt, MSOM_Q, MSOM_Q, m->dt, &advanced) < 0) return MSOM_ERR_HIP;
+  if ((r = rhs_terms(m, MSOM_Q, MSOM_DQ, 1, p.iRe, p.iRe4, p.Eks, p.Ekb, MSOM_QPRED, MSOM_Q, m->dt / 2., &advanced))) return r;
+  if (!advanced && (r = advance_qg(m, MSOM_QPRED, MSOM_Q, MSOM_DQ, m->dt / 2.))) return r;
+  if (solve_and_dt(m, MSOM_QPRED, m->dt) < 0) return m->sticky ? m->sticky : MSOM_ERR_HIP;
+  if ((r = rhs_terms(m, MSOM_QPRED, MSOM_DQ, 1, p.iRe, p.iRe4, p.Eks, p.Ekb, MSOM_Q, MSOM_Q, m->dt, &advanced))) return r;
   if (!advanced && (r = advance_qg(m, MSOM_Q, MSOM_Q, MSOM_DQ, m->dt))) return r;
+  if ((r = sync_stream(m))) return r;
   m->t = tnext;
   m->iter++;
   if (dt_used) *dt_used = m->dt;
@@ -1323,9 +1340,9 @@ extern "C" int msom_dbg_residual(msom_t *m, const double *a, const double *b, do
   int r;
   if ((r = upload(m, MSOM_TMP, a))) return r;
   if ((r = upload(m, MSOM_QPRED, b))) return r;
-  HIPCHK(hipMemsetAsync(m->d_scal, 0, 4 * sizeof(double), m->st));
+  HIPCHK(hipMemsetAsync(m->d_scal, 0, 8 * sizeof(double), m->st));
   residual(m, m->f[MSOM_TMP], m->f[MSOM_QPRED], SC_RES0, 0);
-  HIPCHK(hipMemcpyAsync(m->h_scal, m->d_scal, sizeof(double), hipMemcpyDeviceToHost, m->st));
+  HIPCHK(hipMemcpyAsync(m->h_scal + SC_RES0, m->d_scal + SC_RES0, sizeof(double), hipMemcpyDeviceToHost, m->st));
   if ((r = split_download(m, m->res[0], m->sg[0], res, m->nl))) return r;
   if (maxres) *maxres = m->h_scal[SC_RES0];
   return MSOM_OK;
