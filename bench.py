@@ -163,6 +163,16 @@ def main():
         launch_bytes = (3.0 + sigma) * w / 2.0
         launch_ms = sweep_ms / 2.0
         achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        kernel = f"k_relax_color_x2<{nl}, {'true' if uniform else 'false'}, true> (finest-level red-black colour half-sweep)"
+        # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+        # collected separately with rocprofv3 --pmc and stored under profiles/
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_relax_fine.json")))
+            if N == 4096 and nl == 6 and uniform and world == 1:
+                traffic = pmc["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "grid-point-updates/s (timesteps/s x N^2 x nl), multi-layer QG RK2 step at 4096^2 x 6L per GPU",
             "value": gnx * gny * nl * args.steps / elapsed,
@@ -185,18 +195,19 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_relax_color<NL,UNIFORM,FINE=true> (finest-level red-black colour half-sweep)",
+                "kernel": kernel,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "avg_launch_ms": launch_ms,
                 "launches_timed": 2 * sweep_n,
-                "residual_kernel": {
+                "residual_kernels": {
                     "avg_launch_ms": resid_ms, "launches_timed": resid_n,
-                    "achieved_GBs": ((3.0 + sigma) * w / (resid_ms * 1e-3) / 1e9) if resid_ms > 0 else 0.0,
+                    "note": "k_residual2<write+restrict> (3.25 w) and k_residual2<correct> (4 w) alternate",
+                    "achieved_GBs": (3.625 * w / (resid_ms * 1e-3) / 1e9) if resid_ms > 0 else 0.0,
                 },
             },
         }
