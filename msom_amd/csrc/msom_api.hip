@@ -14,6 +14,8 @@
 #include <sys/stat.h>
 #include <sys/types.h>
 
+#include <algorithm>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -42,6 +44,7 @@ struct ProfSlot {
 
 struct msom {
   Params p;
+  std::string params_text;  // raw params.in text (backup copy in the output directory)
   // decomposition (single tile unless created with msom_create_tiled)
   int px = 1, py = 1, ix = 0, iy = 0, rank = 0, nranks = 1;
   int gnx = 0, gny = 0;  // global cells
@@ -398,13 +401,23 @@ extern "C" msom_t *msom_create_str(const char *text) {
   Params p;
   msom_params_defaults(&p);
   msom_params_parse_text(&p, text);
-  return create_common(p, 1, 1, 0, nullptr);
+  msom *m = create_common(p, 1, 1, 0, nullptr);
+  if (m) m->params_text = text;
+  return m;
 }
 extern "C" msom_t *msom_create(const char *path) {
-  Params p;
-  msom_params_defaults(&p);
-  if (msom_params_parse_file(&p, path ? path : "params.in")) return nullptr;
-  return create_common(p, 1, 1, 0, nullptr);
+  const char *pp = path ? path : "params.in";
+  FILE *fp = fopen(pp, "rt");
+  if (!fp) {
+    msom_set_error("file %s not found", pp);  // reference: message + exit(0), msqg/qg.h:735-738
+    return nullptr;
+  }
+  std::string text;
+  char buf[4096];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, n);
+  fclose(fp);
+  return msom_create_str(text.c_str());
 }
 
 extern "C" int msom_destroy(msom_t *m) {
@@ -1223,6 +1236,50 @@ extern "C" int msom_read_inputs(msom_t *m, const char *dir) {
   return MSOM_OK;
 }
 
+// backup_config, msqg/qg.h:782-835: params.in copy and the constant fields, written into the
+// output directory at t = 0 (event write_const, msqg/qg.c:95-97)
+static int backup_config(msom *m, const char *dpath) {
+  fprintf(stdout, "Backup config\n");
+  char name[700];
+  const int nl = m->nl, N = m->gnx;
+  const size_t n2 = (size_t)m->nx * m->ny;
+  snprintf(name, sizeof name, "%sparams.in", dpath);
+  if (FILE *fp = fopen(name, "w")) {
+    fwrite(m->params_text.data(), 1, m->params_text.size(), fp);
+    fclose(fp);
+  } else {
+    msom_set_error("cannot write %s", name);
+    return MSOM_ERR_IO;
+  }
+  // sig_filt = min(afilt * Rd, Lfmax) with Rd = 1 (msqg/qg.h:913,1060); Rd itself
+  std::vector<double> h(n2 * nl, 0.);
+  for (size_t k = 0; k < n2; k++) h[k] = fmin(m->p.afilt * 1., m->p.Lfmax);
+  snprintf(name, sizeof name, "%ssig_filt.bas", dpath);
+  if (msom_bas_write(name, h.data(), 1, m->nx, m->p.L0)) return MSOM_ERR_IO;
+  for (size_t k = 0; k < n2; k++) h[k] = 1.;
+  snprintf(name, sizeof name, "%srdpg_%dl_N%d.bas", dpath, nl, N);
+  if (msom_bas_write(name, h.data(), 1, m->nx, m->p.L0)) return MSOM_ERR_IO;
+  int r;
+  snprintf(name, sizeof name, "%spsipg_%dl_N%d.bas", dpath, nl, N);
+  if ((r = msom_write_bas(m, MSOM_PSIPG, name))) return r;
+  // Frl has nl layers in the reference (nl - 1 used, the last one stays 0)
+  std::fill(h.begin(), h.end(), 0.);
+  if (nl > 1 && (r = download(m, MSOM_FR, h.data()))) return r;
+  if (nl == 1) std::fill(h.begin(), h.end(), 0.);
+  snprintf(name, sizeof name, "%sfrpg_%dl_N%d.bas", dpath, nl, N);
+  if (msom_bas_write(name, h.data(), nl, m->nx, m->p.L0)) return MSOM_ERR_IO;
+  snprintf(name, sizeof name, "%sqforc_%dl_N%d.bas", dpath, nl, N);
+  if ((r = msom_write_bas(m, MSOM_QFORC, name))) return r;
+  std::vector<float> dh(nl);
+  for (int l = 0; l < nl; l++) dh[l] = (float)m->dhf[l];
+  snprintf(name, sizeof name, "%sdh_%dl.bin", dpath, nl);
+  if (FILE *fp = fopen(name, "w")) {
+    fwrite(dh.data(), sizeof(float), nl, fp);
+    fclose(fp);
+  }
+  return MSOM_OK;
+}
+
 // main loop of msqg/qg.c:34-173: events at the top of every iteration (writestdout i++,
 // output t += dtout), then one predictor-corrector step.
 extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
@@ -1242,6 +1299,7 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
   double tout = 0.;  // next output event: t = 0; t <= tend + 1e-10; t += dtout
   long steps = 0;
   int r;
+  if (m->iter == 0 && (r = backup_config(m, dpath))) return r;  // event write_const (t = 0)
   for (;;) {
     // writestdout, msqg/qg.c:101-109
     fprintf(stdout, "i = %i, dt = %g, t = %g, ke_1 = %g\n", m->iter, m->dt, m->t, msom_ke(m));
@@ -1289,7 +1347,9 @@ extern "C" msom_t *msom_create_tiled(const char *params_text, int px, int py, in
   Params p;
   msom_params_defaults(&p);
   msom_params_parse_text(&p, params_text);
-  return create_common(p, px, py, rank, id128);
+  msom *m = create_common(p, px, py, rank, id128);
+  if (m) m->params_text = params_text;
+  return m;
 }
 extern "C" int msom_tile_info(msom_t *m, int *px, int *py, int *ix, int *iy, int *nx_local, int *ny_local) {
   if (!m) return MSOM_ERR_ARG;
