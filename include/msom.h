@@ -134,6 +134,15 @@ int msom_run(msom_t *m, const char *workdir, long nsteps_max);
 int msom_write_bas(msom_t *m, int field, const char *path);
 int msom_read_bas(msom_t *m, int field, const char *path);
 
+/* ---- NetCDF-3 classic output / restart (libnetcdf-free): create_nc + write_nc + read_nc of
+ * newqg/netcdf_bas.h:42-244 and qg-node/netcdf_vertex_bas.h:315-424.  msom_write_nc appends one
+ * record (time = t; variables "psi" and "q", all levels, float) to `path`, creating the file
+ * with dims level,y,x,time(UNLIMITED) and coordinate variables time,y,x when it does not exist.
+ * msom_read_nc loads record `record` (-1 = last) of variable `varname` into `field`
+ * (restart: "psi" -> MSOM_PSI, then msom_set_const). */
+int msom_write_nc(msom_t *m, const char *path);
+int msom_read_nc(msom_t *m, int field, const char *path, const char *varname, int record);
+
 /* select the HIP device of the calling thread before msom_create* (one process per GPU:
  * device = LOCAL_RANK) */
 int msom_set_device(int device);

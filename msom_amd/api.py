@@ -70,6 +70,8 @@ def load_library(strict=False):
         "msom_run": (ci, [vp, cs, C.c_long]),
         "msom_write_bas": (ci, [vp, ci, cs]),
         "msom_read_bas": (ci, [vp, ci, cs]),
+        "msom_write_nc": (ci, [vp, cs]),
+        "msom_read_nc": (ci, [vp, ci, cs, cs, ci]),
         "msom_set_device": (ci, [ci]),
         "msom_comm_unique_id": (ci, [vp]),
         "msom_create_tiled": (vp, [cs, ci, ci, ci, vp]),
@@ -253,6 +255,12 @@ class QG:
 
     def read_bas(self, field, path):
         self._chk(self.L.msom_read_bas(self.h, field, path.encode()))
+
+    def write_nc(self, path):
+        self._chk(self.L.msom_write_nc(self.h, path.encode()))
+
+    def read_nc(self, field, path, varname, record=-1):
+        self._chk(self.L.msom_read_nc(self.h, field, path.encode(), varname.encode(), record))
 
     # -- debug hooks
     def nlevels(self):

@@ -1191,6 +1191,28 @@ extern "C" int msom_read_bas(msom_t *m, int field, const char *path) {
   return msom_set_field(m, field, h.data());
 }
 
+extern "C" int msom_write_nc(msom_t *m, const char *path) {
+  if (!m || !path) return MSOM_ERR_ARG;
+  if (m->nranks > 1) { msom_set_error("NetCDF output needs a single-tile grid"); return MSOM_ERR_STATE; }
+  static const char *names[2] = {"psi", "q"};
+  const size_t n = (size_t)m->nl * m->nx * m->ny;
+  std::vector<double> hp(n), hq(n);
+  int r;
+  if ((r = download(m, MSOM_PSI, hp.data())) || (r = download(m, MSOM_Q, hq.data()))) return r;
+  struct stat sb;
+  if (stat(path, &sb) != 0 && msom_nc_create(path, m->nl, m->ny, m->nx, m->p.L0, 2, names)) return MSOM_ERR_IO;
+  const double *f[2] = {hp.data(), hq.data()};
+  return msom_nc_append(path, m->nl, m->ny, m->nx, 2, names, m->t, f) < 0 ? MSOM_ERR_IO : MSOM_OK;
+}
+extern "C" int msom_read_nc(msom_t *m, int field, const char *path, const char *varname, int record) {
+  if (check_field(m, field) || !path || !varname) return MSOM_ERR_ARG;
+  if (m->nranks > 1) { msom_set_error("NetCDF input needs a single-tile grid"); return MSOM_ERR_STATE; }
+  std::vector<double> h((size_t)m->flayers[field] * m->nx * m->ny);
+  int r = msom_nc_read(path, varname, record, m->flayers[field], m->ny, m->nx, h.data(), nullptr);
+  if (r) return r == -2 ? MSOM_ERR_IO : MSOM_ERR_ARG;
+  return msom_set_field(m, field, h.data());
+}
+
 static bool file_exists(const char *path) {
   struct stat sb;
   return stat(path, &sb) == 0;

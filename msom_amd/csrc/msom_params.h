@@ -30,6 +30,11 @@ void msom_params_derive(struct Params *p);
  * `a` is [layer][y][x] fp64, n x n cells per layer. */
 int msom_bas_write(const char *path, const double *a, int nl, int n, double L0);
 int msom_bas_read(const char *path, double *a, int nl, int n, double L0);
+/* netcdf3.c: NetCDF-3 classic writer/reader replacing libnetcdf's create_nc/write_nc/read_nc
+ * (newqg/netcdf_bas.h:42-244, qg-node/netcdf_vertex_bas.h:315-424).  Fields are [level][y][x] fp64. */
+int msom_nc_create(const char *path, int nl, int ny, int nx, double L0, int nvars, const char *const *names);
+int msom_nc_append(const char *path, int nl, int ny, int nx, int nvars, const char *const *names, double time, const double *const *fields);
+int msom_nc_read(const char *path, const char *name, int rec, int nl, int ny, int nx, double *out, double *time_out);
 void msom_set_error(const char *fmt, ...);
 #ifdef __cplusplus
 }
