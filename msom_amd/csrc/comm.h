@@ -28,6 +28,9 @@ double *comm_recvbuf(Comm *c, int dir);
 size_t comm_bufcount(const Comm *c);
 int comm_exchange(Comm *c, const Xfer *x, int nx);
 int comm_allreduce(Comm *c, double *dvals, double *hout, int n, int op);
+int comm_allgather(Comm *c, const double *send, double *recv, size_t count);
+void launch_assemble_global(hipStream_t st, const double *recv, double *g, const SplitGeom &gg, int nl, int tnx, int tny, int px);
+void launch_extract_tile(hipStream_t st, const double *g, const SplitGeom &gg, double *t, const SplitGeom &tg, int nl, int ox, int oy);
 
 void launch_nat_pack_strip(hipStream_t st, const double *f, const NatGeom &g, int nl, int i0, int j0, int w, int h, double *buf);
 void launch_nat_unpack_strip(hipStream_t st, double *f, const NatGeom &g, int nl, int i0, int j0, int w, int h, const double *buf);

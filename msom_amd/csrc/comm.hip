@@ -79,6 +79,7 @@ struct RcclApi {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi g_rccl;
@@ -109,6 +110,7 @@ static int rccl_load() {
   SYM(GroupStart, "ncclGroupStart");
   SYM(GroupEnd, "ncclGroupEnd");
   SYM(AllReduce, "ncclAllReduce");
+  SYM(AllGather, "ncclAllGather");
   SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
   g_rccl.h = h;
@@ -150,6 +152,7 @@ struct LocalHub {
   std::vector<const Xfer *> posted;  // per rank: its message list of the current exchange
   std::vector<int> posted_n;
   std::vector<double> red;           // reduction scratch [rank][n]
+  std::vector<const double *> gsend; // all-gather: every rank's send buffer
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
     int g = gen;
@@ -168,6 +171,7 @@ static LocalHub *hub_get(unsigned long long key, int n) {
   h->n = n;
   h->posted.assign(n, nullptr);
   h->posted_n.assign(n, 0);
+  h->gsend.assign(n, nullptr);
   g_hubs.push_back({key, h});
   return h;
 }
@@ -293,6 +297,45 @@ int comm_allreduce(Comm *c, double *dvals, double *hout, int n, int op) {
     HIPCHKC(hipStreamSynchronize(c->st));
   }
   return MSOM_OK;
+}
+
+// recv[r * count .. (r+1) * count) = rank r's send[0 .. count)   (device buffers)
+int comm_allgather(Comm *c, const double *send, double *recv, size_t count) {
+  if (!c || c->kind == COMM_NONE) return MSOM_OK;
+  if (c->kind == COMM_RCCL) {
+    NCCLCHK(g_rccl.AllGather(send, recv, count, ncclDouble, c->nccl, c->st));
+    return MSOM_OK;
+  }
+  LocalHub *h = c->hub;
+  HIPCHKC(hipStreamSynchronize(c->st));
+  h->gsend[c->rank] = send;
+  h->barrier();
+  for (int r = 0; r < h->n; r++)
+    HIPCHKC(hipMemcpyAsync(recv + (size_t)r * count, h->gsend[r], count * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+  HIPCHKC(hipStreamSynchronize(c->st));
+  h->barrier();
+  return MSOM_OK;
+}
+
+// assemble the gathered tile interiors [rank][l][y][x] into a global split-layout field
+__global__ void k_assemble_global(const double *__restrict__ recv, double *g, SplitGeom gg, int nl, int tnx, int tny, int px) {
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x, gj = blockIdx.y;
+  if (gi >= gg.nx || gj >= gg.ny) return;
+  const int r = (gj / tny) * px + gi / tnx, i = gi % tnx, j = gj % tny;
+  const size_t tile = (size_t)nl * tnx * tny;
+  for (int l = 0; l < nl; l++) g[split_idx(gg, l, gj, gi)] = recv[(size_t)r * tile + ((size_t)l * tny + j) * tnx + i];
+}
+void launch_assemble_global(hipStream_t st, const double *recv, double *g, const SplitGeom &gg, int nl, int tnx, int tny, int px) {
+  hipLaunchKernelGGL(k_assemble_global, dim3((gg.nx + 63) / 64, gg.ny), dim3(64), 0, st, recv, g, gg, nl, tnx, tny, px);
+}
+// tile (ix, iy) of a global split field, with its ghost ring (walls or neighbours' cells), -> tile field
+__global__ void k_extract_tile(const double *__restrict__ g, SplitGeom gg, double *t, SplitGeom tg, int nl, int ox, int oy) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1, j = (int)blockIdx.y - 1;
+  if (i > tg.nx || j > tg.ny) return;
+  for (int l = 0; l < nl; l++) t[split_idx(tg, l, j, i)] = g[split_idx(gg, l, oy + j, ox + i)];
+}
+void launch_extract_tile(hipStream_t st, const double *g, const SplitGeom &gg, double *t, const SplitGeom &tg, int nl, int ox, int oy) {
+  hipLaunchKernelGGL(k_extract_tile, dim3((tg.nx + 2 + 63) / 64, tg.ny + 2), dim3(64), 0, st, g, gg, t, tg, nl, ox, oy);
 }
 
 // ------------------------------------------------------------------ strip launchers

@@ -69,6 +69,11 @@ struct msom {
   std::vector<double *> da, da_alt, res, S;
   std::vector<RelaxCoef> rc;
   size_t max_split = 0;
+  // agglomerated coarse levels (tiled mode): levels >= agg_level live on the gathered global grid
+  int agg_level = -1, agglomerate = 1, agg_size = 64;
+  std::vector<SplitGeom> gsg;
+  std::vector<double *> gda, gda_alt, gres;
+  double *agg_send = nullptr, *agg_recv = nullptr;
   // scratch
   double *staging = nullptr;   // contiguous nl*ny*nx
   double *partial = nullptr;   // per-block partial sums
@@ -98,6 +103,8 @@ struct msom {
   int profile = 0;
   ProfSlot prof_sweep, prof_resid, prof_block;
 };
+
+static void free_agglomeration(msom *m);
 
 extern "C" const char *msom_version(void) {
 #ifdef MSOM_STRICT
@@ -431,6 +438,7 @@ extern "C" int msom_destroy(msom_t *m) {
     if (m->res[k]) hipFree(m->res[k]);
     if (m->S[k]) hipFree(m->S[k]);
   }
+  free_agglomeration(m);
   if (m->psi_alt) hipFree(m->psi_alt);
   if (m->staging) hipFree(m->staging);
   if (m->partial) hipFree(m->partial);
@@ -447,6 +455,7 @@ extern "C" int msom_destroy(msom_t *m) {
 }
 
 static int build_coefs(msom *m);
+static void free_agglomeration(msom *m);
 
 extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   if (!m || !key) return MSOM_ERR_ARG;
@@ -464,6 +473,8 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "fused")) m->fused = (int)v;
   else if (!strcmp(key, "mg_fused")) m->mg_fused = (int)v;
   else if (!strcmp(key, "block_sweeps")) m->block_sweeps = (int)v;
+  else if (!strcmp(key, "agglomerate")) { m->agglomerate = (int)v; if (m->const_set) return build_coefs(m); }
+  else if (!strcmp(key, "agg_size")) { m->agg_size = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "prolong_fused")) m->prolong_fused = (int)v;
   else if (!strcmp(key, "block_variant")) { extern int g_block_variant; g_block_variant = (int)v; }
   else if (!strcmp(key, "rhs_variant")) m->rhs_variant = (int)v;
@@ -507,6 +518,7 @@ extern "C" double msom_get_param(msom_t *m, const char *key) {
   if (!strcmp(key, "TOLERANCE")) return p.tolerance;
   if (!strcmp(key, "nlevels")) return m->nlev;
   if (!strcmp(key, "uniform_S")) return m->uniformS;
+  if (!strcmp(key, "agg_level")) return m->agg_level;
   if (!strncmp(key, "idh0_", 5)) return m->lc.idh0[atoi(key + 5) % MSOM_MAXNL];
   if (!strncmp(key, "idh1_", 5)) return m->lc.idh1[atoi(key + 5) % MSOM_MAXNL];
   if (!strncmp(key, "Fr_", 3)) return p.Frm[atoi(key + 3) % MSOM_MAXARR];
@@ -613,6 +625,45 @@ static void make_relax_coef(msom *m, int k) {
   }
 }
 
+static void free_agglomeration(msom *m) {
+  for (auto *v : {&m->gda, &m->gda_alt, &m->gres}) {
+    for (double *p : *v)
+      if (p) hipFree(p);
+    v->clear();
+  }
+  m->gsg.clear();
+  if (m->agg_send) hipFree(m->agg_send);
+  if (m->agg_recv) hipFree(m->agg_recv);
+  m->agg_send = m->agg_recv = nullptr;
+  m->agg_level = -1;
+}
+static int setup_agglomeration(msom *m) {
+  hipStreamSynchronize(m->st);
+  free_agglomeration(m);
+  if (m->nranks == 1 || !m->agglomerate || (m->nl > 1 && !m->uniformS)) return MSOM_OK;
+  int kc = -1;
+  for (int k = 0; k < m->nlev; k++)
+    if (m->sg[k].nx <= m->agg_size && m->sg[k].ny <= m->agg_size) { kc = k; break; }
+  if (kc < 0) return MSOM_OK;
+  const int n = m->nlev - kc;
+  m->gsg.resize(n); m->gda.assign(n, nullptr); m->gda_alt.assign(n, nullptr); m->gres.assign(n, nullptr);
+  for (int q = 0; q < n; q++) {
+    m->gsg[q] = make_split(m->sg[kc + q].nx * m->px, m->sg[kc + q].ny * m->py);
+    const size_t bytes = m->gsg[q].ls * m->nl * sizeof(double);
+    HIPCHK(hipMalloc(&m->gda[q], bytes));
+    HIPCHK(hipMalloc(&m->gda_alt[q], bytes));
+    HIPCHK(hipMalloc(&m->gres[q], bytes));
+    HIPCHK(hipMemsetAsync(m->gda[q], 0, bytes, m->st));
+    HIPCHK(hipMemsetAsync(m->gda_alt[q], 0, bytes, m->st));
+    HIPCHK(hipMemsetAsync(m->gres[q], 0, bytes, m->st));
+  }
+  const size_t cnt = (size_t)m->nl * m->sg[kc].nx * m->sg[kc].ny;
+  HIPCHK(hipMalloc(&m->agg_send, cnt * sizeof(double)));
+  HIPCHK(hipMalloc(&m->agg_recv, cnt * m->nranks * sizeof(double)));
+  m->agg_level = kc;
+  return MSOM_OK;
+}
+
 // layer metrics, Ro, S on all levels, column-solver constants, forcing profile
 static int build_coefs(msom *m) {
   const Params &p = m->p;
@@ -665,6 +716,12 @@ static int build_coefs(msom *m) {
 #endif
   m->uniformS = (m->uniform_opt < 0 ? auto_uniform : m->uniform_opt) && m->fr_uniform && nl > 1;
   for (int k = 0; k < m->nlev; k++) make_relax_coef(m, k);
+  // coarse-level agglomeration (tiles): from the first level whose tile is <= agg_size cells
+  // wide, every rank holds the whole coarse grid
+  {
+    int r = setup_agglomeration(m);
+    if (r) return r;
+  }
   // surface forcing profile :451 (host libm so that it matches the CPU formulation bit for bit)
   {
     std::vector<double> w(m->ny);
@@ -709,61 +766,110 @@ extern "C" int msom_set_const(msom_t *m) {
 
 // ------------------------------------------------------------------ elliptic solver
 
-// can level k use the temporally blocked smoother (k_relax_block: 2 sweeps per pass)?
-static bool block_ok(msom *m, int k) {
-  return m->block_sweeps && m->uniformS && m->nranks == 1 && m->sg[k].nx >= 64 && m->sg[k].ny >= 16;
+// One multigrid level as the smoother sees it: either this rank's tile of level k (halo
+// exchange with the neighbour tiles after every colour) or, below the agglomeration level, the
+// whole coarse grid gathered on every rank (walls only, no communication).
+struct Lev {
+  double **da, **da_alt;
+  double *res;
+  const double *S;
+  const SplitGeom *sg;
+  const RelaxCoef *rc;
+  int walls;
+  bool tiled;   // needs halo exchanges
+  bool fine;    // level 0 (profiling tag)
+};
+static Lev tile_lev(msom *m, int k) {
+  return Lev{&m->da[k], &m->da_alt[k], m->res[k], m->S[k], &m->sg[k], &m->rc[k], m->walls, m->nranks > 1, k == 0};
+}
+static Lev glob_lev(msom *m, int k) {
+  const int q = k - m->agg_level;
+  return Lev{&m->gda[q], &m->gda_alt[q], m->gres[q], nullptr, &m->gsg[q], &m->rc[k], WALL_ALL, false, false};
 }
 
-// is the prolongation da[k+1] -> da[k] folded into the first smoothing pass of level k?
-static bool fuse_prolong(msom *m, int k, int nrelax) {
-  if (block_ok(m, k) && nrelax >= 2) return true;
-  return m->prolong_fused && nrelax >= 1 && m->sg[k].nx >= 4 && m->sg[k].ny >= 4;
+// can the level use the temporally blocked smoother (k_relax_block: 2 sweeps per pass)?
+static bool block_ok(msom *m, const Lev &L) {
+  return m->block_sweeps && m->uniformS && !L.tiled && L.sg->nx >= 64 && L.sg->ny >= 16;
+}
+// is the prolongation coarse -> L folded into the first smoothing pass of L?
+static bool fuse_prolong(msom *m, const Lev &L, int nrelax) {
+  if (block_ok(m, L) && nrelax >= 2) return true;
+  return m->prolong_fused && nrelax >= 1 && L.sg->nx >= 4 && L.sg->ny >= 4;
 }
 
-// nrelax red-black relaxations of da[k] against res[k] (each followed by boundary_level).
-// from_coarse: da[k] has not been prolongated yet -- the first blocked pass interpolates it
-// from da[k+1] on the fly.
-static void relax_sweeps(msom *m, int k, int nrelax, int last_level_exchange_corners = 0, bool from_coarse = false) {
-  const bool prof = m->profile && k == 0;
+// nrelax red-black relaxations of L.da against L.res (each followed by boundary_level).
+// coarse != nullptr: L.da has not been prolongated yet -- the first pass interpolates it from
+// the coarser level on the fly.  corners_last: the last exchange also carries corner ghosts.
+static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int corners_last) {
+  const bool prof = m->profile && L.fine;
+  const int nl = m->nl;
   int it = 0;
-  if (block_ok(m, k)) {
+  if (block_ok(m, L)) {
     for (; it + 2 <= nrelax; it += 2) {
-      const bool pl = from_coarse && it == 0;
+      const bool pl = coarse && it == 0;
       if (prof && !pl) prof_begin(m, m->prof_block);
-      launch_relax_block2(m->st, m->da[k], pl ? m->da[k + 1] : nullptr, m->sg[pl ? k + 1 : k], m->res[k], m->da_alt[k], m->sg[k], m->nl, m->rc[k],
-                          m->walls, k == 0);
+      launch_relax_block2(m->st, *L.da, pl ? *coarse->da : nullptr, pl ? *coarse->sg : *L.sg, L.res, *L.da_alt, *L.sg, nl, *L.rc, L.walls, L.fine);
       if (prof && !pl) prof_end(m, m->prof_block);
-      std::swap(m->da[k], m->da_alt[k]);
+      std::swap(*L.da, *L.da_alt);
     }
   }
   for (; it < nrelax; it++) {
-    const bool pl = from_coarse && it == 0;  // prolongation rides in the first red half-sweep
+    const bool pl = coarse && it == 0;  // prolongation rides in the first red half-sweep
     if (prof && !pl) prof_begin(m, m->prof_sweep);
     for (int c = 0; c < 2; c++) {
       if (pl && c == 0)
-        launch_relax_red_prolong(m->st, m->da[k], m->da[k + 1], m->sg[k + 1], m->res[k], m->S[k], m->sg[k], m->nl, m->rc[k], m->uniformS, m->walls);
+        launch_relax_red_prolong(m->st, *L.da, *coarse->da, *coarse->sg, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, L.walls);
       else
-        launch_relax_color(m->st, m->da[k], m->res[k], m->S[k], m->sg[k], m->nl, m->rc[k], m->uniformS, c, m->walls, k == 0);
+        launch_relax_color(m->st, *L.da, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, c, L.walls, L.fine);
       // boundary_level(da, l): the last exchange of the level also carries the corner ghosts
       // that the bilinear prolongation to the next finer level reads
-      STICKY(m, exch_split(m, m->da[k], m->sg[k], m->nl, last_level_exchange_corners && it == nrelax - 1 && c == 1));
+      if (L.tiled) STICKY(m, exch_split(m, *L.da, *L.sg, nl, corners_last && it == nrelax - 1 && c == 1));
     }
     if (prof && !pl) prof_end(m, m->prof_sweep);
   }
 }
 
+// one level of the coarse-to-fine half of mg_cycle: initial guess (zero / prolongation), then
+// the relaxations
+static void level_solve(msom *m, Lev &L, const Lev *coarse, int nrelax, int corners_last) {
+  const int nl = m->nl;
+  bool fused = false;
+  if (!coarse) hipMemsetAsync(*L.da, 0, L.sg->ls * nl * sizeof(double), m->st);
+  else if (fuse_prolong(m, L, nrelax)) fused = true;
+  else {
+    launch_prolong(m->st, *coarse->da, *coarse->sg, *L.da, *L.sg, nl, L.walls);
+    if (L.tiled) STICKY(m, exch_split(m, *L.da, *L.sg, nl, 0));
+  }
+  relax_sweeps(m, L, fused ? coarse : nullptr, nrelax, corners_last);
+}
+
 // coarse-to-fine part of mg_cycle, mspg/elliptic.h:53-89 (minlevel = 1): restriction of the
 // residual to all levels (level 1 may already come out of the fused residual kernel), then
-// prolongation + nrelax relaxations per level
+// prolongation + nrelax relaxations per level.  With tiles, the levels >= agg_level are solved
+// on the gathered global coarse grid by every rank (identical arithmetic, no halo traffic).
 static void mg_cycle_levels(msom *m, int nrelax, int first_restrict) {
-  for (int k = first_restrict; k < m->nlev; k++) launch_restrict(m->st, m->res[k - 1], m->sg[k - 1], m->res[k], m->sg[k], m->nl);
-  for (int k = m->nlev - 1; k >= 0; k--) {
-    if (k == m->nlev - 1) hipMemsetAsync(m->da[k], 0, m->sg[k].ls * m->nl * sizeof(double), m->st);
-    else if (!fuse_prolong(m, k, nrelax)) {
-      launch_prolong(m->st, m->da[k + 1], m->sg[k + 1], m->da[k], m->sg[k], m->nl, m->walls);
-      STICKY(m, exch_split(m, m->da[k], m->sg[k], m->nl, 0));
+  const int nl = m->nl, kc = m->agg_level >= 0 ? m->agg_level : m->nlev;
+  for (int k = first_restrict; k < m->nlev && k <= kc; k++) launch_restrict(m->st, m->res[k - 1], m->sg[k - 1], m->res[k], m->sg[k], nl);
+  if (kc < m->nlev) {
+    // gather the level-kc residual of all tiles, restrict it further on the global grid
+    const SplitGeom &tg = m->sg[kc];
+    const size_t cnt = (size_t)nl * tg.nx * tg.ny;
+    launch_split_unpack(m->st, m->res[kc], tg, m->agg_send, nl);
+    STICKY(m, comm_allgather(m->comm, m->agg_send, m->agg_recv, cnt));
+    launch_assemble_global(m->st, m->agg_recv, m->gres[0], m->gsg[0], nl, tg.nx, tg.ny, m->px);
+    for (int k = kc + 1; k < m->nlev; k++) launch_restrict(m->st, m->gres[k - 1 - kc], m->gsg[k - 1 - kc], m->gres[k - kc], m->gsg[k - kc], nl);
+    for (int k = m->nlev - 1; k >= kc; k--) {
+      Lev L = glob_lev(m, k);
+      if (k == m->nlev - 1) level_solve(m, L, nullptr, nrelax, 0);
+      else { Lev C = glob_lev(m, k + 1); level_solve(m, L, &C, nrelax, 0); }
     }
-    relax_sweeps(m, k, nrelax, k > 0, k < m->nlev - 1 && fuse_prolong(m, k, nrelax));
+    // this rank's tile of the level-kc correction, with its ghost ring
+    launch_extract_tile(m->st, m->gda[0], m->gsg[0], m->da[kc], tg, nl, m->ix * tg.nx, m->iy * tg.ny);
+  }
+  for (int k = (kc < m->nlev ? kc : m->nlev) - 1; k >= 0; k--) {
+    Lev L = tile_lev(m, k);
+    if (k == m->nlev - 1) level_solve(m, L, nullptr, nrelax, k > 0);
+    else { Lev C = tile_lev(m, k + 1); level_solve(m, L, &C, nrelax, k > 0); }
   }
 }
 
@@ -1413,7 +1519,10 @@ extern "C" int msom_dbg_relax(msom_t *m, int lev, double *da, const double *res,
   STICKY(m, exch_split(m, m->da[lev], m->sg[lev], m->nl, 0));
   const int prof = m->profile;
   m->profile = 0;
-  relax_sweeps(m, lev, nsweeps);
+  {
+    Lev L = tile_lev(m, lev);
+    relax_sweeps(m, L, nullptr, nsweeps, 0);
+  }
   m->profile = prof;
   return split_download(m, m->da[lev], m->sg[lev], da, m->nl);
 }

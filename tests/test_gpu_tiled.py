@@ -15,7 +15,7 @@ from msom_amd import QG, FIELDS as F
 pytestmark = pytest.mark.gpu
 
 
-def run_tiled(params, px, py, psi, nsteps, strict, fn=None):
+def run_tiled(params, px, py, psi, nsteps, strict, fn=None, opts=None):
     n = px * py
     uid = b"MSOMLOCL" + os.urandom(8) + bytes(112)
     nl, gny, gnx = psi.shape
@@ -26,13 +26,15 @@ def run_tiled(params, px, py, psi, nsteps, strict, fn=None):
         try:
             g = QG(params, strict=strict, tiled=(px, py, rank, uid))
             g.option("quiet", 1)
+            for k_, v_ in (opts or {}).items():
+                g.option(k_, v_)
             ix, iy = rank % px, rank // px
             assert g.tile == (px, py, ix, iy) and (g.nx, g.ny) == (tx, ty)
             g.set(F["PSI"], psi[:, iy * ty:(iy + 1) * ty, ix * tx:(ix + 1) * tx])
             g.set_const()
             g.set_tnext(float("inf"))
             dts = [g.step() for _ in range(nsteps)]
-            res = dict(q=g.get(F["Q"]), psi=g.get(F["PSI"]), ke=g.ke(), t=g.t, dts=dts, st=g.mgstats())
+            res = dict(q=g.get(F["Q"]), psi=g.get(F["PSI"]), ke=g.ke(), t=g.t, dts=dts, st=g.mgstats(), agg=g.param("agg_level"))
             if fn:
                 res["extra"] = fn(g, rank)
             out[rank] = res
@@ -137,3 +139,35 @@ def test_rccl_library_resolves():
     assert L.msom_comm_unique_id(buf) == 0, L.msom_last_error()
     assert any(b != 0 for b in buf.raw)
     assert L.msom_set_device(0) == 0
+
+
+@pytest.mark.parametrize("px,py,tile,nl", [(2, 2, 32, 3), (2, 4, 16, 6), (2, 1, 64, 2)])
+@pytest.mark.parametrize("agg_size,expect_level", [(64, 0), (8, None), (0, -1)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_coarse_level_agglomeration_is_bit_identical(px, py, tile, nl, agg_size, expect_level, strict):
+    """Below the agglomeration level every rank solves the gathered global coarse grid instead of
+    exchanging halos after every colour: same arithmetic, so the result must not change by a bit
+    -- whether all levels (agg_size 64), only the coarse ones (8) or none (0) are agglomerated."""
+    gnx, gny = tile * px, tile * py
+    levels = int(np.log2(tile))
+    params = orc.double_gyre_params(gnx, nl, extra=(f"Ny = {gny}\n" if gny != gnx else "") + f"MGLEVELS = {levels}\nTOLERANCE = 1e-9\n")
+    psi = orc.synthetic_psi(nl, gny, gnx)
+    opts = {"agg_size": agg_size, "uniform_S": 1}
+    out = run_tiled(params, px, py, psi, nsteps=3, strict=strict, opts=opts)
+    lev = out[0]["agg"]
+    if expect_level is None:
+        assert 0 < lev < levels
+    else:
+        assert lev == expect_level
+    g = QG(params, strict=strict)
+    g.option("quiet", 1)
+    g.option("uniform_S", 1)
+    g.set(F["PSI"], psi)
+    g.set_const()
+    g.set_tnext(float("inf"))
+    for _ in range(3):
+        g.step()
+    assert g.mgstats().i > 1            # several cycles per solve at this tolerance
+    assert out[0]["st"].i == g.mgstats().i and out[0]["st"].resa == g.mgstats().resa
+    assert np.array_equal(assemble(out, "q", px, py), g.get(F["Q"]))
+    assert np.array_equal(assemble(out, "psi", px, py), g.get(F["PSI"]))
