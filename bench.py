@@ -211,7 +211,7 @@ def main():
                 },
             },
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # CPU baseline: rank 0 at N = 1 only
             g.close()
             out["cpu_baseline"] = cpu_baseline(nl, n_cpu=args.cpu_n)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -71,6 +71,7 @@ struct msom {
   size_t max_split = 0;
   // agglomerated coarse levels (tiled mode): levels >= agg_level live on the gathered global grid
   int agg_level = -1, agglomerate = 1, agg_size = 64;
+  int mg_global_sum = 0;
   std::vector<SplitGeom> gsg;
   std::vector<double *> gda, gda_alt, gres;
   double *agg_send = nullptr, *agg_recv = nullptr;
@@ -473,6 +474,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "fused")) m->fused = (int)v;
   else if (!strcmp(key, "mg_fused")) m->mg_fused = (int)v;
   else if (!strcmp(key, "block_sweeps")) m->block_sweeps = (int)v;
+  else if (!strcmp(key, "mg_global_sum")) m->mg_global_sum = (int)v;
   else if (!strcmp(key, "agglomerate")) { m->agglomerate = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "agg_size")) { m->agg_size = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "prolong_fused")) m->prolong_fused = (int)v;
@@ -892,6 +894,13 @@ static void residual2(msom *m, int mode, const double *b, int slot, int want_sum
 static int read_residuals(msom *m) {
   int r = reduce_scal(m, SC_RES0, 2 + m->nl, RED_MAX);  // RES0, RES1, UMAX[nl]
   if (r) return r;
+  // mgstats.sum is informational (the reference never prints it, msqg/qg.h:61): with tiles it
+  // stays the local tile's sum unless "mg_global_sum" asks for the extra all-reduce
+  if (m->nranks > 1 && !m->mg_global_sum) {
+    HIPCHK(hipMemcpyAsync(m->h_scal + SC_BSUM, m->d_scal + SC_BSUM, sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    return MSOM_OK;
+  }
   return reduce_scal(m, SC_BSUM, 1, RED_SUM);
 }
 
