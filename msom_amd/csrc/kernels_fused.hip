@@ -36,6 +36,7 @@ struct RhsArgs {
   const double *psi, *S, *qforc, *wind, *q_in;
   double *dq, *umax_partial, *q_out;  // q_out != 0: advance fused, q_out = q_in + dt * dq (msqg/qg.h:602), dq not stored
   double dt;
+  int dbg;  // timing experiments only (tools/bench_kernels.py): 1 skip lap passes, 2 skip centre loop, 4 skip psi fetch
   NatGeom g;
   int nl, walls, uniformS, have_qforc;
   double D, beta, iRe, iRe4, cs, cb, slip_c;
@@ -210,15 +211,16 @@ __global__ void __launch_bounds__(FNT, MINW) k_rhs_fused(RhsArgs a) {
     // psi_{l+1} -> LDS (its buffer was last read as P0 of layer l-1, before the closing barrier
     // of that iteration); then start the global loads of psi_{l+2}, hidden behind this layer
     if (l + 1 < nl) stash(sP[(l + 1) & 1]);
-    if (l + 2 < nl) fetch(l + 2);
+    if (l + 2 < nl && !(a.dbg & 4)) fetch(l + 2);
     __syncthreads();
-    lds_lap<ZW, ZH, 2, PW, 3, FNT>(sZ, P0, bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);   // zeta_l
+    if (!(a.dbg & 1)) lds_lap<ZW, ZH, 2, PW, 3, FNT>(sZ, P0, bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);   // zeta_l
     __syncthreads();
-    lds_lap<TW, TH, 1, ZW, 2, FNT>(sT, sZ, bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);   // tmp_l = lap(zeta_l)
+    if (!(a.dbg & 1)) lds_lap<TW, TH, 1, ZW, 2, FNT>(sT, sZ, bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);   // tmp_l = lap(zeta_l)
     __syncthreads();
     // centre points: RPT consecutive rows per thread, 3x3 windows slide down the column
     double um = 0.;
     double p[3][3], z[3][3], p1[3][3], tcol[3];
+    if (!(a.dbg & 2)) {
 #pragma unroll
     for (int b = 0; b < 2; b++) {
 #pragma unroll
@@ -266,6 +268,7 @@ __global__ void __launch_bounds__(FNT, MINW) k_rhs_fused(RhsArgs a) {
       t_prev[k] = t; lapT_prev[k] = lapT; jd_prev[k] = jd;
       zc0[k] = zc1[k]; zc1[k] = zc; tc0[k] = tc1[k]; tc1[k] = tc;
     }
+    }
     // per-wave maximum of |u| of this layer
     um = wave_max_f(um);
     if ((tid & 63) == 0) sM[tid >> 6][l] = um;
@@ -292,6 +295,170 @@ __global__ void k_max_final2(const double *partial, double *out, int nb, int nl)
   if (threadIdx.x == 0) out[l] = sm[0];
 }
 
+// ------------------------------------------------------------------ software-pipelined variant
+//
+// Same arithmetic as k_rhs_fused, different schedule.  Measured on MI355X the phases of
+// k_rhs_fused do not overlap (fetch 0.15 + lap passes 0.45 + centre 0.75 + barriers 0.25 ms at
+// 4096^2 x 6): with one 8-wave workgroup per CU every barrier-delimited phase is either
+// latency-bound (the LDS lap passes) or fp64-issue-bound (the centre loop).  Here the lap passes
+// of layer l+1 run in the same barrier interval as the centre loop of layer l (double-buffered
+// zeta / tmp tiles, three psi buffers), and the two waves that share a SIMD take the two jobs
+// in opposite order (waves 0-3: pass first, waves 4-7: centre first), so a SIMD always has one
+// wave waiting on LDS and one issuing fp64 work.  2 barriers per layer instead of 4.
+template <int FTY, int FNT>
+__global__ void __launch_bounds__(FNT, 2) k_rhs_fused_pipe(RhsArgs a) {
+  constexpr int RPT = FTX * FTY / FNT, HALF = RPT / 2;
+  constexpr int PH = FTY + 6, ZH = FTY + 4, TH = FTY + 2;
+  __shared__ double sP[3][PW * PH];
+  __shared__ double sZ[2][ZW * ZH];
+  __shared__ double sT[2][TW * TH];
+
+  const int tid = threadIdx.x, tx = tid & (FTX - 1), ly0 = (tid / FTX) * RPT;
+  const int x0 = blockIdx.x * FTX, y0 = blockIdx.y * FTY;
+  const int nx = a.g.nx, ny = a.g.ny, nl = a.nl, pitch = a.g.pitch;
+  const double D = a.D, D2 = D * D, rD2 = 1. / D2, D12 = 12. * D * D, rD12 = 1. / D12, D2x = 2 * D, rD2x = 1. / D2x;
+  const int gi = x0 + tx;
+  const bool late = tid >= FNT / 2;  // second wave of each SIMD: centre first, pass second
+
+  double t_prev[RPT], lapT_prev[RPT], zc0[RPT], zc1[RPT], tc0[RPT], tc1[RPT], jd_prev[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; k++) t_prev[k] = lapT_prev[k] = zc0[k] = zc1[k] = tc0[k] = tc1[k] = jd_prev[k] = 0.;
+
+  constexpr int NW = FNT / 64, NR = (PH + NW - 1) / NW, NE = (6 * PH + FNT - 1) / FNT;
+  const int lane = tid & 63, wv = tid >> 6;
+  const bool whole = x0 + FTX + 3 <= nx + 3 && y0 + FTY + 3 <= ny + 3;
+  double pf[NR + NE];
+  auto fetch = [&](int l) {
+    const double *p = a.psi + (size_t)l * a.g.ls + (ptrdiff_t)(y0 - 3 + MSOM_YP) * pitch + (x0 - 3 + MSOM_XP);
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      const int lj = wv + r * NW;
+      pf[r] = (lj < PH && (whole || (x0 + lane - 3 < nx + 3 && y0 + lj - 3 < ny + 3))) ? p[(ptrdiff_t)lj * pitch + lane] : 0.;
+    }
+#pragma unroll
+    for (int r = 0; r < NE; r++) {
+      const int e = tid + r * FNT, lj = e / 6, li = 64 + e % 6;
+      pf[NR + r] = (e < 6 * PH && (whole || (x0 + li - 3 < nx + 3 && y0 + lj - 3 < ny + 3))) ? p[(ptrdiff_t)lj * pitch + li] : 0.;
+    }
+  };
+  auto stash = [&](double *dst) {
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      const int lj = wv + r * NW;
+      if (lj < PH) dst[lj * PW + lane] = pf[r];
+    }
+#pragma unroll
+    for (int r = 0; r < NE; r++) {
+      const int e = tid + r * FNT;
+      if (e < 6 * PH) dst[(e / 6) * PW + 64 + e % 6] = pf[NR + r];
+    }
+  };
+  auto finalize = [&](int l, int gj, double t, double lapT, double zm, double zc, double zp, double tm, double tc, double tp) {
+    double dq = t;
+    const size_t c = nat_idx(a.g, l, gj, gi);
+    double s0 = 0., s1 = 0.;
+    if (nl > 1) {
+      if (l > 0) s0 = a.uniformS ? a.Su[l - 1] : a.S[c - a.g.ls];
+      if (l < nl - 1) s1 = a.uniformS ? a.Su[l] : a.S[c];
+    }
+    auto stretch = [&](double fac, double pm, double pc, double pp) -> double {
+      if (l == 0) return fac * s1 * (pp - pc) * a.lc.idh1[l];
+      if (l < nl - 1) return fac * (s0 * (pm - pc) * a.lc.idh0[l] + s1 * (pp - pc) * a.lc.idh1[l]);
+      return fac * s0 * (pm - pc) * a.lc.idh0[l];
+    };
+    if (a.iRe != 0.) {
+      if (nl > 1) dq = 1. * dq + stretch(a.iRe, zm, zc, zp);
+      dq += tc * a.iRe;
+    }
+    if (a.iRe4 != 0.) {
+      if (nl > 1) dq = 1. * dq + stretch(a.iRe4, tm, tc, tp);
+      dq = 1. * dq + a.iRe4 * lapT;
+    }
+    if (l == 0) dq -= a.cs * zc;
+    if (l == nl - 1) dq -= a.cb * zc;
+    if (l == 0) dq -= a.wind[gj];
+    if (a.have_qforc) dq += a.qforc[c];
+    if (a.q_out) a.q_out[c] = a.q_in[c] + dq * a.dt;
+    else a.dq[c] = dq;
+  };
+  // centre rows [k0, k0 + HALF) of layer l
+  auto centre = [&](int l, int k0, const double *P0, const double *P1, const double *Z, const double *T) {
+    double p[3][3], z[3][3], p1[3][3], tcol[3];
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        p[b + 1][c] = P0[(ly0 + k0 + 2 + b) * PW + (tx + 2 + c)];
+        z[b + 1][c] = Z[(ly0 + k0 + 1 + b) * ZW + (tx + 1 + c)];
+        p1[b + 1][c] = P1[(ly0 + k0 + 2 + b) * PW + (tx + 2 + c)];
+      }
+      tcol[b + 1] = T[(ly0 + k0 + b) * TW + (tx + 1)];
+    }
+#pragma unroll
+    for (int kk = 0; kk < HALF; kk++) {
+      const int k = k0 + kk, ly = ly0 + k, gj = y0 + ly;
+      const bool in = gi < nx && gj < ny;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        p[0][c] = p[1][c]; p[1][c] = p[2][c]; p[2][c] = P0[(ly + 4) * PW + (tx + 2 + c)];
+        z[0][c] = z[1][c]; z[1][c] = z[2][c]; z[2][c] = Z[(ly + 3) * ZW + (tx + 1 + c)];
+        p1[0][c] = p1[1][c]; p1[1][c] = p1[2][c]; p1[2][c] = P1[(ly + 4) * PW + (tx + 2 + c)];
+      }
+      tcol[0] = tcol[1]; tcol[1] = tcol[2]; tcol[2] = T[(ly + 2) * TW + (tx + 1)];
+      const double adv = mjac9(p, z, D12, rD12);
+      const double be = DIVC(a.beta * (p[1][0] - p[1][2]), D2x, rD2x);
+      const double jd = l + 1 < nl ? mjac9(p, p1, D12, rD12) : 0.;
+      const double ju = -jd_prev[k];
+      double t = adv + be;
+      if (in && nl > 1) {
+        const size_t c = nat_idx(a.g, l, gj, gi);
+        if (l > 0) t = t + (a.uniformS ? a.Su[l - 1] : a.S[c - a.g.ls]) * ju * a.lc.idh0[l];
+        if (l < nl - 1) t = t + (a.uniformS ? a.Su[l] : a.S[c]) * jd * a.lc.idh1[l];
+      }
+      t = 0. + t;
+      const double zc = z[1][1], tc = tcol[1];
+      const int ct = (ly + 1) * TW + (tx + 1);
+      const double lapT = DIVC(T[ct + 1] + T[ct - 1] + tcol[2] + tcol[0] - 4 * tc, D2, rD2);
+      if (in && l > 0) finalize(l - 1, gj, t_prev[k], lapT_prev[k], zc0[k], zc1[k], zc, tc0[k], tc1[k], tc);
+      if (in && l == nl - 1) finalize(l, gj, t, lapT, zc1[k], zc, 0., tc1[k], tc, 0.);
+      t_prev[k] = t; lapT_prev[k] = lapT; jd_prev[k] = jd;
+      zc0[k] = zc1[k]; zc1[k] = zc; tc0[k] = tc1[k]; tc1[k] = tc;
+    }
+  };
+
+  const bool bc = ((a.walls & WALL_W) && x0 - 2 < 0) || ((a.walls & WALL_E) && x0 + FTX + 2 > nx) || ((a.walls & WALL_S) && y0 - 2 < 0) ||
+                  ((a.walls & WALL_N) && y0 + FTY + 2 > ny);
+  // prologue: psi_0, psi_1 in LDS, psi_2 in flight, zeta_0 and tmp_0 ready
+  fetch(0);
+  stash(sP[0]);
+  if (nl > 1) { fetch(1); stash(sP[1]); }
+  if (nl > 2) fetch(2);
+  __syncthreads();
+  lds_lap<ZW, ZH, 2, PW, 3, FNT>(sZ[0], sP[0], bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);
+  __syncthreads();
+  lds_lap<TW, TH, 1, ZW, 2, FNT>(sT[0], sZ[0], bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);
+  __syncthreads();
+  for (int l = 0; l < nl; l++) {
+    const double *P0 = sP[l % 3], *P1 = sP[(l + 1) % 3];
+    const double *Z = sZ[l & 1], *T = sT[l & 1];
+    const bool more = l + 1 < nl;
+    // psi_{l+2}: registers -> LDS (buffer of psi_{l-1}, free since the last barrier); start psi_{l+3}
+    if (l + 2 < nl) stash(sP[(l + 2) % 3]);
+    if (l + 3 < nl) fetch(l + 3);
+    // interval 1: zeta_{l+1} pass || first half of the centre rows of layer l
+    if (!late && more) lds_lap<ZW, ZH, 2, PW, 3, FNT>(sZ[(l + 1) & 1], P1, bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);
+    centre(l, 0, P0, P1, Z, T);
+    if (late && more) lds_lap<ZW, ZH, 2, PW, 3, FNT>(sZ[(l + 1) & 1], P1, bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);
+    __syncthreads();
+    // interval 2: tmp_{l+1} pass || second half of the centre rows
+    if (!late && more) lds_lap<TW, TH, 1, ZW, 2, FNT>(sT[(l + 1) & 1], sZ[(l + 1) & 1], bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);
+    centre(l, HALF, P0, P1, Z, T);
+    if (late && more) lds_lap<TW, TH, 1, ZW, 2, FNT>(sT[(l + 1) & 1], sZ[(l + 1) & 1], bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);
+    __syncthreads();
+  }
+}
+
+int g_rhs_dbg = 0;
 int rhs_fused_blocks(const NatGeom &g) { return ((g.nx + FTX - 1) / FTX) * ((g.ny + 7) / 8); }  // upper bound (smallest FTY)
 
 void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq,
@@ -299,15 +466,17 @@ void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const 
                       int have_qforc, double D, double beta, double iRe, double iRe4, double cs, double cb, double slip_c,
                       const LayerCoef &lc, int variant, const double *q_in, double *q_out, double dt) {
   RhsArgs a;
+  extern int g_rhs_dbg;
+  a.dbg = g_rhs_dbg;
   a.q_in = q_in; a.q_out = q_out; a.dt = dt;
   a.psi = psi; a.S = S; a.qforc = qforc; a.wind = wind; a.dq = dq; a.umax_partial = umax_partial;
   a.g = g; a.nl = nl; a.walls = walls; a.uniformS = uniformS; a.have_qforc = have_qforc;
   a.D = D; a.beta = beta; a.iRe = iRe; a.iRe4 = iRe4; a.cs = cs; a.cb = cb; a.slip_c = slip_c; a.lc = lc;
   for (int l = 0; l < MSOM_MAXNL; l++) a.Su[l] = Su ? Su[l] : 0.;
-  int fty = (variant == 1 || variant == 2 || variant == 4) ? 16 : (variant == 3 || variant == 5) ? 8 : 32;
+  int fty = (variant == 2 || variant == 4) ? 16 : (variant == 3 || variant == 5) ? 8 : 32;
   dim3 gr((g.nx + FTX - 1) / FTX, (g.ny + fty - 1) / fty);
   switch (variant) {
-    case 1: hipLaunchKernelGGL((k_rhs_fused<16, 256, 1>), gr, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((k_rhs_fused_pipe<32, 512>), gr, dim3(512), 0, st, a); break;
     case 2: hipLaunchKernelGGL((k_rhs_fused<16, 512, 2>), gr, dim3(512), 0, st, a); break;
     case 3: hipLaunchKernelGGL((k_rhs_fused<8, 256, 2>), gr, dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL((k_rhs_fused<16, 512, 4>), gr, dim3(512), 0, st, a); break;

@@ -92,7 +92,7 @@ struct msom {
   int block_sweeps = 0;  // experimental temporally blocked smoother (2 sweeps per pass); measured not faster at nl = 6
   int mg_fused = 1;  // fused residual+restriction and correction+residual passes of the multigrid cycle
   double *psi_alt = nullptr;  // second psi buffer (the fused correction writes out of place)
-  int rhs_variant = 0;
+  int rhs_variant = 1;  // 1: software-pipelined fused tendency kernel (default), 0: phase-by-phase version
   int fused = 1;  // one-pass PV tendency kernel (kernels_fused.hip) when the configuration allows
   unsigned seed = 1;
   int quiet = 0;
@@ -479,6 +479,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "agg_size")) { m->agg_size = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "prolong_fused")) m->prolong_fused = (int)v;
   else if (!strcmp(key, "block_variant")) { extern int g_block_variant; g_block_variant = (int)v; }
+  else if (!strcmp(key, "rhs_dbg")) { extern int g_rhs_dbg; g_rhs_dbg = (int)v; }
   else if (!strcmp(key, "rhs_variant")) m->rhs_variant = (int)v;
   else if (!strcmp(key, "seed")) { m->seed = (unsigned)v; srand(m->seed); }
   else if (!strcmp(key, "noise_mode")) m->noise_mode = (int)v;
