@@ -53,6 +53,19 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // writes the homogeneous-Dirichlet ghosts that mirror cell (i, j) (edges: -v, corners: +v)
 __device__ __forceinline__ void split_write_ghosts(double *f, const SplitGeom &g, int l, int j, int i, double v, int walls) {
+  if (walls & WALL_PER) {  // periodic images of an edge cell
+    const bool w = i == 0, e = i == g.nx - 1, s = j == 0, n = j == g.ny - 1;
+    if (!(w | e | s | n)) return;
+    if (w) f[split_idx(g, l, j, g.nx)] = v;
+    if (e) f[split_idx(g, l, j, -1)] = v;
+    if (s) f[split_idx(g, l, g.ny, i)] = v;
+    if (n) f[split_idx(g, l, -1, i)] = v;
+    if (w && s) f[split_idx(g, l, g.ny, g.nx)] = v;
+    if (w && n) f[split_idx(g, l, -1, g.nx)] = v;
+    if (e && s) f[split_idx(g, l, g.ny, -1)] = v;
+    if (e && n) f[split_idx(g, l, -1, -1)] = v;
+    return;
+  }
   const bool w = i == 0 && (walls & WALL_W), e = i == g.nx - 1 && (walls & WALL_E);
   const bool s = j == 0 && (walls & WALL_S), n = j == g.ny - 1 && (walls & WALL_N);
   if (!(w | e | s | n)) return;
@@ -66,6 +79,19 @@ __device__ __forceinline__ void split_write_ghosts(double *f, const SplitGeom &g
   if (e && n) f[split_idx(g, l, g.ny, g.nx)] = v;
 }
 __device__ __forceinline__ void nat_write_ghosts(double *f, const NatGeom &g, int l, int j, int i, double v, int walls) {
+  if (walls & WALL_PER) {
+    const bool w = i == 0, e = i == g.nx - 1, s = j == 0, n = j == g.ny - 1;
+    if (!(w | e | s | n)) return;
+    if (w) f[nat_idx(g, l, j, g.nx)] = v;
+    if (e) f[nat_idx(g, l, j, -1)] = v;
+    if (s) f[nat_idx(g, l, g.ny, i)] = v;
+    if (n) f[nat_idx(g, l, -1, i)] = v;
+    if (w && s) f[nat_idx(g, l, g.ny, g.nx)] = v;
+    if (w && n) f[nat_idx(g, l, -1, g.nx)] = v;
+    if (e && s) f[nat_idx(g, l, g.ny, -1)] = v;
+    if (e && n) f[nat_idx(g, l, -1, -1)] = v;
+    return;
+  }
   const bool w = i == 0 && (walls & WALL_W), e = i == g.nx - 1 && (walls & WALL_E);
   const bool s = j == 0 && (walls & WALL_S), n = j == g.ny - 1 && (walls & WALL_N);
   if (!(w | e | s | n)) return;
@@ -104,7 +130,7 @@ __global__ void k_split_pack(const double *__restrict__ src, double *sp, SplitGe
   for (int l = 0; l < nl; l++) {
     const double v = src[((size_t)l * sg.ny + j) * sg.nx + i];
     sp[split_idx(sg, l, j, i)] = v;
-    if (bc == BC_DIRICHLET0) split_write_ghosts(sp, sg, l, j, i, v, walls);
+    if (bc != BC_NEUMANN) split_write_ghosts(sp, sg, l, j, i, v, walls);
   }
 }
 __global__ void k_split_unpack(const double *__restrict__ sp, SplitGeom sg, double *dst, int nl) {
@@ -675,7 +701,7 @@ __device__ __forceinline__ void relax_red_prolong_body(const RelaxPArgs &p) {
   }
 #pragma unroll
   for (int l = 0; l < NL; l++) p.da[own + l * ls] = x[l];
-  if ((ow | oe | os | on)) {
+  if ((ow | oe | os | on) || ((p.walls & WALL_PER) && (i == 0 || i == nx - 1 || j == 0 || j == ny - 1))) {
 #pragma unroll
     for (int l = 0; l < NL; l++) split_write_ghosts(p.da, p.g, l, j, i, x[l], p.walls);
   }

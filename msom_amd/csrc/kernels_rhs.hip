@@ -96,6 +96,66 @@ void launch_fill_ghost(hipStream_t st, double *f, const NatGeom &g, int nl, int 
   hipLaunchKernelGGL(k_fill_ghost, dim3((n + 255) / 256), dim3(256), 0, st, f, g, nl, bc, walls, depth);
 }
 
+// doubly periodic ghost cells up to depth d (sbc = -1: periodic(right), periodic(top),
+// msqg/qg.h:842-846): every cell of the d-wide frame is the wrapped copy of an interior cell
+__global__ void k_fill_periodic(double *f, NatGeom g, int nl, int d) {
+  const int wide = g.nx + 2 * d, per = 2 * d * wide + 2 * d * g.ny;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per * nl) return;
+  const int l = t / per, r = t % per;
+  int i, j;
+  if (r < 2 * d * wide) {  // rows below and above
+    const int row = r / wide;
+    i = r % wide - d;
+    j = row < d ? row - d : g.ny + (row - d);
+  } else {
+    const int q = r - 2 * d * wide;
+    j = q / (2 * d);
+    const int c = q % (2 * d);
+    i = c < d ? c - d : g.nx + (c - d);
+  }
+  const int si = ((i % g.nx) + g.nx) % g.nx, sj = ((j % g.ny) + g.ny) % g.ny;
+  f[nat_idx(g, l, j, i)] = f[nat_idx(g, l, sj, si)];
+}
+void launch_fill_periodic(hipStream_t st, double *f, const NatGeom &g, int nl, int depth) {
+  const int n = (2 * depth * (g.nx + 2 * depth) + 2 * depth * g.ny) * nl;
+  hipLaunchKernelGGL(k_fill_periodic, dim3((n + 255) / 256), dim3(256), 0, st, f, g, nl, depth);
+}
+
+// large-scale stream function in a periodic domain: dirichlet(vpg*x - upg*y) on the four wall
+// faces (msqg/qg.h:1105-1114): ghost = 2 * value(face centre) - interior; corners = y-BC of
+// the x-ghost column
+struct LinBC { double u[MSOM_MAXNL], v[MSOM_MAXNL]; };
+__global__ void k_fill_lin_dirichlet(double *f, NatGeom g, int nl, LinBC b, double D, double x0, double y0, double Lx, double Ly) {
+  const int per = 2 * g.ny + 2 * (g.nx + 2);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per * nl) return;
+  const int l = t / per, r = t % per;
+  const double u = b.u[l], v = b.v[l];
+  if (r < 2 * g.ny) {
+    const int j = r >> 1, east = r & 1;
+    const double y = y0 + (j + 0.5) * D;
+    if (east) f[nat_idx(g, l, j, g.nx)] = 2. * (v * Lx - u * y) - f[nat_idx(g, l, j, g.nx - 1)];
+    else f[nat_idx(g, l, j, -1)] = 2. * (v * 0. - u * y) - f[nat_idx(g, l, j, 0)];
+  } else {
+    const int q = r - 2 * g.ny, i = (q >> 1) - 1, north = q & 1;
+    const int jsrc = north ? g.ny - 1 : 0;
+    const double x = x0 + (i + 0.5) * D;
+    double inner;  // value of the x-extended row next to the wall
+    if (i == -1) inner = 2. * (v * 0. - u * (y0 + (jsrc + 0.5) * D)) - f[nat_idx(g, l, jsrc, 0)];
+    else if (i == g.nx) inner = 2. * (v * Lx - u * (y0 + (jsrc + 0.5) * D)) - f[nat_idx(g, l, jsrc, g.nx - 1)];
+    else inner = f[nat_idx(g, l, jsrc, i)];
+    f[nat_idx(g, l, north ? g.ny : -1, i)] = 2. * (v * x - u * (north ? Ly : 0.)) - inner;
+  }
+}
+void launch_fill_lin_dirichlet(hipStream_t st, double *f, const NatGeom &g, int nl, const double *upg, const double *vpg, double D, double Lx,
+                               double Ly) {
+  LinBC b;
+  for (int l = 0; l < MSOM_MAXNL; l++) { b.u[l] = l < nl ? upg[l] : 0.; b.v[l] = l < nl ? vpg[l] : 0.; }
+  const int n = (2 * g.ny + 2 * (g.nx + 2)) * nl;
+  hipLaunchKernelGGL(k_fill_lin_dirichlet, dim3((n + 255) / 256), dim3(256), 0, st, f, g, nl, b, D, 0., 0., Lx, Ly);
+}
+
 // partial-slip override of the zeta ghosts, msqg/qg.h:185-198
 __global__ void k_slip_bc(const double *po, double *zeta, NatGeom g, int nl, double c, int walls) {
   const int per = 2 * g.ny + 2 * g.nx;

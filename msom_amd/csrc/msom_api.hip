@@ -278,6 +278,7 @@ static int alloc_all(msom *m) {
   m->flayers[MSOM_FR] = m->flayers[MSOM_S] = m->nlm;
   m->flayers[MSOM_RO] = m->flayers[MSOM_TOPO] = 1;
   m->fbc[MSOM_FR] = m->fbc[MSOM_S] = m->fbc[MSOM_RO] = m->fbc[MSOM_TOPO] = m->bc == BC_PERIODIC ? BC_PERIODIC : BC_NEUMANN;
+  if (m->bc == BC_PERIODIC) m->fbc[MSOM_PSIPG] = BC_DIRICHLET_LIN;  // msqg/qg.h:1105-1114
   for (int k = 0; k < MSOM_NFIELDS; k++) {
     if (k == MSOM_NOISE || k == MSOM_SIGMA) continue;  // allocated when "stochastic" is switched on
     size_t bytes = m->g.ls * m->flayers[k] * sizeof(double);
@@ -364,8 +365,8 @@ static msom *create_common(const Params &p0, int px, int py, int rank, const voi
     msom_set_error("grid %d x %d on %d x %d tiles: every tile edge must be a power of two >= 2", p.N, p.Ny, px, py);
     return nullptr;
   }
-  if (p.sbc == -1) {
-    msom_set_error("sbc = -1 (doubly periodic) is not supported by this build");
+  if (p.sbc == -1 && px * py > 1) {
+    msom_set_error("sbc = -1 (doubly periodic) is supported on a single tile only");
     return nullptr;
   }
   int ndev = 0;
@@ -381,10 +382,15 @@ static msom *create_common(const Params &p0, int px, int py, int rank, const voi
   m->nx = p.N / px; m->ny = p.Ny / py;
   m->nl = p.nl; m->nlm = p.nl > 1 ? p.nl - 1 : 1;
   m->walls = 0;
-  if (m->ix == 0) m->walls |= WALL_W;
-  if (m->ix == px - 1) m->walls |= WALL_E;
-  if (m->iy == 0) m->walls |= WALL_S;
-  if (m->iy == py - 1) m->walls |= WALL_N;
+  if (p.sbc == -1) {  // periodic(right); periodic(top), msqg/qg.h:842-846
+    m->bc = BC_PERIODIC;
+    m->walls = WALL_PER;
+  } else {
+    if (m->ix == 0) m->walls |= WALL_W;
+    if (m->ix == px - 1) m->walls |= WALL_E;
+    if (m->iy == 0) m->walls |= WALL_S;
+    if (m->iy == py - 1) m->walls |= WALL_N;
+  }
   // neighbour ranks
   for (int d = 0; d < 8; d++) m->nb[d] = -1;
   {
@@ -545,7 +551,11 @@ static int check_field(msom *m, int field) {
 static int fill_bc(msom *m, int field) {
   if (m->nranks > 1 && field != MSOM_Q && field != MSOM_DQ && field != MSOM_QPRED && field != MSOM_NOISE && field != MSOM_SIGMA)
     return exch_nat(m, m->f[field], m->flayers[field], m->fbc[field], 1);
-  launch_fill_ghost(m->st, m->f[field], m->g, m->flayers[field], m->fbc[field], m->walls);
+  if (m->fbc[field] == BC_PERIODIC) launch_fill_periodic(m->st, m->f[field], m->g, m->flayers[field], 1);
+  else if (m->fbc[field] == BC_DIRICHLET_LIN)
+    launch_fill_lin_dirichlet(m->st, m->f[field], m->g, m->flayers[field], m->p.upg, m->p.vpg, m->p.L0 / m->gnx, m->p.L0,
+                              m->p.L0 * m->gny / m->gnx);
+  else launch_fill_ghost(m->st, m->f[field], m->g, m->flayers[field], m->fbc[field], m->walls);
   return MSOM_OK;
 }
 
@@ -792,7 +802,7 @@ static Lev glob_lev(msom *m, int k) {
 
 // can the level use the temporally blocked smoother (k_relax_block: 2 sweeps per pass)?
 static bool block_ok(msom *m, const Lev &L) {
-  return m->block_sweeps && m->uniformS && !L.tiled && L.sg->nx >= 64 && L.sg->ny >= 16;
+  return m->block_sweeps && m->uniformS && !L.tiled && !(m->walls & WALL_PER) && L.sg->nx >= 64 && L.sg->ny >= 16;
 }
 // is the prolongation coarse -> L folded into the first smoothing pass of L?
 static bool fuse_prolong(msom *m, const Lev &L, int nrelax) {
@@ -1018,9 +1028,10 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
   if (m->fused && !m->have_pg && !m->have_zpg && !m->flag_topo && !m->stochastic && (m->nranks == 1 || (m->nx >= 4 && m->ny >= 4))) {
     // tiles: the fused kernel needs psi on a 3-cell halo (zeta on 2, lap(zeta) on 1)
     if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], nl, m->bc, 3));
+    if (m->bc == BC_PERIODIC) launch_fill_periodic(m->st, m->f[MSOM_PSI], m->g, nl, 3);
     // one pass over psi: zeta, Jacobians, beta, dissipation, drag, forcing, max|u| (kernels_fused.hip)
     launch_rhs_fused(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, m->f[dqfield], nullptr,
-                     nullptr, m->g, nl, m->walls, m->uniformS, m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe,
+                     nullptr, m->g, nl, m->walls & WALL_ALL, m->uniformS, m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe,
                      iRe4, Eks / (p.Rom * 2 * m->dhf[0]), Ekb / (p.Rom * 2 * m->dhf[nl - 1]),
                      p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, m->rhs_variant, adv_out >= 0 ? m->f[adv_in] : nullptr,
                      adv_out >= 0 ? m->f[adv_out] : nullptr, adv_dt);

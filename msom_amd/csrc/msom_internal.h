@@ -23,8 +23,10 @@
 #define MSOM_YP 3   // pad rows below/above a natural layer
 #define MSOM_SP 16  // pad columns on each side of a split half-row
 
-enum { BC_DIRICHLET0 = 0, BC_NEUMANN = 1, BC_PERIODIC = 2 };
-enum { WALL_W = 1, WALL_E = 2, WALL_S = 4, WALL_N = 8, WALL_ALL = 15 };
+enum { BC_DIRICHLET0 = 0, BC_NEUMANN = 1, BC_PERIODIC = 2, BC_DIRICHLET_LIN = 3 };
+// WALL_PER: doubly periodic domain (sbc = -1): ghost cells are wrapped copies kept up to date by
+// the thread that owns the source cell
+enum { WALL_W = 1, WALL_E = 2, WALL_S = 4, WALL_N = 8, WALL_ALL = 15, WALL_PER = 16 };
 
 struct NatGeom {
   int nx, ny;     // interior cells of this tile

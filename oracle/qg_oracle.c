@@ -25,11 +25,14 @@
 #define M_PI 3.14159265358979323846
 #endif
 
-enum { BC_DIRICHLET0 = 0, BC_NEUMANN = 1, BC_PERIODIC = 2 };
+enum { BC_DIRICHLET0 = 0, BC_NEUMANN = 1, BC_PERIODIC = 2, BC_DIRICHLET_LIN = 3 };
 
 typedef struct {
   int nx, ny, nl, bc;
   double *d;
+  /* BC_DIRICHLET_LIN: value vpg[l]*x - upg[l]*y imposed on the wall faces (msqg/qg.h:1105-1114) */
+  const double *lin_u, *lin_v;
+  double lin_D;
 } fld;
 
 #define IDX(f, l, i, j) ((((size_t)(l) * ((f)->ny + 2)) + (size_t)((j) + 1)) * ((f)->nx + 2) + (size_t)((i) + 1))
@@ -75,6 +78,25 @@ static void fld_zero(fld *f) { memset(f->d, 0, (size_t)f->nl * (f->nx + 2) * (f-
  * on the cell face, msqg/layer.h:13-21); default: ghost = interior; periodic: wrap. */
 static void boundary(fld *f) {
   const int nx = f->nx, ny = f->ny;
+  if (f->bc == BC_DIRICHLET_LIN) {
+    /* [BASILISK RULE] dirichlet(expr): ghost = 2*expr - interior, expr evaluated at the
+     * centre of the boundary face; same direction order / corner rule as below */
+    const double D = f->lin_D, Lx = nx * D, Ly = ny * D;
+    for (int l = 0; l < f->nl; l++) {
+      const double u = f->lin_u[l], v = f->lin_v[l];
+      for (int j = 0; j < ny; j++) {
+        const double y = (j + 0.5) * D;
+        V(f, l, nx, j) = 2. * (v * Lx - u * y) - V(f, l, nx - 1, j);
+        V(f, l, -1, j) = 2. * (v * 0. - u * y) - V(f, l, 0, j);
+      }
+      for (int i = -1; i <= nx; i++) {
+        const double x = (i + 0.5) * D;
+        V(f, l, i, ny) = 2. * (v * x - u * Ly) - V(f, l, i, ny - 1);
+        V(f, l, i, -1) = 2. * (v * x - u * 0.) - V(f, l, i, 0);
+      }
+    }
+    return;
+  }
   for (int l = 0; l < f->nl; l++) {
     for (int j = 0; j < ny; j++) {
       if (f->bc == BC_PERIODIC) {
@@ -224,6 +246,10 @@ orc_t *orc_create_str(const char *text) {
     if (k == ORC_FR || k == ORC_S) { layers = nlm; b = bcn; }
     if (k == ORC_RO || k == ORC_TOPO) { layers = 1; b = bcn; }
     fld_alloc(&o->f[k], o->nx, o->ny, layers, b);
+  }
+  if (o->sbc == -1) { /* msqg/qg.h:1105-1114: the large-scale stream function is not periodic */
+    fld *pg = &o->f[ORC_PSIPG];
+    pg->bc = BC_DIRICHLET_LIN; pg->lin_u = o->upg; pg->lin_v = o->vpg; pg->lin_D = D;
   }
   for (int l = 0; l < nl; l++) o->dhf[l] = o->dhu[l];
   fld *Fr = &o->f[ORC_FR], *pp = &o->f[ORC_PSIPG], *Ro = &o->f[ORC_RO];
@@ -585,6 +611,11 @@ static void relax_level(orc_t *o, int k, fld *al, const fld *bl) {
 #pragma omp parallel for
       for (int j = 0; j < al->ny; j++)
         for (int i = (j + c) & 1; i < al->nx; i += 2) relax_column(o, al, bl, S, D, i, j);
+      /* red-black is the build's ordering; its definition refreshes the ghosts after every
+       * colour (what a halo exchange between tiles does).  With walls this equals the
+       * reference's once-per-sweep boundary_level(); with periodic BCs the black half-sweep
+       * then sees the new red values across the seam. */
+      if (c == 0) boundary(al);
     }
   }
 }
