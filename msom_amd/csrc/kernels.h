@@ -49,6 +49,9 @@ void launch_sum_layers(hipStream_t st, const double *f, double *partial, double 
 void launch_sub_layer_const(hipStream_t st, double *f, const double *sums, const NatGeom &g, int nl, double inv_count);
 void launch_make_S(hipStream_t st, const double *Fr, const double *Ro, double *S, const NatGeom &g, int nlm);
 
+void launch_noise(hipStream_t st, double *n, const double *sigma, const NatGeom &g, int nl, double amp, unsigned seed, unsigned draw, int gx0,
+                  int gy0, int gnx);
+
 // ---- kernels_fused.hip
 int rhs_fused_blocks(const NatGeom &g);
 void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq,

@@ -533,3 +533,40 @@ __global__ void k_make_S(const double *__restrict__ Fr, const double *__restrict
 void launch_make_S(hipStream_t st, const double *Fr, const double *Ro, double *S, const NatGeom &g, int nlm) {
   hipLaunchKernelGGL(k_make_S, grid2d(g.nx, g.ny), block2d(), 0, st, Fr, Ro, S, g, nlm);
 }
+
+// ------------------------------------------------------------------ K14 stochastic forcing noise
+
+// n = amp * sigma(x) * N(0,1) per point-layer (generate_noise, msqg/qg_stochastic.h:117-126).
+// The reference draws from the serial rand() stream in foreach order, which no parallel
+// machine can reproduce; noise_mode 0 replays exactly that stream on the host (parity tests),
+// noise_mode 1 (this kernel) uses a counter-based generator: Philox-4x32-10 keyed by the seed,
+// counter = (global cell index, layer, draw number), then the reference's Box-Muller formula
+// on two uniforms quantised to rand()'s 31 bits.  Results are independent of tiling and of
+// the launch geometry; parity with the reference is statistical only.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__global__ void k_noise(double *n, const double *__restrict__ sigma, NatGeom g, int nl, double amp, unsigned seed, unsigned draw, int gx0, int gy0,
+                        int gnx) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  const uint32_t cell = (uint32_t)((size_t)(gy0 + j) * gnx + (gx0 + i));
+  for (int l = 0; l < nl; l++) {
+    uint32_t c[4] = {cell, (uint32_t)l, draw, 0x6d736f6du};
+    philox4x32_10(c, seed, 0x4d493335u);
+    const double r1 = (double)(c[0] >> 1), r2 = (double)(c[1] >> 1), RM = 2147483647.;  // RAND_MAX
+    const double a = sqrt(-2. * log((r1 + 1.) / (RM + 2.)));
+    const size_t k = nat_idx(g, l, j, i);
+    n[k] = amp * sigma[k] * (a * cos(2 * 3.14159265358979323846 * r2 / RM));
+  }
+}
+void launch_noise(hipStream_t st, double *n, const double *sigma, const NatGeom &g, int nl, double amp, unsigned seed, unsigned draw, int gx0,
+                  int gy0, int gnx) {
+  hipLaunchKernelGGL(k_noise, grid2d(g.nx, g.ny), block2d(), 0, st, n, sigma, g, nl, amp, seed, draw, gx0, gy0, gnx);
+}

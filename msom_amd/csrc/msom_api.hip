@@ -94,7 +94,7 @@ struct msom {
   double *psi_alt = nullptr;  // second psi buffer (the fused correction writes out of place)
   int rhs_variant = 1;  // 1: software-pipelined fused tendency kernel (default), 0: phase-by-phase version
   int fused = 1;  // one-pass PV tendency kernel (kernels_fused.hip) when the configuration allows
-  unsigned seed = 1;
+  unsigned seed = 1, noise_draw = 0;
   int quiet = 0;
   // time loop
   double t = 0, dt = 1., tnext = HUGE_VAL, previous = 0;
@@ -1110,8 +1110,12 @@ static int advance_qg(msom *m, int out, int in, int dq, double dt) {
     m->corrector_step = (m->corrector_step + 1) % 2;
     float fdts = sqrt(dt);
     if (m->corrector_step) {
-      int r = generate_noise_host(m);
-      if (r) return r;
+      if (m->noise_mode == 0) {  // reference-exact serial rand() stream
+        int r = generate_noise_host(m);
+        if (r) return r;
+      } else  // counter-based device generator
+        launch_noise(m->st, m->f[MSOM_NOISE], m->f[MSOM_SIGMA], m->g, m->nl, m->p.amp_stoch, m->seed, m->noise_draw++, m->ix * m->nx,
+                     m->iy * m->ny, m->gnx);
       fdts = fdts / sqrt(2);
     }
     dts = fdts;

@@ -525,3 +525,36 @@ def test_periodic_arakawa_identities_on_gpu():
         assert abs(J.sum()) <= 1e-13 * scale
         assert abs((J * psi).sum()) <= 1e-13 * scale * np.abs(psi).max()
         assert abs((J * zeta).sum()) <= 1e-13 * scale * np.abs(zeta).max()
+
+
+def test_device_noise_statistics_and_tiling_independence():
+    """noise_mode = 1: counter-based N(0,1) on the device (the reference's serial rand() stream
+    cannot be reproduced in parallel: parity is statistical)."""
+    nx = ny = 256; nl = 3
+    txt = orc.double_gyre_params(nx, nl, extra="tr_stoch = 50\namp_stoch = 2.0\n")
+    fields = []
+    for seed in (11, 11, 12):
+        g = QG(txt)
+        g.option("quiet", 1); g.option("stochastic", 1); g.option("noise_mode", 1); g.option("seed", seed)
+        g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx)); g.set_const()
+        sig = np.full((nl, ny, nx), 0.5)
+        g.set(F["SIGMA"], sig)
+        g.set_tnext(float("inf"))
+        g.step()
+        fields.append(g.get(F["NOISE"]))
+    assert np.array_equal(fields[0], fields[1]) and not np.array_equal(fields[0], fields[2])
+    n = fields[0] / (2.0 * 0.5)                      # amp * sigma
+    N = n.size
+    assert abs(n.mean()) < 5 / np.sqrt(N) and abs(n.var() - 1) < 5 * np.sqrt(2 / N)
+    assert abs(np.mean(n**3)) < 5 * np.sqrt(15 / N) and abs(np.mean(n**4) - 3) < 5 * np.sqrt(96 / N)
+    # neighbours and layers uncorrelated
+    for a, b in ((n[:, :, 1:], n[:, :, :-1]), (n[:, 1:], n[:, :-1]), (n[1:], n[:-1])):
+        assert abs(np.mean(a * b)) < 5 / np.sqrt(a.size)
+    # the same field comes out of a 2 x 2 tiling (counter = global cell index)
+    from test_gpu_tiled import run_tiled, assemble
+    txt_t = orc.double_gyre_params(nx, nl, extra="tr_stoch = 50\namp_stoch = 2.0\nMGLEVELS = 7\n")
+    out = run_tiled(txt_t, 2, 2, orc.synthetic_psi(nl, ny, nx), nsteps=1, strict=False,
+                    opts={"stochastic": 1, "noise_mode": 1, "seed": 11},
+                    fn=lambda g, r: g.get(F["NOISE"]), pre=lambda g, r: g.set(F["SIGMA"], np.full((nl, ny // 2, nx // 2), 0.5)))
+    got = np.concatenate([np.concatenate([out[iy * 2 + ix]["extra"] for ix in range(2)], axis=2) for iy in range(2)], axis=1)
+    assert np.array_equal(got, fields[0])

@@ -15,7 +15,7 @@ from msom_amd import QG, FIELDS as F
 pytestmark = pytest.mark.gpu
 
 
-def run_tiled(params, px, py, psi, nsteps, strict, fn=None, opts=None):
+def run_tiled(params, px, py, psi, nsteps, strict, fn=None, opts=None, pre=None):
     n = px * py
     uid = b"MSOMLOCL" + os.urandom(8) + bytes(112)
     nl, gny, gnx = psi.shape
@@ -32,6 +32,8 @@ def run_tiled(params, px, py, psi, nsteps, strict, fn=None, opts=None):
             assert g.tile == (px, py, ix, iy) and (g.nx, g.ny) == (tx, ty)
             g.set(F["PSI"], psi[:, iy * ty:(iy + 1) * ty, ix * tx:(ix + 1) * tx])
             g.set_const()
+            if pre:
+                pre(g, rank)
             g.set_tnext(float("inf"))
             dts = [g.step() for _ in range(nsteps)]
             res = dict(q=g.get(F["Q"]), psi=g.get(F["PSI"]), ke=g.ke(), t=g.t, dts=dts, st=g.mgstats(), agg=g.param("agg_level"))
