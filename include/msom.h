@@ -49,7 +49,12 @@ enum {
   MSOM_QPRED = 12, /* predictor                              */
   MSOM_NOISE = 13, /* n_stochl (msqg/qg_stochastic.h:13)     */
   MSOM_SIGMA = 14, /* s_stochl (msqg/qg_stochastic.h:14)     */
-  MSOM_NFIELDS = 15
+  /* passive tracers (nptr > 0): nl*nptr layers, index l*nptr + nt (msqg/qg.h:100-101) */
+  MSOM_PTR = 15,       /* ptracersl                          */
+  MSOM_PTR_RELAX = 16, /* ptr_relaxl                         */
+  MSOM_DPTR = 17,      /* tracer part of `updates`           */
+  MSOM_PTR_PRED = 18,  /* tracer part of the predictor       */
+  MSOM_NFIELDS = 19
 };
 
 /* mgstats of Basilisk (text: mspg/elliptic.h:118-123), kept by the reference in `mgpsi`

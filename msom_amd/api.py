@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBDIR = os.path.join(_HERE, "lib")
 
 FIELDS = dict(PSI=0, Q=1, ZETA=2, PSIPG=3, ZETAPG=4, QFORC=5, TMP=6, FR=7, S=8, DQ=9, RO=10, TOPO=11,
-              QPRED=12, NOISE=13, SIGMA=14)
+              QPRED=12, NOISE=13, SIGMA=14, PTR=15, PTR_RELAX=16, DPTR=17, PTR_PRED=18)
 
 
 class MsomError(RuntimeError):

@@ -52,6 +52,9 @@ void launch_make_S(hipStream_t st, const double *Fr, const double *Ro, double *S
 void launch_noise(hipStream_t st, double *n, const double *sigma, const NatGeom &g, int nl, double amp, unsigned seed, unsigned draw, int gx0,
                   int gy0, int gnx);
 
+void launch_ptr_rhs(hipStream_t st, const double *psi, const double *c, const double *rel, double *dp, const NatGeom &g, int nl, int np,
+                    const double *iPe, const double *ptr_ir, double D);
+
 // ---- kernels_fused.hip
 int rhs_fused_blocks(const NatGeom &g);
 void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq,

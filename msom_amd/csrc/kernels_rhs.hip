@@ -570,3 +570,29 @@ void launch_noise(hipStream_t st, double *n, const double *sigma, const NatGeom 
                   int gy0, int gnx) {
   hipLaunchKernelGGL(k_noise, grid2d(g.nx, g.ny), block2d(), 0, st, n, sigma, g, nl, amp, seed, draw, gx0, gy0, gnx);
 }
+
+// ------------------------------------------------------------------ passive tracers
+
+// ptr_rhs, msqg/qg.h:574-588: dpdt += -J(psi_l, c) + c-diffusion + relaxation, tracer fields
+// stored [l * nptr + nt]
+struct PtrCoef { double iPe[MSOM_MAXNL], ptr_ir[MSOM_MAXNL]; };
+__global__ void k_ptr_rhs(const double *__restrict__ psi, const double *__restrict__ c, const double *__restrict__ rel, double *dp, NatGeom g,
+                          int nl, int np, PtrCoef pc, double D) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  const double D2 = D * D, rD2 = 1. / D2, D12 = 12. * D * D, rD12 = 1. / D12;
+  const size_t c0 = nat_idx(g, 0, j, i);
+  for (int l = 0; l < nl; l++)
+    for (int nt = 0; nt < np; nt++) {
+      const size_t k = c0 + (size_t)(l * np + nt) * g.ls;
+      const double *cl = c + (size_t)(l * np + nt) * g.ls;
+      dp[k] += mjac(psi + (size_t)l * g.ls, cl, c0, g.pitch, D12, rD12) + pc.iPe[nt] * DIVC(LAPV(cl, c0, g.pitch), D2, rD2) +
+               pc.ptr_ir[nt] * (rel[k] - c[k]);
+    }
+}
+void launch_ptr_rhs(hipStream_t st, const double *psi, const double *c, const double *rel, double *dp, const NatGeom &g, int nl, int np,
+                    const double *iPe, const double *ptr_ir, double D) {
+  PtrCoef pc;
+  for (int k = 0; k < MSOM_MAXNL; k++) { pc.iPe[k] = k < np ? iPe[k] : 0.; pc.ptr_ir[k] = k < np ? ptr_ir[k] : 0.; }
+  hipLaunchKernelGGL(k_ptr_rhs, grid2d(g.nx, g.ny), block2d(), 0, st, psi, c, rel, dp, g, nl, np, pc, D);
+}

@@ -279,8 +279,13 @@ static int alloc_all(msom *m) {
   m->flayers[MSOM_RO] = m->flayers[MSOM_TOPO] = 1;
   m->fbc[MSOM_FR] = m->fbc[MSOM_S] = m->fbc[MSOM_RO] = m->fbc[MSOM_TOPO] = m->bc == BC_PERIODIC ? BC_PERIODIC : BC_NEUMANN;
   if (m->bc == BC_PERIODIC) m->fbc[MSOM_PSIPG] = BC_DIRICHLET_LIN;  // msqg/qg.h:1105-1114
+  for (int k = MSOM_PTR; k <= MSOM_PTR_PRED; k++) {  // passive tracers: Neumann / periodic (msqg/qg.h:867-870)
+    m->flayers[k] = m->nl * (m->p.nptr > 0 ? m->p.nptr : 1);
+    m->fbc[k] = m->bc == BC_PERIODIC ? BC_PERIODIC : BC_NEUMANN;
+  }
   for (int k = 0; k < MSOM_NFIELDS; k++) {
     if (k == MSOM_NOISE || k == MSOM_SIGMA) continue;  // allocated when "stochastic" is switched on
+    if (k >= MSOM_PTR && m->p.nptr <= 0) continue;
     size_t bytes = m->g.ls * m->flayers[k] * sizeof(double);
     HIPCHK(hipMalloc(&m->f[k], bytes));
     HIPCHK(hipMemsetAsync(m->f[k], 0, bytes, m->st));
@@ -306,7 +311,7 @@ static int alloc_all(msom *m) {
   }
   HIPCHK(hipMalloc(&m->psi_alt, m->g.ls * m->nl * sizeof(double)));
   HIPCHK(hipMemsetAsync(m->psi_alt, 0, m->g.ls * m->nl * sizeof(double), m->st));
-  HIPCHK(hipMalloc(&m->staging, (size_t)m->nl * m->nx * m->ny * sizeof(double)));
+  HIPCHK(hipMalloc(&m->staging, (size_t)m->nl * (m->p.nptr > 1 ? m->p.nptr : 1) * m->nx * m->ny * sizeof(double)));
   HIPCHK(hipMalloc(&m->partial, (size_t)partial_count(m->g) * m->nl * sizeof(double)));
   {
     size_t nb = (size_t)rhs_fused_blocks(m->g);
@@ -363,6 +368,10 @@ static msom *create_common(const Params &p0, int px, int py, int rank, const voi
   }
   if (p.N % px || p.Ny % py || !is_pow2(p.N / px) || !is_pow2(p.Ny / py) || p.N / px < 2 || p.Ny / py < 2) {
     msom_set_error("grid %d x %d on %d x %d tiles: every tile edge must be a power of two >= 2", p.N, p.Ny, px, py);
+    return nullptr;
+  }
+  if (p.nptr < 0 || p.nptr > MSOM_MAXNL) {
+    msom_set_error("nptr = %d outside 0..%d", p.nptr, MSOM_MAXNL);
     return nullptr;
   }
   if (p.sbc == -1 && px * py > 1) {
@@ -511,6 +520,7 @@ extern "C" double msom_get_param(msom_t *m, const char *key) {
   if (!strcmp(key, "N") || !strcmp(key, "nx")) return m->gnx;
   if (!strcmp(key, "ny")) return m->gny;
   if (!strcmp(key, "nl")) return m->nl;
+  if (!strcmp(key, "nptr")) return p.nptr;
   if (!strcmp(key, "L0")) return p.L0;
   if (!strcmp(key, "DT")) return p.DT;
   if (!strcmp(key, "iRe")) return p.iRe;
@@ -1056,6 +1066,8 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
   return MSOM_OK;
 }
 
+static int tracer_update(msom *m, int cfield);
+
 // first half of update_qg (msqg/qg.h:621-623): invert q -> psi, then the CFL part of
 // advection_pv (:383-391): 2*nl limiter calls (psi_l then psipg_l) sharing one static
 // `previous`.  max|u| of psi comes out of the solver's last pass (k_residual2<CORRECT>), so dt
@@ -1081,6 +1093,7 @@ static double update_qg(msom *m, int qfield, int dqfield, double dtmax) {
   dtmax = solve_and_dt(m, qfield, dtmax);
   if (dtmax < 0) return -1;
   if (rhs_terms(m, qfield, dqfield, 1, p.iRe, p.iRe4, p.Eks, p.Ekb)) return -1;
+  if (p.nptr > 0 && tracer_update(m, qfield == MSOM_QPRED ? MSOM_PTR_PRED : MSOM_PTR)) return -1;
   return dtmax;
 }
 
@@ -1264,6 +1277,20 @@ static double dtnext(msom *m, double dt, double *tnext_out) {
   return dt;
 }
 
+// tracer part of update_qg (msqg/qg.h:634-647): dpdt = ptr_rhs(tracers, psi) with `updates` zeroed
+static int tracer_update(msom *m, int cfield) {
+  const int nt = m->nl * m->p.nptr;
+  HIPCHK(hipMemsetAsync(m->f[MSOM_DPTR], 0, m->g.ls * nt * sizeof(double), m->st));
+  launch_ptr_rhs(m->st, m->f[MSOM_PSI], m->f[cfield], m->f[MSOM_PTR_RELAX], m->f[MSOM_DPTR], m->g, m->nl, m->p.nptr, m->p.iPe, m->p.ptr_ir,
+                 m->p.L0 / m->gnx);
+  return MSOM_OK;
+}
+// tracer part of advance_qg (msqg/qg.h:597-605)
+static int tracer_advance(msom *m, int out, int in, double dt) {
+  launch_advance(m->st, m->f[out], m->f[in], m->f[MSOM_DPTR], nullptr, m->g, m->nl * m->p.nptr, dt, 0.);
+  return fill_bc(m, out);
+}
+
 // one iteration of run() [Basilisk predictor-corrector.h]:
 //   dt = dtnext(update(evolving, updates, DT)); advance(predictor, evolving, updates, dt/2);
 //   update(predictor, updates, dt); advance(evolving, evolving, updates, dt)
@@ -1279,9 +1306,12 @@ extern "C" int msom_step(msom_t *m, double *dt_used) {
   m->dt = dtnext(m, d, &tnext);
   if ((r = rhs_terms(m, MSOM_Q, MSOM_DQ, 1, p.iRe, p.iRe4, p.Eks, p.Ekb, MSOM_QPRED, MSOM_Q, m->dt / 2., &advanced))) return r;
   if (!advanced && (r = advance_qg(m, MSOM_QPRED, MSOM_Q, MSOM_DQ, m->dt / 2.))) return r;
+  const bool tracers = m->p.nptr > 0;
+  if (tracers && ((r = tracer_update(m, MSOM_PTR)) || (r = tracer_advance(m, MSOM_PTR_PRED, MSOM_PTR, m->dt / 2.)))) return r;
   if (solve_and_dt(m, MSOM_QPRED, m->dt) < 0) return m->sticky ? m->sticky : MSOM_ERR_HIP;
   if ((r = rhs_terms(m, MSOM_QPRED, MSOM_DQ, 1, p.iRe, p.iRe4, p.Eks, p.Ekb, MSOM_Q, MSOM_Q, m->dt, &advanced))) return r;
   if (!advanced && (r = advance_qg(m, MSOM_Q, MSOM_Q, MSOM_DQ, m->dt))) return r;
+  if (tracers && ((r = tracer_update(m, MSOM_PTR_PRED)) || (r = tracer_advance(m, MSOM_PTR, MSOM_PTR, m->dt)))) return r;
   if ((r = sync_stream(m))) return r;
   m->t = tnext;
   m->iter++;
@@ -1380,6 +1410,15 @@ extern "C" int msom_read_inputs(msom_t *m, const char *dir) {
     if ((r = msom_read_bas(m, MSOM_TOPO, name))) return r;
     if (!m->quiet) fprintf(stdout, "%s .. ok\n", name);
   }
+  if (m->p.nptr > 0) {  // msqg/qg.c:75-90
+    snprintf(name, sizeof name, "%s/ptr0.bas", d);
+    if (file_exists(name)) {
+      if ((r = msom_read_bas(m, MSOM_PTR, name))) return r;
+      if (!m->quiet) fprintf(stdout, "%s .. ok\n", name);
+    }
+    snprintf(name, sizeof name, "%s/ptr_relax.bas", d);
+    if (file_exists(name) && (r = msom_read_bas(m, MSOM_PTR_RELAX, name))) return r;
+  }
   snprintf(name, sizeof name, "%s/p0.bas", d);
   if (file_exists(name)) {
     if ((r = msom_read_bas(m, MSOM_PSI, name))) return r;
@@ -1465,6 +1504,10 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
       if ((r = msom_write_bas(m, MSOM_PSI, name))) return r;
       snprintf(name, sizeof name, "%sqo%09d.bas", dpath, m->iter);
       if ((r = msom_write_bas(m, MSOM_Q, name))) return r;
+      if (p.nptr > 0) {  // msqg/qg.c:168-171
+        snprintf(name, sizeof name, "%sptr%09d.bas", dpath, m->iter);
+        if ((r = msom_write_bas(m, MSOM_PTR, name))) return r;
+      }
       tout += p.dtout;
       out_pending = tout <= p.tend + 1e-10;
     }

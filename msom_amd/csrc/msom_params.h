@@ -12,6 +12,7 @@ struct Params {
   double L0, Rom, Ekb, Eks, tau0, Re, Re4, iRe, iRe4, sbc, beta, afilt, Lfmax;
   double DT, tend, dtout, dtflt, CFL;
   double Frm[MSOM_MAXARR], dhu[MSOM_MAXARR], upg[MSOM_MAXARR], vpg[MSOM_MAXARR];
+  double ptr_r[MSOM_MAXARR], ptr_ir[MSOM_MAXARR], Pe[MSOM_MAXARR], iPe[MSOM_MAXARR]; /* passive tracers, qg.h:103-106 */
   double tr_stoch, itr_stoch, amp_stoch;
   double tolerance; /* extension key TOLERANCE (reference: 1e-3, msqg/qg.h:159) */
   int nitermax, nitermin;

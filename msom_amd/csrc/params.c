@@ -36,7 +36,7 @@ static const keydef KEYS[] = {
   K("Re4", T_DBL, Re4), K("sbc", T_DBL, sbc), K("beta", T_DBL, beta), K("afilt", T_DBL, afilt),
   K("Lfmax", T_DBL, Lfmax), K("DT", T_DBL, DT), K("tend", T_DBL, tend), K("dtout", T_DBL, dtout),
   K("dtflt", T_DBL, dtflt), K("CFL", T_DBL, CFL), K("Fr", T_ARR, Frm), K("dh", T_ARR, dhu),
-  K("upg", T_ARR, upg), K("vpg", T_ARR, vpg), K("tr_stoch", T_DBL, tr_stoch),
+  K("upg", T_ARR, upg), K("vpg", T_ARR, vpg), K("ptr_r", T_ARR, ptr_r), K("Pe", T_ARR, Pe), K("tr_stoch", T_DBL, tr_stoch),
   K("amp_stoch", T_DBL, amp_stoch),
   /* extension keys, unknown to (hence ignored by) the reference parser */
   K("Ny", T_INT, Ny), K("TOLERANCE", T_DBL, tolerance), K("NITERMAX", T_INT, nitermax),
@@ -122,4 +122,8 @@ void msom_params_derive(struct Params *p) {
   if (p->Re != 0) p->DT = 0.5 * fmin(p->DT, D2 * p->Re / 4.);
   if (p->Re4 != 0) p->DT = 0.5 * fmin(p->DT, D2 * D2 * p->Re4 / 32.);
   if (p->tr_stoch != 0) p->itr_stoch = 1 / p->tr_stoch;
+  for (int nt = 0; nt < p->nptr && nt < MSOM_MAXARR; nt++) { /* msqg/qg.h:751-754 */
+    p->ptr_ir[nt] = p->ptr_r[nt] == 0 ? 0. : 1 / p->ptr_r[nt];
+    p->iPe[nt] = p->Pe[nt] == 0 ? 0. : 1 / p->Pe[nt];
+  }
 }

@@ -42,7 +42,8 @@ struct orc {
   /* parameters, msqg/qg.h:63-106 */
   int nx, ny, nl;
   double L0, Rom, Ekb, Eks, tau0, Re, Re4, iRe, iRe4, sbc, beta, DT, CFL, tend, dtout;
-  int varRo, flsrv, flag_topo;
+  int varRo, flsrv, flag_topo, nptr;
+  double ptr_r[ORC_MAXNL], ptr_ir[ORC_MAXNL], Pe[ORC_MAXNL], iPe[ORC_MAXNL];
   double Frm[ORC_MAXNL], dhu[ORC_MAXNL], upg[ORC_MAXNL], vpg[ORC_MAXNL];
   double dhf[ORC_MAXNL], dhc[ORC_MAXNL], idh0[ORC_MAXNL], idh1[ORC_MAXNL];
   /* stochastic variant msqg/qg_stochastic.h */
@@ -171,6 +172,9 @@ static void parse_line(orc_t *o, char *buf, int *N, int *Ny) {
   else if (!strcmp(k, "nl")) o->nl = atoi(v);
   else if (!strcmp(k, "varRo")) o->varRo = atoi(v);
   else if (!strcmp(k, "flsrv")) o->flsrv = atoi(v);
+  else if (!strcmp(k, "nptr")) o->nptr = atoi(v);
+  else if (!strcmp(k, "ptr_r")) str2array(v, o->ptr_r);
+  else if (!strcmp(k, "Pe")) str2array(v, o->Pe);
   else if (!strcmp(k, "L0")) o->L0 = atof(v);
   else if (!strcmp(k, "Rom")) o->Rom = atof(v);
   else if (!strcmp(k, "Ekb")) o->Ekb = atof(v);
@@ -235,6 +239,10 @@ orc_t *orc_create_str(const char *text) {
   if (o->Re != 0) o->DT = 0.5 * fmin(o->DT, D * D * o->Re / 4.);
   if (o->Re4 != 0) o->DT = 0.5 * fmin(o->DT, (D * D) * (D * D) * o->Re4 / 32.);
   if (o->tr_stoch != 0) o->itr_stoch = 1 / o->tr_stoch;   /* qg.h:757 */
+  for (int nt = 0; nt < o->nptr && nt < ORC_MAXNL; nt++) { /* qg.h:751-754 */
+    o->ptr_ir[nt] = o->ptr_r[nt] == 0 ? 0. : 1 / o->ptr_r[nt];
+    o->iPe[nt] = o->Pe[nt] == 0 ? 0. : 1 / o->Pe[nt];
+  }
   if (o->nl < 1 || o->nl > ORC_MAXNL) { free(o); return NULL; }
 
   /* set_vars msqg/qg.h:837-925 */
@@ -245,6 +253,7 @@ orc_t *orc_create_str(const char *text) {
     int layers = nl, b = bc;
     if (k == ORC_FR || k == ORC_S) { layers = nlm; b = bcn; }
     if (k == ORC_RO || k == ORC_TOPO) { layers = 1; b = bcn; }
+    if (k >= ORC_PTR) { layers = nl * (o->nptr > 0 ? o->nptr : 1); b = bcn; } /* qg.h:867-870 */
     fld_alloc(&o->f[k], o->nx, o->ny, layers, b);
   }
   if (o->sbc == -1) { /* msqg/qg.h:1105-1114: the large-scale stream function is not periodic */
@@ -295,6 +304,7 @@ double orc_get_param(orc_t *o, const char *key) {
   if (!strcmp(key, "N") || !strcmp(key, "nx")) return o->nx;
   if (!strcmp(key, "ny")) return o->ny;
   if (!strcmp(key, "nl")) return o->nl;
+  if (!strcmp(key, "nptr")) return o->nptr;
   if (!strcmp(key, "L0")) return o->L0;
   if (!strcmp(key, "DT")) return o->DT;
   if (!strcmp(key, "iRe")) return o->iRe;
@@ -815,6 +825,21 @@ void orc_set_const(orc_t *o) {
 
 /* ------------------------------------------------------------------ time stepping */
 
+/* ptr_rhs, msqg/qg.h:574-588 */
+static void ptr_rhs(orc_t *o, fld *c, fld *po, fld *dp) {
+  fld *rel = &o->f[ORC_PTR_RELAX];
+  const double D = o->L0 / o->nx, D2 = D * D;
+  const int np = o->nptr;
+#pragma omp parallel for
+  for (int j = 0; j < po->ny; j++)
+    for (int i = 0; i < po->nx; i++)
+      for (int l = 0; l < o->nl; l++)
+        for (int nt = 0; nt < np; nt++) {
+          const int k = l * np + nt;
+          V(dp, k, i, j) += jacobian(po, l, c, k, i, j, D) + o->iPe[nt] * LAP(c, k, i, j, D2) + o->ptr_ir[nt] * (V(rel, k, i, j) - V(c, k, i, j));
+        }
+}
+
 /* msqg/qg.h:609-650 */
 static double update_qg(orc_t *o, fld *q, fld *dq, double dtmax) {
   fld_zero(dq);
@@ -823,6 +848,11 @@ static double update_qg(orc_t *o, fld *q, fld *dq, double dtmax) {
   dtmax = advection_pv(o, &o->f[ORC_ZETA], q, &o->f[ORC_PSI], dq, dtmax);
   dissip(o, &o->f[ORC_ZETA], dq);
   forcing_terms(o, &o->f[ORC_ZETA], &o->f[ORC_PSI], dq, 1);
+  if (o->nptr > 0) { /* :634-647: the tracers are the part of `evolving` that goes with q */
+    fld *c = q == &o->f[ORC_QPRED] ? &o->f[ORC_PTR_PRED] : &o->f[ORC_PTR];
+    fld_zero(&o->f[ORC_DPTR]);
+    ptr_rhs(o, c, &o->f[ORC_PSI], &o->f[ORC_DPTR]);
+  }
   return dtmax;
 }
 double orc_update(orc_t *o, int q, int dq, double dtmax) { return update_qg(o, &o->f[q], &o->f[dq], dtmax); }
@@ -837,6 +867,14 @@ static void generate_noise(orc_t *o) {
   for (int i = 0; i < n->nx; i++)
     for (int j = 0; j < n->ny; j++)
       for (int l = 0; l < o->nl; l++) V(n, l, i, j) = o->amp_stoch * V(s, l, i, j) * normal_noise();
+}
+
+/* advance_qg for the tracer part of the lists, msqg/qg.h:597-605 */
+static void advance_plain(fld *out, fld *in, fld *d, double dt) {
+  for (int l = 0; l < out->nl; l++)
+    for (int j = 0; j < out->ny; j++)
+      for (int i = 0; i < out->nx; i++) V(out, l, i, j) = V(in, l, i, j) + V(d, l, i, j) * dt;
+  boundary(out);
 }
 
 /* msqg/qg.h:594-606; stochastic: msqg/qg_stochastic.h:128-149 */
@@ -895,8 +933,10 @@ int orc_step(orc_t *o) {
   double tnext;
   o->dt = dtnext(o, update_qg(o, q, dq, o->DT), &tnext);
   advance_qg(o, pred, q, dq, o->dt / 2.);
+  if (o->nptr > 0) advance_plain(&o->f[ORC_PTR_PRED], &o->f[ORC_PTR], &o->f[ORC_DPTR], o->dt / 2.);
   update_qg(o, pred, dq, o->dt);
   advance_qg(o, q, q, dq, o->dt);
+  if (o->nptr > 0) advance_plain(&o->f[ORC_PTR], &o->f[ORC_PTR], &o->f[ORC_DPTR], o->dt);
   o->t = tnext;
   o->iter++;
   return 0;

@@ -27,7 +27,9 @@ enum {
   ORC_PSI = 0, ORC_Q = 1, ORC_ZETA = 2, ORC_PSIPG = 3, ORC_ZETAPG = 4, ORC_QFORC = 5,
   ORC_TMP = 6, ORC_FR = 7 /* nl-1 layers */, ORC_S = 8 /* nl-1 layers */, ORC_DQ = 9,
   ORC_RO = 10 /* 1 layer */, ORC_TOPO = 11 /* 1 layer */, ORC_QPRED = 12,
-  ORC_NOISE = 13, ORC_SIGMA = 14, ORC_NFIELDS = 15
+  ORC_NOISE = 13, ORC_SIGMA = 14,
+  /* passive tracers, nl*nptr layers, index l*nptr + nt (msqg/qg.h:100-101,574-588) */
+  ORC_PTR = 15, ORC_PTR_RELAX = 16, ORC_DPTR = 17, ORC_PTR_PRED = 18, ORC_NFIELDS = 19
 };
 
 enum { ORC_GS_LEX = 0, ORC_GS_RB = 1 };

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _LIB = os.path.join(_ROOT, "oracle", "_build", "liborc.so")
 
-PSI, Q, ZETA, PSIPG, ZETAPG, QFORC, TMP, FR, S, DQ, RO, TOPO, QPRED, NOISE, SIGMA = range(15)
+PSI, Q, ZETA, PSIPG, ZETAPG, QFORC, TMP, FR, S, DQ, RO, TOPO, QPRED, NOISE, SIGMA, PTR, PTR_RELAX, DPTR, PTR_PRED = range(19)
 GS_LEX, GS_RB = 0, 1
 
 

@@ -20,7 +20,7 @@ class Params(C.Structure):
     _fields_ = ([(k, C.c_int) for k in ("N", "Ny", "nl", "ediag", "varRo", "nptr", "flsrv")]
                 + [(k, C.c_double) for k in ("L0", "Rom", "Ekb", "Eks", "tau0", "Re", "Re4", "iRe", "iRe4", "sbc", "beta",
                                               "afilt", "Lfmax", "DT", "tend", "dtout", "dtflt", "CFL")]
-                + [(k, C.c_double * MAXARR) for k in ("Frm", "dhu", "upg", "vpg")]
+                + [(k, C.c_double * MAXARR) for k in ("Frm", "dhu", "upg", "vpg", "ptr_r", "ptr_ir", "Pe", "iPe")]
                 + [(k, C.c_double) for k in ("tr_stoch", "itr_stoch", "amp_stoch", "tolerance")]
                 + [("nitermax", C.c_int), ("nitermin", C.c_int), ("mglevels", C.c_int)])
 

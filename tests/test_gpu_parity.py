@@ -558,3 +558,25 @@ def test_device_noise_statistics_and_tiling_independence():
                     fn=lambda g, r: g.get(F["NOISE"]), pre=lambda g, r: g.set(F["SIGMA"], np.full((nl, ny // 2, nx // 2), 0.5)))
     got = np.concatenate([np.concatenate([out[iy * 2 + ix]["extra"] for ix in range(2)], axis=2) for iy in range(2)], axis=1)
     assert np.array_equal(got, fields[0])
+
+
+@pytest.mark.parametrize("nx,ny,nl,nptr,extra", [(32, 32, 3, 2, ""), (64, 32, 2, 1, PER), (32, 32, 1, 3, "")])
+def test_passive_tracers_bit_exact(nx, ny, nl, nptr, extra):
+    """nptr > 0 (msqg/qg.h:574-588, 634-647): tracer tendency -J(psi, c) + c-diffusion +
+    relaxation and the tracer part of advance_qg, strict build against the oracle."""
+    ex = extra + f"nptr = {nptr}\nptr_r = [{','.join(['10', '0', '3.5'][:nptr])}]\nPe = [{','.join(['200', '50', '0'][:nptr])}]\n"
+    o, g = make_pair(nx, ny, nl, strict=True, extra=ex)
+    assert g.param("nptr") == nptr == o.param("nptr")
+    c0, rel_ = rand_field(70, (nl * nptr, ny, nx), 1e-3), rand_field(71, (nl * nptr, ny, nx), 1e-3)
+    o.set(orc.PTR, c0); g.set(F["PTR"], c0)
+    o.set(orc.PTR_RELAX, rel_); g.set(F["PTR_RELAX"], rel_)
+    d_o = o.update()
+    dq, d_g = g.update()
+    assert d_g == d_o and np.array_equal(dq, o.get(orc.DQ))
+    assert np.array_equal(g.get(F["DPTR"]), o.get(orc.DPTR))
+    o.set_tnext(float("inf")); g.set_tnext(float("inf"))
+    for _ in range(4):
+        o.step(); g.step()
+    assert np.array_equal(g.get(F["PTR"]), o.get(orc.PTR))
+    assert np.array_equal(g.get(F["Q"]), o.get(orc.Q))
+    assert np.abs(g.get(F["PTR"]) - c0).max() > 0
