@@ -18,8 +18,8 @@ class MGStats(C.Structure):
 
 
 def build():
-    src = os.path.join(_ROOT, "oracle", "qg_oracle.c")
-    if (not os.path.exists(_LIB)) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_ROOT, "oracle", f) for f in ("qg_oracle.c", "qgnode_oracle.c")]
+    if (not os.path.exists(_LIB)) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")], stdout=subprocess.DEVNULL)
     return _LIB
 
