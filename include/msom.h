@@ -175,6 +175,78 @@ int msom_profile_read(msom_t *m, const char *kernel, double *avg_ms, long *launc
 int msom_profile_reset(msom_t *m);
 int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double *avg_ms);
 
+/* ======================================================================================
+ * Vertex-grid (masked-domain) variant: qg-node/qg.h + qg_baroclinic_ms.h (nl >= 2) /
+ * qg_barotropic.h (nl = 1) + nodal-poisson.h + my_vertex.h, driver qg-node/qg.c.
+ * Unknowns on the (N+1)^2 vertices; field arrays are fp64 [layer][N+1][N+1]
+ * (qg-node/netcdf_vertex_bas.h:253), host or device pointers.  Single GPU.
+ * ====================================================================================== */
+enum {
+  MSOMN_PSI = 0,   /* psi       stream function                           qg-node/qg.h:130 */
+  MSOMN_Q = 1,     /* q         potential vorticity (evolving)            qg.h:131         */
+  MSOMN_ZETA = 2,  /* zeta      relative vorticity                qg_baroclinic_ms.h:32   */
+  MSOMN_TMP = 3,   /* tmp                                                                  */
+  MSOMN_PSIPG = 4, /* psi_pg    large-scale stream function                                */
+  MSOMN_S2 = 5,    /* S2        N^2 before, f^2/N^2 after set_const; nl-1 layers           */
+  MSOMN_TOPO = 6,  /* topo      1 layer                                                    */
+  MSOMN_QFORC = 7, /* q_forcing 1 layer                                   qg.h:133         */
+  MSOMN_MASK = 8,  /* mask      1 inside / 0 land and boundary, 1 layer   qg.h:134         */
+  MSOMN_DQ = 9,    /* updates                                                              */
+  MSOMN_QPRED = 10,/* predictor                                                            */
+  MSOMN_NFIELDS = 11
+};
+typedef struct msomn msomn_t;
+
+/* read_params (qg-node/extra.h:83-116, key list qg.c:72-107) + init_grid + set_bc/set_vars
+ * (qg.h:404-459, qg_baroclinic_ms.h:400-447): mask = 1 inside and 0 on the boundary
+ * vertices, S2 = N2[l], everything else 0.  Extension: none.  NULL on error. */
+msomn_t *msomn_create(const char *params_path);
+msomn_t *msomn_create_str(const char *params_text);
+void msomn_destroy(msomn_t *m);                                 /* trash_vars qg.h:537-544 */
+/* keys: TOLERANCE NITERMAX NITERMIN (nodal-poisson.h:19-23) DT quiet */
+int msomn_set_option(msomn_t *m, const char *key, double value);
+/* keys: N nl L0 DT tend dtout nlevels iRd2_low bc_fac idh0_<l> idh1_<l>; NaN if unknown */
+double msomn_get_param(msomn_t *m, const char *key);
+int msomn_field_layers(msomn_t *m, int field);
+int msomn_set_field(msomn_t *m, int field, const double *a);   /* a: [layers][N+1][N+1] */
+int msomn_get_field(msomn_t *m, int field, double *a);
+/* init events: layer metrics + S2 = f^2/N^2 + topo scaling (qg_baroclinic_ms.h:449-510),
+ * iRd2_low (qg_barotropic.h:115-118), mask and S2 on every multigrid level, DT limits and
+ * q = comp_q(psi) (set_const, qg.h:465-524).  psi, S2 (= N^2), mask, topo, psi_pg must be
+ * set before; restart / input files are the driver's business (msomn_run). */
+int msomn_set_const(msomn_t *m);
+/* update_qg (qg.h:334-354): invert_q + rhs_pv + adjust_dt; *dt_out = new time step */
+int msomn_update(msomn_t *m, int qfield, int dqfield, double dtmax, double *dt_out);
+int msomn_advance(msomn_t *m, int out, int in, int dq, double dt);        /* advance_qg qg.h:291-302 */
+int msomn_invert_q(msomn_t *m, int qfield, msom_mgstats *stats);           /* qg_baroclinic_ms.h:217-225 */
+int msomn_comp_q(msomn_t *m, int psifield, int qfield);                    /* :199-211 / qg_barotropic.h:32-39 */
+int msomn_rhs_pv(msomn_t *m, int qfield, int dqfield);                     /* :104-196 / qg_barotropic.h:16-29 */
+int msomn_forcing(msomn_t *m);                                             /* event forcing, qg.c:136-145 */
+/* events of iteration i (forcing if with_forcing_event), then one predictor-corrector step of run() */
+int msomn_step(msomn_t *m, int with_forcing_event);
+int msomn_set_tnext(msomn_t *m, double tnext);
+double msomn_time(msomn_t *m);
+double msomn_dt(msomn_t *m);
+int msomn_iter(msomn_t *m);
+int msomn_ke(msomn_t *m, double *ke);                                      /* event writestdout qg.c:171-178 */
+int msomn_last_mgstats(msomn_t *m, msom_mgstats *stats);
+/* NetCDF-3 output / restart of vertex fields (qg-node/netcdf_vertex_bas.h:95-424): one record of
+ * "psi" and "q" appended to `path`; msomn_read_nc loads variable `varname` into `field` */
+int msomn_write_nc(msomn_t *m, const char *path);
+int msomn_read_nc(msomn_t *m, int field, const char *path, const char *varname, int record);
+/* main() + events of qg-node/qg.c: psi = noise_init (noise + sin(2 pi y / L0)) (qg.h:475-479),
+ * restart.nc and input_vars_<nl>l_N<N>.nc when present in the working directory, vars.nc in
+ * <workdir>/outdir_%04d/, one stdout line per iteration; nsteps_max < 0: run to tend.
+ * Returns the iteration count or < 0. */
+int msomn_run(msomn_t *m, const char *workdir, long nsteps_max);
+/* multigrid pieces on level arrays [layer][n_k+1][n_k+1] (level 0 = finest), for the parity tests */
+int msomn_dbg_relax(msomn_t *m, int level, double *da, const double *res, int nsweeps);
+int msomn_dbg_residual(msomn_t *m, const double *a, const double *b, double *res, double *maxres);
+int msomn_dbg_restrict(msomn_t *m, int level_fine, const double *fine, double *coarse);
+int msomn_dbg_prolong(msomn_t *m, int level_coarse, const double *coarse, double *fine);
+int msomn_dbg_level_mask(msomn_t *m, int level, double *out);
+int msomn_dbg_del2_zeta(msomn_t *m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,8 @@ from .api import (  # noqa: F401
     FIELDS,
     MGStats,
     MsomError,
+    NODE_FIELDS,
+    NodeQG,
     QG,
     init_grid,
     load_library,
@@ -25,6 +27,6 @@ from .api import (  # noqa: F401
 )
 
 __all__ = [
-    "QG", "MGStats", "MsomError", "FIELDS", "load_library", "read_params", "init_grid", "set_vars",
+    "QG", "NodeQG", "NODE_FIELDS", "MGStats", "MsomError", "FIELDS", "load_library", "read_params", "init_grid", "set_vars",
     "set_vars_bfn", "set_const", "pystep_bfn", "pyq2p", "pyp2q", "trash_vars", "trash_vars_bfn",
 ]

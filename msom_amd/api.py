@@ -86,6 +86,38 @@ def load_library(strict=False):
         "msom_profile_read": (ci, [vp, cs, _dp, C.POINTER(C.c_long)]),
         "msom_profile_reset": (ci, [vp]),
         "msom_bench_kernel": (ci, [vp, cs, ci, _dp]),
+        # vertex-grid variant (qg-node/)
+        "msomn_create": (vp, [cs]),
+        "msomn_create_str": (vp, [cs]),
+        "msomn_destroy": (None, [vp]),
+        "msomn_set_option": (ci, [vp, cs, cd]),
+        "msomn_get_param": (cd, [vp, cs]),
+        "msomn_field_layers": (ci, [vp, ci]),
+        "msomn_set_field": (ci, [vp, ci, vp]),
+        "msomn_get_field": (ci, [vp, ci, vp]),
+        "msomn_set_const": (ci, [vp]),
+        "msomn_update": (ci, [vp, ci, ci, cd, _dp]),
+        "msomn_advance": (ci, [vp, ci, ci, ci, cd]),
+        "msomn_invert_q": (ci, [vp, ci, C.POINTER(MGStats)]),
+        "msomn_comp_q": (ci, [vp, ci, ci]),
+        "msomn_rhs_pv": (ci, [vp, ci, ci]),
+        "msomn_forcing": (ci, [vp]),
+        "msomn_step": (ci, [vp, ci]),
+        "msomn_set_tnext": (ci, [vp, cd]),
+        "msomn_time": (cd, [vp]),
+        "msomn_dt": (cd, [vp]),
+        "msomn_iter": (ci, [vp]),
+        "msomn_ke": (ci, [vp, _dp]),
+        "msomn_last_mgstats": (ci, [vp, C.POINTER(MGStats)]),
+        "msomn_write_nc": (ci, [vp, cs]),
+        "msomn_read_nc": (ci, [vp, ci, cs, cs, ci]),
+        "msomn_run": (ci, [vp, cs, C.c_long]),
+        "msomn_dbg_relax": (ci, [vp, ci, vp, vp, ci]),
+        "msomn_dbg_residual": (ci, [vp, vp, vp, vp, _dp]),
+        "msomn_dbg_restrict": (ci, [vp, ci, vp, vp]),
+        "msomn_dbg_prolong": (ci, [vp, ci, vp, vp]),
+        "msomn_dbg_level_mask": (ci, [vp, ci, vp]),
+        "msomn_dbg_del2_zeta": (ci, [vp]),
     }
     for fn, (res, args) in sig.items():
         f = getattr(L, fn)  # AttributeError if the library does not export a declared symbol
@@ -368,3 +400,161 @@ def trash_vars():
 
 def trash_vars_bfn():
     return None
+
+
+NODE_FIELDS = dict(PSI=0, Q=1, ZETA=2, TMP=3, PSIPG=4, S2=5, TOPO=6, QFORC=7, MASK=8, DQ=9, QPRED=10)
+
+
+class NodeQG:
+    """Vertex-grid (masked-domain) model: one `qg.e` process of qg-node/qg.c.  Field arrays are
+    [layers][N+1][N+1] (qg-node/netcdf_vertex_bas.h:253)."""
+
+    def __init__(self, params=None, path=None, strict=False):
+        self.L = load_library(strict)
+        self.h = self.L.msomn_create(path.encode()) if path is not None else self.L.msomn_create_str(params.encode())
+        if not self.h:
+            raise MsomError(self.L.msom_last_error().decode())
+        self.N, self.nl = int(self.param("N")), int(self.param("nl"))
+        self.nlevels = int(self.param("nlevels"))
+
+    def close(self):
+        if self.h:
+            self.L.msomn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r != 0:
+            raise MsomError(f"error {r}: {self.L.msom_last_error().decode()}")
+
+    def _fid(self, f):
+        return NODE_FIELDS[f] if isinstance(f, str) else int(f)
+
+    def param(self, key):
+        return self.L.msomn_get_param(self.h, key.encode())
+
+    def set_option(self, key, v):
+        self._chk(self.L.msomn_set_option(self.h, key.encode(), float(v)))
+
+    def layers(self, f):
+        return self.L.msomn_field_layers(self.h, self._fid(f))
+
+    def shape(self, f):
+        return (self.layers(f), self.N + 1, self.N + 1)
+
+    def set(self, f, a):
+        a = _f64(a, self.shape(f))
+        self._chk(self.L.msomn_set_field(self.h, self._fid(f), _ptr(a)))
+
+    def get(self, f):
+        a = np.empty(self.shape(f))
+        self._chk(self.L.msomn_get_field(self.h, self._fid(f), _ptr(a)))
+        return a
+
+    def set_const(self):
+        self._chk(self.L.msomn_set_const(self.h))
+
+    def update(self, q="Q", dq="DQ", dtmax=None):
+        dt = C.c_double()
+        self._chk(self.L.msomn_update(self.h, self._fid(q), self._fid(dq), self.param("DT") if dtmax is None else dtmax, C.byref(dt)))
+        return dt.value
+
+    def advance(self, out, inp, dq, dt):
+        self._chk(self.L.msomn_advance(self.h, self._fid(out), self._fid(inp), self._fid(dq), dt))
+
+    def invert_q(self, q="Q"):
+        st = MGStats()
+        self._chk(self.L.msomn_invert_q(self.h, self._fid(q), C.byref(st)))
+        return st
+
+    def comp_q(self, psi="PSI", q="Q"):
+        self._chk(self.L.msomn_comp_q(self.h, self._fid(psi), self._fid(q)))
+
+    def rhs_pv(self, q="Q", dq="DQ"):
+        self._chk(self.L.msomn_rhs_pv(self.h, self._fid(q), self._fid(dq)))
+
+    def forcing(self):
+        self._chk(self.L.msomn_forcing(self.h))
+
+    def step(self, with_forcing_event=False):
+        self._chk(self.L.msomn_step(self.h, int(with_forcing_event)))
+
+    def set_tnext(self, t):
+        self._chk(self.L.msomn_set_tnext(self.h, t))
+
+    @property
+    def t(self):
+        return self.L.msomn_time(self.h)
+
+    @property
+    def dt(self):
+        return self.L.msomn_dt(self.h)
+
+    @property
+    def iter(self):
+        return self.L.msomn_iter(self.h)
+
+    def ke(self):
+        v = C.c_double()
+        self._chk(self.L.msomn_ke(self.h, C.byref(v)))
+        return v.value
+
+    def mgstats(self):
+        st = MGStats()
+        self._chk(self.L.msomn_last_mgstats(self.h, C.byref(st)))
+        return st
+
+    def write_nc(self, path):
+        self._chk(self.L.msomn_write_nc(self.h, path.encode()))
+
+    def read_nc(self, f, path, var, record=-1):
+        self._chk(self.L.msomn_read_nc(self.h, self._fid(f), path.encode(), var.encode(), record))
+
+    def run(self, workdir=".", nsteps_max=-1):
+        r = self.L.msomn_run(self.h, workdir.encode(), nsteps_max)
+        if r < 0:
+            self._chk(r)
+        return r
+
+    # multigrid pieces (parity tests); level k has (N >> k) + 1 vertices per side
+    def _lshape(self, k, nl=None):
+        n1 = (self.N >> k) + 1
+        return (self.nl if nl is None else nl, n1, n1)
+
+    def dbg_relax(self, k, da, res, nsweeps):
+        da = np.array(_f64(da, self._lshape(k)))
+        res = _f64(res, self._lshape(k))
+        self._chk(self.L.msomn_dbg_relax(self.h, k, _ptr(da), _ptr(res), nsweeps))
+        return da
+
+    def dbg_residual(self, a, b):
+        a, b = _f64(a, self._lshape(0)), _f64(b, self._lshape(0))
+        res = np.empty(self._lshape(0))
+        mx = C.c_double()
+        self._chk(self.L.msomn_dbg_residual(self.h, _ptr(a), _ptr(b), _ptr(res), C.byref(mx)))
+        return res, mx.value
+
+    def dbg_restrict(self, k, fine):
+        fine = _f64(fine, self._lshape(k))
+        out = np.empty(self._lshape(k + 1))
+        self._chk(self.L.msomn_dbg_restrict(self.h, k, _ptr(fine), _ptr(out)))
+        return out
+
+    def dbg_prolong(self, k, coarse):
+        coarse = _f64(coarse, self._lshape(k))
+        out = np.empty(self._lshape(k - 1))
+        self._chk(self.L.msomn_dbg_prolong(self.h, k, _ptr(coarse), _ptr(out)))
+        return out
+
+    def dbg_level_mask(self, k):
+        out = np.empty(self._lshape(k, 1))
+        self._chk(self.L.msomn_dbg_level_mask(self.h, k, _ptr(out)))
+        return out
+
+    def dbg_del2_zeta(self):
+        self._chk(self.L.msomn_dbg_del2_zeta(self.h))

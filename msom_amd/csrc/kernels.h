@@ -83,4 +83,29 @@ void launch_relax_red_prolong(hipStream_t st, double *da, const double *coarse, 
                               const SplitGeom &sg, int nl, const RelaxCoef &rc, int uniformS, int walls);
 void launch_correct(hipStream_t st, double *a, const NatGeom &g, const double *da, const SplitGeom &sg, int nl, int walls);
 
+// ---- kernels_node.hip (vertex-grid variant, qg-node/)
+void launch_n_bnd_from(hipStream_t st, double *f, const double *g, const NatGeom &ge, int nl, double c, int use_g_bnd, double gbc);
+void launch_n_bnd_const(hipStream_t st, double *f, const NatGeom &ge, int nl, double v);
+void launch_n_mul_mask(hipStream_t st, double *a, double *b, const double *mk, const NatGeom &g, int nl);
+void launch_n_del2(hipStream_t st, const double *in, double *out, const NatGeom &g, int nl, double add, double fac, double D);
+void launch_n_stretch(hipStream_t st, const double *in, double *out, const double *S2, const NatGeom &g, int nl, double add, double fac,
+                      const LayerCoef &lc);
+void launch_n_rhs_main(hipStream_t st, const double *psi, const double *zeta, const double *pg, const double *S2, const double *topo, double *dq,
+                       const NatGeom &g, int nl, int have_pg, int have_topo, double D, double beta, double drag, double f0, double dhb, const LayerCoef &lc);
+void launch_n_axpy(hipStream_t st, double *dq, const double *x, const NatGeom &g, int nl, double c);
+void launch_n_add2d(hipStream_t st, double *dq, const double *qf, const NatGeom &g);
+void launch_n_rhs_barotropic(hipStream_t st, const double *psi, const double *q, const double *qf, double *dq, const NatGeom &g, double D, double beta,
+                             double drag, double nu);
+void launch_n_helm(hipStream_t st, const double *psi, double *q, const NatGeom &g, double D, double iRd2);
+void launch_n_rowfill(hipStream_t st, double *f, const double *row, const NatGeom &g);
+void launch_n_relax(hipStream_t st, double *a, const double *b, const double *mk, const double *S2, const NatGeom &g, int nl, int color, double D,
+                    double iRd2, const LayerCoef &lc);
+void launch_n_residual(hipStream_t st, const double *a, const double *b, const double *mk, const double *S2, double *res, double *maxres,
+                       const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc);
+void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind);
+void launch_n_prolong(hipStream_t st, const double *c, const NatGeom &cg, double *f, const NatGeom &fg, int nl);
+void launch_n_correct(hipStream_t st, double *a, const double *da, const NatGeom &g, int nl, double bcv);
+void launch_n_umax(hipStream_t st, const double *psi, double *out, const NatGeom &g, int nl, double D);
+void launch_n_ke(hipStream_t st, const double *psi, double *partial, double *out, const NatGeom &g, double D);
+
 #endif

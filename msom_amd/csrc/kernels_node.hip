@@ -1,0 +1,423 @@
+// kernels_node.hip -- HIP kernels of the VERTEX-grid (masked) QG variant of the reference:
+// qg-node/qg.h, qg-node/qg_baroclinic_ms.h (-DLAYERS=1, nl >= 2), qg-node/qg_barotropic.h
+// (nl = 1), qg-node/nodal-poisson.h, qg-node/my_vertex.h.
+//
+// Unknowns on the (N+1)^2 vertices x = i D, y = j D (i, j = 0..N), stored in the natural padded
+// layout with nx = ny = N + 1 (pad cells stay 0: they are the never-defined values outside the
+// boundary vertices).  One thread per vertex walks the layers.  Everything is multiplied by
+// `mask` (1 inside, 0 on boundary vertices and land; fractional on coarse multigrid levels).
+// Boundary vertices carry the boundary conditions (psi = psi_bc, q = zeta =
+// 2 bc_fac / D^2 (psi_first_interior - psi_bc), qg-node/qg.h:197-214).
+// Smoother: the reference's relax_baroclinic is a lexicographic Gauss-Seidel over all
+// vertices with a Thomas solve per column (qg_baroclinic_ms.h:228-291); here the same column
+// solve in red-black order ((i + j) even first), as for the cell-centred model.
+#include "kernels.h"
+
+#ifdef MSOM_STRICT
+#define DIVC(x, c, rc) ((x) / (c))
+#else
+#define DIVC(x, c, rc) ((x) * (rc))
+#endif
+#define BX 64
+#define BY 4
+static inline dim3 grid2d(int nx, int ny) { return dim3((nx + BX - 1) / BX, (ny + BY - 1) / BY); }
+static inline dim3 block2d() { return dim3(BX, BY); }
+#define VTX(g, i, j) const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y; if (i >= (g).nx || j >= (g).ny) return
+
+__device__ __forceinline__ double wave_max_n(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64)); return v; }
+__device__ __forceinline__ double wave_sum_n(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; }
+
+#define LAPN(p, c, pitch) ((p)[(c) + 1] + (p)[(c)-1] + (p)[(c) + (pitch)] + (p)[(c) - (pitch)] - 4 * (p)[c])
+// +J(p,q), qg-node/qg.h:178-188
+__device__ __forceinline__ double jacn(const double *__restrict__ p, const double *__restrict__ q, size_t c, int pitch, double D12, double rD12) {
+#define P(a, b) p[c + (a) + (ptrdiff_t)(b)*pitch]
+#define Q(a, b) q[c + (a) + (ptrdiff_t)(b)*pitch]
+  const double s = (P(1, 0) - P(-1, 0)) * (Q(0, 1) - Q(0, -1)) + (P(0, -1) - P(0, 1)) * (Q(1, 0) - Q(-1, 0)) + P(1, 0) * (Q(1, 1) - Q(1, -1)) -
+                   P(-1, 0) * (Q(-1, 1) - Q(-1, -1)) - P(0, 1) * (Q(1, 1) - Q(-1, 1)) + P(0, -1) * (Q(1, -1) - Q(-1, -1)) +
+                   Q(0, 1) * (P(1, 1) - P(-1, 1)) - Q(0, -1) * (P(1, -1) - P(-1, -1)) - Q(1, 0) * (P(1, 1) - P(1, -1)) +
+                   Q(-1, 0) * (P(-1, 1) - P(-1, -1));
+#undef P
+#undef Q
+  return DIVC(s, D12, rD12);
+}
+
+// ---------------------------------------------------------------- boundary vertices
+// f_bnd = c * (g_first_interior - (use_g_bnd ? g_bnd : gbc)); x sides first, then y sides (corners
+// end up with the y rule).  One thread per boundary vertex and layer.
+__global__ void k_n_bnd_from(double *f, const double *g, NatGeom ge, int nl, double c, int use_g_bnd, double gbc) {
+  const int n = ge.nx - 1, per = 4 * n;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per * nl) return;
+  const int l = t / per, r = t % per;
+  int i, j, ii, jj;  // boundary vertex and its first interior neighbour
+  if (r < 2 * (n + 1)) {  // y sides, all i (corners included -> y rule)
+    i = ii = r >> 1;
+    if (r & 1) { j = n; jj = n - 1; } else { j = 0; jj = 1; }
+  } else {  // x sides without the corners
+    const int q = r - 2 * (n + 1);
+    j = jj = 1 + (q >> 1);
+    if (q & 1) { i = n; ii = n - 1; } else { i = 0; ii = 1; }
+  }
+  const size_t b = nat_idx(ge, l, j, i);
+  // corner: the y rule reads g at (i, jj), which is an x-side boundary vertex; for use_g_bnd its
+  // value must be the one the x pass gave it -- g is a different field here (zeta for tmp), so ok
+  f[b] = c * (g[nat_idx(ge, l, jj, ii)] - (use_g_bnd ? g[b] : gbc));
+}
+void launch_n_bnd_from(hipStream_t st, double *f, const double *g, const NatGeom &ge, int nl, double c, int use_g_bnd, double gbc) {
+  const int n = 4 * (ge.nx - 1) * nl;
+  hipLaunchKernelGGL(k_n_bnd_from, dim3((n + 255) / 256), dim3(256), 0, st, f, g, ge, nl, c, use_g_bnd, gbc);
+}
+__global__ void k_n_bnd_const(double *f, NatGeom ge, int nl, double v) {
+  const int n = ge.nx - 1, per = 4 * n;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per * nl) return;
+  const int l = t / per, r = t % per;
+  int i, j;
+  if (r < 2 * (n + 1)) { i = r >> 1; j = (r & 1) ? n : 0; } else { const int q = r - 2 * (n + 1); j = 1 + (q >> 1); i = (q & 1) ? n : 0; }
+  f[nat_idx(ge, l, j, i)] = v;
+}
+void launch_n_bnd_const(hipStream_t st, double *f, const NatGeom &ge, int nl, double v) {
+  const int n = 4 * (ge.nx - 1) * nl;
+  hipLaunchKernelGGL(k_n_bnd_const, dim3((n + 255) / 256), dim3(256), 0, st, f, ge, nl, v);
+}
+
+// ---------------------------------------------------------------- pointwise / stencil operators
+__global__ void k_n_mul_mask(double *a, double *b, const double *__restrict__ mk, NatGeom g, int nl) {
+  VTX(g, i, j);
+  const size_t c0 = nat_idx(g, 0, j, i);
+  const double m = mk[c0];
+  for (int l = 0; l < nl; l++) { a[c0 + l * g.ls] *= m; if (b) b[c0 + l * g.ls] *= m; }
+}
+void launch_n_mul_mask(hipStream_t st, double *a, double *b, const double *mk, const NatGeom &g, int nl) {
+  hipLaunchKernelGGL(k_n_mul_mask, grid2d(g.nx, g.ny), block2d(), 0, st, a, b, mk, g, nl);
+}
+__global__ void k_n_del2(const double *__restrict__ in, double *out, NatGeom g, int nl, double add, double fac, double D2, double rD2) {
+  VTX(g, i, j);
+  size_t c = nat_idx(g, 0, j, i);
+  for (int l = 0; l < nl; l++, c += g.ls) {
+    const double lap = DIVC(LAPN(in, c, g.pitch), D2, rD2);
+    out[c] = add == 0. ? fac * lap : add * out[c] + fac * lap;
+  }
+}
+void launch_n_del2(hipStream_t st, const double *in, double *out, const NatGeom &g, int nl, double add, double fac, double D) {
+  hipLaunchKernelGGL(k_n_del2, grid2d(g.nx, g.ny), block2d(), 0, st, in, out, g, nl, add, fac, D * D, 1. / (D * D));
+}
+// comp_stretch qg_baroclinic_ms.h:79-100
+__global__ void k_n_stretch(const double *__restrict__ in, double *out, const double *__restrict__ S2, NatGeom g, int nl, double add, double fac,
+                            LayerCoef lc) {
+  VTX(g, i, j);
+  const size_t c0 = nat_idx(g, 0, j, i);
+  double pm = 0., pc = in[c0], pp = 0., s0 = 0., s1 = 0.;
+  for (int l = 0; l < nl; l++) {
+    const size_t c = c0 + (size_t)l * g.ls;
+    if (l < nl - 1) { pp = in[c + g.ls]; s1 = S2[c]; }
+    double v;
+    if (l == 0) v = fac * s1 * (pp - pc) * lc.idh1[l];
+    else if (l < nl - 1) v = fac * (s0 * (pm - pc) * lc.idh0[l] + s1 * (pp - pc) * lc.idh1[l]);
+    else v = fac * s0 * (pm - pc) * lc.idh0[l];
+    out[c] = add == 0. ? v : add * out[c] + v;
+    pm = pc; pc = pp; s0 = s1;
+  }
+}
+void launch_n_stretch(hipStream_t st, const double *in, double *out, const double *S2, const NatGeom &g, int nl, double add, double fac,
+                      const LayerCoef &lc) {
+  hipLaunchKernelGGL(k_n_stretch, grid2d(g.nx, g.ny), block2d(), 0, st, in, out, S2, g, nl, add, fac, lc);
+}
+
+// advective part of rhs_pv_baroclinic, qg_baroclinic_ms.h:116-155
+struct NRhsArgs {
+  const double *psi, *zeta, *pg, *S2, *topo;
+  double *dq;
+  NatGeom g;
+  int nl, have_pg, have_topo;
+  double D, beta, drag, f0, dhb;  // drag = hEkb*f0/(2*dh_b)
+  LayerCoef lc;
+};
+__global__ void k_n_rhs_main(NRhsArgs a) {
+  VTX(a.g, i, j);
+  const int nl = a.nl, pitch = a.g.pitch;
+  const size_t ls = a.g.ls;
+  const double D12 = 12. * a.D * a.D, rD12 = 1. / D12, D2x = 2 * a.D, rD2x = 1. / D2x;
+  size_t c = nat_idx(a.g, 0, j, i);
+  const size_t c0 = c;
+  double ju = 0., jd = 0.;
+  for (int l = 0; l < nl; l++, c += ls) {
+    ju = -jd;
+    if (l < nl - 1) {
+      jd = jacn(a.psi, a.psi + ls, c, pitch, D12, rD12);
+      if (a.have_pg) jd = jd + jacn(a.pg, a.psi + ls, c, pitch, D12, rD12) + jacn(a.psi, a.pg + ls, c, pitch, D12, rD12);
+    }
+    double d = -jacn(a.psi, a.zeta, c, pitch, D12, rD12);
+    if (a.have_pg) d = d - jacn(a.pg, a.zeta, c, pitch, D12, rD12);
+    if (l < nl - 1) d = d - a.S2[c] * jd * a.lc.idh1[l];
+    if (l > 0) d = d - a.S2[c - ls] * ju * a.lc.idh0[l];
+    d = d - DIVC(a.beta * (a.psi[c + 1] - a.psi[c - 1]), D2x, rD2x);
+    if (l == nl - 1) {  // bottom friction and topography, :150
+      double e = -a.drag * a.zeta[c];
+      if (a.have_topo) {
+        const double jt = jacn(a.psi + (size_t)l * ls, a.topo, c0, pitch, D12, rD12);
+#ifdef MSOM_STRICT
+        e = e - jt * a.f0 / a.dhb;
+#else
+        e = e - jt * (a.f0 / a.dhb);
+#endif
+      }
+      d += e;
+    }
+    a.dq[c] = d;
+  }
+}
+void launch_n_rhs_main(hipStream_t st, const double *psi, const double *zeta, const double *pg, const double *S2, const double *topo, double *dq,
+                       const NatGeom &g, int nl, int have_pg, int have_topo, double D, double beta, double drag, double f0, double dhb, const LayerCoef &lc) {
+  NRhsArgs a;
+  a.psi = psi; a.zeta = zeta; a.pg = pg; a.S2 = S2; a.topo = topo; a.dq = dq; a.g = g; a.nl = nl; a.have_pg = have_pg; a.have_topo = have_topo;
+  a.D = D; a.beta = beta; a.drag = drag; a.f0 = f0; a.dhb = dhb; a.lc = lc;
+  hipLaunchKernelGGL(k_n_rhs_main, grid2d(g.nx, g.ny), block2d(), 0, st, a);
+}
+// dq += c * x   /   dq_0 += qf   /   rhs_pv_barotropic (qg_barotropic.h:16-29)
+__global__ void k_n_axpy(double *dq, const double *__restrict__ x, NatGeom g, int nl, double c) {
+  VTX(g, i, j);
+  size_t k = nat_idx(g, 0, j, i);
+  for (int l = 0; l < nl; l++, k += g.ls) dq[k] += c * x[k];
+}
+void launch_n_axpy(hipStream_t st, double *dq, const double *x, const NatGeom &g, int nl, double c) {
+  hipLaunchKernelGGL(k_n_axpy, grid2d(g.nx, g.ny), block2d(), 0, st, dq, x, g, nl, c);
+}
+__global__ void k_n_add2d(double *dq, const double *__restrict__ qf, NatGeom g) {
+  VTX(g, i, j);
+  const size_t k = nat_idx(g, 0, j, i);
+  dq[k] += qf[k];
+}
+void launch_n_add2d(hipStream_t st, double *dq, const double *qf, const NatGeom &g) { hipLaunchKernelGGL(k_n_add2d, grid2d(g.nx, g.ny), block2d(), 0, st, dq, qf, g); }
+__global__ void k_n_rhs_barotropic(const double *__restrict__ psi, const double *__restrict__ q, const double *__restrict__ qf, double *dq, NatGeom g,
+                                   double D, double beta, double drag, double nu) {
+  VTX(g, i, j);
+  const size_t c = nat_idx(g, 0, j, i);
+  const double D12 = 12. * D * D, D2 = D * D, D2x = 2 * D;
+  dq[c] = -jacn(psi, q, c, g.pitch, D12, 1. / D12) - DIVC(beta * (psi[c + 1] - psi[c - 1]), D2x, 1. / D2x) - drag * q[c] + qf[c] +
+          nu * DIVC(LAPN(q, c, g.pitch), D2, 1. / D2);
+}
+void launch_n_rhs_barotropic(hipStream_t st, const double *psi, const double *q, const double *qf, double *dq, const NatGeom &g, double D, double beta,
+                             double drag, double nu) {
+  hipLaunchKernelGGL(k_n_rhs_barotropic, grid2d(g.nx, g.ny), block2d(), 0, st, psi, q, qf, dq, g, D, beta, drag, nu);
+}
+// q = lap(psi) - iRd2 psi (nl = 1)   qg_barotropic.h:32-39
+__global__ void k_n_helm(const double *__restrict__ psi, double *q, NatGeom g, double D2, double rD2, double iRd2) {
+  VTX(g, i, j);
+  const size_t c = nat_idx(g, 0, j, i);
+  q[c] = DIVC(LAPN(psi, c, g.pitch), D2, rD2) - iRd2 * psi[c];
+}
+void launch_n_helm(hipStream_t st, const double *psi, double *q, const NatGeom &g, double D, double iRd2) {
+  hipLaunchKernelGGL(k_n_helm, grid2d(g.nx, g.ny), block2d(), 0, st, psi, q, g, D * D, 1. / (D * D), iRd2);
+}
+__global__ void k_n_rowfill(double *f, const double *__restrict__ row, NatGeom g) {
+  VTX(g, i, j);
+  f[nat_idx(g, 0, j, i)] = row[j];
+}
+void launch_n_rowfill(hipStream_t st, double *f, const double *row, const NatGeom &g) { hipLaunchKernelGGL(k_n_rowfill, grid2d(g.nx, g.ny), block2d(), 0, st, f, row, g); }
+
+// ---------------------------------------------------------------- vertex multigrid
+struct NRelaxArgs {
+  double *a;
+  const double *b, *mk, *S2;
+  NatGeom g;
+  int color;
+  double sqD, iRd2;
+  LayerCoef lc;
+};
+// one colour of relax_baroclinic (qg_baroclinic_ms.h:228-291) / relax_barotropic (qg_barotropic.h:57-76)
+// on the interior vertices; boundary vertices of the correction stay 0 (homogeneous psi BC).
+template <int NL>
+__global__ void __launch_bounds__(BX *BY) k_n_relax(NRelaxArgs p) {
+  const int n = p.g.nx - 1;
+  const int j = 1 + blockIdx.y * BY + threadIdx.y;
+  const int i = 1 + 2 * (blockIdx.x * BX + threadIdx.x) + ((j + p.color + 1) & 1);  // (i + j) & 1 == color
+  if (i >= n || j >= n) return;
+  const int pitch = p.g.pitch;
+  const size_t ls = p.g.ls, c = nat_idx(p.g, 0, j, i);
+  const double sq = p.sqD, m = p.mk[c];
+  if (NL == 1) {
+    double d = -(-p.iRd2) * sq, v = -p.b[c] * sq;
+    v += (p.a[c + 1] + p.a[c - 1]) * m; d += 2.;
+    v += (p.a[c + pitch] + p.a[c - pitch]) * m; d += 2.;
+    p.a[c] = v / d;
+    return;
+  }
+  double t0[NL], t1[NL], t2[NL], rhs[NL], x[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    const size_t k = c + l * ls;
+    rhs[l] = -sq * p.b[k] * m;
+    t0[l] = l == 0 ? 0. : (l < NL - 1 ? -sq * p.S2[k - ls] * p.lc.idh0[l] * m : -sq * p.S2[k - ls] * p.lc.idh0[l]);  // bottom t0 not masked, :267
+    t2[l] = l < NL - 1 ? -sq * p.S2[k] * p.lc.idh1[l] * m : 0.;
+    t1[l] = l == 0 ? -t2[l] : (l < NL - 1 ? -t0[l] - t2[l] : -t0[l]);
+    rhs[l] += (p.a[k + 1] + p.a[k - 1]) * m; t1[l] += 2;
+    rhs[l] += (p.a[k + pitch] + p.a[k - pitch]) * m; t1[l] += 2;
+  }
+#pragma unroll
+  for (int l = 1; l < NL; l++) { t1[l] -= t0[l] * t2[l - 1] / t1[l - 1]; rhs[l] -= t0[l] * rhs[l - 1] / t1[l - 1]; }
+  x[NL - 1] = rhs[NL - 1] / t1[NL - 1];
+#pragma unroll
+  for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - t2[l] * x[l + 1]) / t1[l];
+#pragma unroll
+  for (int l = 0; l < NL; l++) p.a[c + l * ls] = x[l];
+}
+void launch_n_relax(hipStream_t st, double *a, const double *b, const double *mk, const double *S2, const NatGeom &g, int nl, int color, double D,
+                    double iRd2, const LayerCoef &lc) {
+  NRelaxArgs p;
+  p.a = a; p.b = b; p.mk = mk; p.S2 = S2; p.g = g; p.color = color; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc;
+  const int n = g.nx - 1;
+  dim3 gr = grid2d((n + 1) / 2, n - 1);
+  switch (nl) {
+    case 1: hipLaunchKernelGGL(k_n_relax<1>, gr, block2d(), 0, st, p); break;
+    case 2: hipLaunchKernelGGL(k_n_relax<2>, gr, block2d(), 0, st, p); break;
+    case 3: hipLaunchKernelGGL(k_n_relax<3>, gr, block2d(), 0, st, p); break;
+    case 4: hipLaunchKernelGGL(k_n_relax<4>, gr, block2d(), 0, st, p); break;
+    case 5: hipLaunchKernelGGL(k_n_relax<5>, gr, block2d(), 0, st, p); break;
+    case 6: hipLaunchKernelGGL(k_n_relax<6>, gr, block2d(), 0, st, p); break;
+    case 7: hipLaunchKernelGGL(k_n_relax<7>, gr, block2d(), 0, st, p); break;
+    case 8: hipLaunchKernelGGL(k_n_relax<8>, gr, block2d(), 0, st, p); break;
+    default: break;
+  }
+}
+// residual_baroclinic qg_baroclinic_ms.h:295-341 / residual_barotropic qg_barotropic.h:78-97; max -> *maxres
+struct NResArgs {
+  const double *a, *b, *mk, *S2;
+  double *res, *maxres;
+  NatGeom g;
+  int nl;
+  double sqD, iRd2;
+  LayerCoef lc;
+};
+__global__ void k_n_residual(NResArgs p) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  double mx = 0.;
+  if (i < p.g.nx && j < p.g.ny) {
+    const int nl = p.nl, pitch = p.g.pitch;
+    const size_t ls = p.g.ls, c0 = nat_idx(p.g, 0, j, i);
+    const double m = p.mk[c0], sq = p.sqD, rsq = 1. / sq;
+    for (int l = 0; l < nl; l++) {
+      const size_t c = c0 + l * ls;
+      const double a1 = p.a[c];
+      double r;
+      if (nl == 1) r = (p.b[c] - (-p.iRd2 * a1)) * m;
+      else if (l == 0) r = (p.b[c] + p.S2[c] * (a1 - p.a[c + ls]) * p.lc.idh1[l]) * m;
+      else if (l < nl - 1) r = (p.b[c] + p.S2[c - ls] * (a1 - p.a[c - ls]) * p.lc.idh0[l] - p.S2[c] * (p.a[c + ls] - a1) * p.lc.idh1[l]) * m;
+      else r = (p.b[c] + p.S2[c - ls] * (a1 - p.a[c - ls]) * p.lc.idh0[l]) * m;
+      r -= DIVC(p.a[c - 1] - 2. * a1 + p.a[c + 1], sq, rsq) * m;
+      r -= DIVC(p.a[c - pitch] - 2. * a1 + p.a[c + pitch], sq, rsq) * m;
+      p.res[c] = r;
+      mx = fmax(mx, fabs(r));
+    }
+  }
+  __shared__ double sm[BY];
+  mx = wave_max_n(mx);
+  if (threadIdx.x == 0) sm[threadIdx.y] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    double v = sm[0];
+    for (int k = 1; k < BY; k++) v = fmax(v, sm[k]);
+    atomicMax((unsigned long long *)p.maxres, (unsigned long long)__double_as_longlong(v));
+  }
+}
+void launch_n_residual(hipStream_t st, const double *a, const double *b, const double *mk, const double *S2, double *res, double *maxres,
+                       const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc) {
+  NResArgs p;
+  p.a = a; p.b = b; p.mk = mk; p.S2 = S2; p.res = res; p.maxres = maxres; p.g = g; p.nl = nl; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc;
+  hipLaunchKernelGGL(k_n_residual, grid2d(g.nx, g.ny), block2d(), 0, st, p);
+}
+// restriction_coarsen_vert (residual), restriction_coarsen_vert2 (mask), restriction_vert (injection), my_vertex.h:49-75
+__global__ void k_n_restrict(const double *__restrict__ f, NatGeom fg, double *c, NatGeom cg, int nl, int kind) {
+  VTX(cg, I, J);
+  for (int l = 0; l < nl; l++) {
+    const size_t k = nat_idx(fg, l, 2 * J, 2 * I);
+    const int p = fg.pitch;
+    double v;
+    if (kind == 0) v = (f[k + 1] + 2 * f[k] + f[k - 1] + f[k + p] + f[k - p]) / 6.;
+    else if (kind == 1)
+      v = (4 * f[k] + 2 * f[k + 1] + 2 * f[k - 1] + 2 * f[k + p] + 2 * f[k - p] + f[k + 1 + p] + f[k - 1 + p] + f[k + 1 - p] + f[k - 1 - p]) / 16.;
+    else v = f[k];
+    c[nat_idx(cg, l, J, I)] = v;
+  }
+}
+void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind) {
+  hipLaunchKernelGGL(k_n_restrict, grid2d(cg.nx, cg.ny), block2d(), 0, st, f, fg, c, cg, nl, kind);
+}
+// refine_vert my_vertex.h:82-105 followed by boundary_level(da) = 0 on the boundary vertices; one thread per FINE vertex
+__global__ void k_n_prolong(const double *__restrict__ c, NatGeom cg, double *f, NatGeom fg, int nl) {
+  VTX(fg, i, j);
+  const int n = fg.nx - 1, I = i >> 1, J = j >> 1;
+  const bool bnd = i == 0 || j == 0 || i == n || j == n;
+  for (int l = 0; l < nl; l++) {
+    const size_t k = nat_idx(cg, l, J, I);
+    double v;
+    if (bnd) v = 0.;
+    else if (!(i & 1) && !(j & 1)) v = c[k];
+    else if ((i & 1) && !(j & 1)) v = (c[k] + c[k + 1]) / 2.;
+    else if (!(i & 1)) v = (c[k] + c[k + cg.pitch]) / 2.;
+    else v = (c[k] + c[k + 1] + c[k + cg.pitch] + c[k + 1 + cg.pitch]) / 4.;
+    f[nat_idx(fg, l, j, i)] = v;
+  }
+}
+void launch_n_prolong(hipStream_t st, const double *c, const NatGeom &cg, double *f, const NatGeom &fg, int nl) {
+  hipLaunchKernelGGL(k_n_prolong, grid2d(fg.nx, fg.ny), block2d(), 0, st, c, cg, f, fg, nl);
+}
+// a += da, then boundary(a): psi_bc on the boundary vertices (nodal-poisson.h:119-128)
+__global__ void k_n_correct(double *a, const double *__restrict__ da, NatGeom g, int nl, double bcv) {
+  VTX(g, i, j);
+  const int n = g.nx - 1;
+  const bool bnd = i == 0 || j == 0 || i == n || j == n;
+  size_t k = nat_idx(g, 0, j, i);
+  for (int l = 0; l < nl; l++, k += g.ls) a[k] = bnd ? bcv : a[k] + da[k];
+}
+void launch_n_correct(hipStream_t st, double *a, const double *da, const NatGeom &g, int nl, double bcv) {
+  hipLaunchKernelGGL(k_n_correct, grid2d(g.nx, g.ny), block2d(), 0, st, a, da, g, nl, bcv);
+}
+// adjust_dt qg-node/qg.h:258-284: max |psi[0,1] - psi[]| / D and |psi[1,0] - psi[]| / D over faces and layers
+__global__ void k_n_umax(const double *__restrict__ psi, double *out, NatGeom g, int nl, double D) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  double m = 0.;
+  if (i < g.nx && j < g.ny) {
+    const double rD = 1. / D;
+    for (int l = 0; l < nl; l++) {
+      const size_t c = nat_idx(g, l, j, i);
+      if (j < g.ny - 1) m = fmax(m, fabs(DIVC(psi[c + g.pitch] - psi[c], D, rD)));
+      if (i < g.nx - 1) m = fmax(m, fabs(DIVC(psi[c + 1] - psi[c], D, rD)));
+    }
+  }
+  __shared__ double sm[BY];
+  m = wave_max_n(m);
+  if (threadIdx.x == 0) sm[threadIdx.y] = m;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    double v = sm[0];
+    for (int k = 1; k < BY; k++) v = fmax(v, sm[k]);
+    atomicMax((unsigned long long *)out, (unsigned long long)__double_as_longlong(v));
+  }
+}
+void launch_n_umax(hipStream_t st, const double *psi, double *out, const NatGeom &g, int nl, double D) {
+  hipLaunchKernelGGL(k_n_umax, grid2d(g.nx, g.ny), block2d(), 0, st, psi, out, g, nl, D);
+}
+// KE diagnostic qg-node/qg.c:172-178 (per-block partials, summed by launch_sum_final)
+__global__ void k_n_ke(const double *__restrict__ psi, double *partial, NatGeom g, double D2, double rD2) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  double v = 0.;
+  if (i < g.nx && j < g.ny) {
+    const size_t c = nat_idx(g, 0, j, i);
+    v = 0.5 * psi[c] * DIVC(LAPN(psi, c, g.pitch), D2, rD2) * D2;
+  }
+  __shared__ double sm[BY];
+  v = wave_sum_n(v);
+  if (threadIdx.x == 0) sm[threadIdx.y] = v;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    double s = 0.;
+    for (int k = 0; k < BY; k++) s += sm[k];
+    partial[blockIdx.y * gridDim.x + blockIdx.x] = s;
+  }
+}
+void launch_n_ke(hipStream_t st, const double *psi, double *partial, double *out, const NatGeom &g, double D) {
+  dim3 gr = grid2d(g.nx, g.ny);
+  hipLaunchKernelGGL(k_n_ke, gr, block2d(), 0, st, psi, partial, g, D * D, 1. / (D * D));
+  launch_sum_final(st, partial, out, (int)(gr.x * gr.y));
+}

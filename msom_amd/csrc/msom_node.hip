@@ -1,0 +1,619 @@
+// msom_node.hip -- host side of the vertex-grid QG variant (C ABI msomn_*, include/msom.h).
+//
+// Restates the control flow of qg-node/qg.h (update_qg :334-354, advance_qg :291-302, adjust_dt
+// :258-284, set_vars :404-450, set_const :465-524), qg_baroclinic_ms.h (rhs_pv_baroclinic :104-196,
+// comp_q :199-211, invert_q :217-225, init :449-510), qg_barotropic.h and the nodal multigrid
+// vpoisson (nodal-poisson.h:19-143) on top of the kernels of kernels_node.hip.  No CPU fallback.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+#define HIPCHK(x)                                                                          \
+  do {                                                                                     \
+    hipError_t e__ = (x);                                                                  \
+    if (e__ != hipSuccess) {                                                               \
+      msom_set_error("HIP error %s at %s:%d (%s)", hipGetErrorString(e__), __FILE__, __LINE__, #x); \
+      return MSOM_ERR_HIP;                                                                 \
+    }                                                                                      \
+  } while (0)
+
+struct NLevel {
+  int n;        // cells per side: (n + 1)^2 vertices
+  double D;     // L0 / n
+  NatGeom g;
+  double *da, *res, *mask, *S2;  // level 0: mask and S2 alias the model fields
+};
+enum { NSC_RES = 0, NSC_UMAX = 1, NSC_KE = 2, NSC_COUNT = 8 };
+
+struct msomn {
+  NodeParams p;
+  std::string params_text;
+  int N = 0, nl = 1, nlm = 1;
+  double D = 0, psi_bc = 0., iRd2_low = 0.;
+  double tolerance = 1e-3;
+  int nitermax = 100, nitermin = 1, nrelax = 5, quiet = 0;  // nodal-poisson.h:19-23
+  NatGeom g;
+  double *f[MSOMN_NFIELDS] = {nullptr};
+  int fl[MSOMN_NFIELDS] = {0};
+  LayerCoef lc;
+  int nlev = 0;
+  std::vector<NLevel> lev;
+  double *d_scal = nullptr, *h_scal = nullptr, *partial = nullptr, *d_row = nullptr, *h_row = nullptr;
+  hipStream_t st = nullptr;
+  int const_set = 0;
+  double t = 0, dt = 1., tnext = HUGE_VAL, previous = 0;
+  int iter = 0;
+  msom_mgstats mg = {0, 0, 0, 0, 0};
+};
+
+static NatGeom node_geom(int n) {
+  NatGeom g;
+  g.nx = g.ny = n + 1;
+  g.pitch = ((n + 1 + 15) / 16) * 16 + 2 * MSOM_XP;
+  g.rows = n + 1 + 2 * MSOM_YP;
+  g.ls = (size_t)g.pitch * g.rows;
+  return g;
+}
+static int dalloc(double **p, size_t n) {
+  HIPCHK(hipMalloc((void **)p, n * sizeof(double)));
+  HIPCHK(hipMemset(*p, 0, n * sizeof(double)));
+  return MSOM_OK;
+}
+static int field_layers(const msomn *m, int f) {
+  return f == MSOMN_S2 ? m->nlm : (f == MSOMN_TOPO || f == MSOMN_QFORC || f == MSOMN_MASK) ? 1 : m->nl;
+}
+
+// [layers][n+1][n+1] contiguous (host or device) <-> padded natural layout
+static int upload_g(msomn *m, double *dst, const NatGeom &g, int nl, const double *a) {
+  const size_t n1 = g.nx;
+  for (int l = 0; l < nl; l++)
+    HIPCHK(hipMemcpy2DAsync(dst + nat_idx(g, l, 0, 0), g.pitch * sizeof(double), a + (size_t)l * n1 * n1, n1 * sizeof(double), n1 * sizeof(double), n1,
+                            hipMemcpyDefault, m->st));
+  HIPCHK(hipStreamSynchronize(m->st));
+  return MSOM_OK;
+}
+static int download_g(msomn *m, const double *src, const NatGeom &g, int nl, double *a) {
+  const size_t n1 = g.nx;
+  for (int l = 0; l < nl; l++)
+    HIPCHK(hipMemcpy2DAsync(a + (size_t)l * n1 * n1, n1 * sizeof(double), src + nat_idx(g, l, 0, 0), g.pitch * sizeof(double), n1 * sizeof(double), n1,
+                            hipMemcpyDefault, m->st));
+  HIPCHK(hipStreamSynchronize(m->st));
+  return MSOM_OK;
+}
+
+extern "C" void msomn_destroy(msomn_t *m) {
+  if (!m) return;
+  for (int k = 0; k < MSOMN_NFIELDS; k++) if (m->f[k]) (void)hipFree(m->f[k]);
+  for (size_t k = 0; k < m->lev.size(); k++) {
+    if (m->lev[k].da) (void)hipFree(m->lev[k].da);
+    if (m->lev[k].res) (void)hipFree(m->lev[k].res);
+    if (k > 0 && m->lev[k].mask) (void)hipFree(m->lev[k].mask);
+    if (k > 0 && m->lev[k].S2) (void)hipFree(m->lev[k].S2);
+  }
+  if (m->d_scal) (void)hipFree(m->d_scal);
+  if (m->partial) (void)hipFree(m->partial);
+  if (m->d_row) (void)hipFree(m->d_row);
+  if (m->h_scal) (void)hipHostFree(m->h_scal);
+  if (m->h_row) (void)hipHostFree(m->h_row);
+  if (m->st) (void)hipStreamDestroy(m->st);
+  delete m;
+}
+
+static int node_alloc(msomn *m) {
+  HIPCHK(hipStreamCreate(&m->st));
+  for (int k = 0; k < MSOMN_NFIELDS; k++) {
+    m->fl[k] = field_layers(m, k);
+    int r = dalloc(&m->f[k], m->g.ls * m->fl[k]);
+    if (r) return r;
+  }
+  m->lev.resize(m->nlev);
+  for (int k = 0; k < m->nlev; k++) {
+    NLevel &L = m->lev[k];
+    L.n = m->N >> k;
+    L.D = m->p.L0 / L.n;
+    L.g = node_geom(L.n);
+    L.da = L.res = L.mask = L.S2 = nullptr;
+    int r;
+    if ((r = dalloc(&L.da, L.g.ls * m->nl)) || (r = dalloc(&L.res, L.g.ls * m->nl))) return r;
+    if (k == 0) { L.mask = m->f[MSOMN_MASK]; L.S2 = m->f[MSOMN_S2]; }
+    else if ((r = dalloc(&L.mask, L.g.ls)) || (r = dalloc(&L.S2, L.g.ls * m->nlm))) return r;
+  }
+  int r;
+  if ((r = dalloc(&m->d_scal, NSC_COUNT))) return r;
+  const int nblk = ((m->g.nx + 63) / 64) * ((m->g.ny + 3) / 4);
+  if ((r = dalloc(&m->partial, nblk)) || (r = dalloc(&m->d_row, m->N + 1))) return r;
+  HIPCHK(hipHostMalloc((void **)&m->h_scal, NSC_COUNT * sizeof(double)));
+  HIPCHK(hipHostMalloc((void **)&m->h_row, (m->N + 1) * sizeof(double)));
+  // set_vars qg-node/qg.h:426-430: mask = 1 on every vertex, its BC 0 on the four walls; S2 = N2[l]
+  // (qg_baroclinic_ms.h:471-476)
+  const size_t n1 = m->N + 1;
+  std::vector<double> h(n1 * n1 * (m->nlm > 1 ? m->nlm : 1));
+  for (size_t j = 0; j < n1; j++) for (size_t i = 0; i < n1; i++) h[j * n1 + i] = (i == 0 || j == 0 || i == n1 - 1 || j == n1 - 1) ? 0. : 1.;
+  if ((r = upload_g(m, m->f[MSOMN_MASK], m->g, 1, h.data()))) return r;
+  if (m->nl > 1) {
+    for (int l = 0; l < m->nlm; l++) for (size_t k = 0; k < n1 * n1; k++) h[l * n1 * n1 + k] = m->p.N2[l];
+    if ((r = upload_g(m, m->f[MSOMN_S2], m->g, m->nlm, h.data()))) return r;
+  }
+  return MSOM_OK;
+}
+
+static msomn *node_create(const NodeParams &p, const char *text) {
+  if (p.nl < 1 || p.nl > MSOM_MAXNL) { msom_set_error("nl = %d outside the supported range 1..%d", p.nl, MSOM_MAXNL); return nullptr; }
+  if (p.N < 2 || (p.N & (p.N - 1))) { msom_set_error("N = %d must be a power of two >= 2", p.N); return nullptr; }
+  if (p.bc_fac == -1) { msom_set_error("bc_fac = -1 (periodic vertex grid) is not supported"); return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    msom_set_error("no HIP device available: libmsomhip has no CPU fallback");
+    return nullptr;
+  }
+  msomn *m = new msomn;
+  m->p = p;
+  if (text) m->params_text = text;
+  m->N = p.N; m->nl = p.nl; m->nlm = p.nl > 1 ? p.nl - 1 : 1;
+  m->D = p.L0 / p.N;
+  m->tolerance = p.TOLERANCE;
+  m->g = node_geom(p.N);
+  int n = 0;
+  while ((p.N >> n) >= 2) n++;
+  m->nlev = n;  // coarsest level: 2 x 2 cells, one interior vertex
+  memset(&m->lc, 0, sizeof m->lc);
+  if (node_alloc(m) != MSOM_OK) { msomn_destroy(m); return nullptr; }
+  return m;
+}
+extern "C" msomn_t *msomn_create_str(const char *text) {
+  if (!text) { msom_set_error("null params text"); return nullptr; }
+  NodeParams p;
+  msom_node_params_defaults(&p);
+  msom_node_params_parse_text(&p, text);
+  return node_create(p, text);
+}
+extern "C" msomn_t *msomn_create(const char *path) {
+  NodeParams p;
+  msom_node_params_defaults(&p);
+  const char *pp = path ? path : "params.in";
+  if (msom_node_params_parse_file(&p, pp)) return nullptr;
+  std::string text;
+  if (FILE *fp = fopen(pp, "rb")) {
+    char buf[4096];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, k);
+    fclose(fp);
+  }
+  return node_create(p, text.c_str());
+}
+
+extern "C" int msomn_set_option(msomn_t *m, const char *key, double v) {
+  if (!m || !key) return MSOM_ERR_ARG;
+  if (!strcmp(key, "TOLERANCE")) m->tolerance = v;
+  else if (!strcmp(key, "NITERMAX")) m->nitermax = (int)v;
+  else if (!strcmp(key, "NITERMIN")) m->nitermin = (int)v;
+  else if (!strcmp(key, "DT")) m->p.DT = v;
+  else if (!strcmp(key, "quiet")) m->quiet = (int)v;
+  else { msom_set_error("unknown option %s", key); return MSOM_ERR_ARG; }
+  return MSOM_OK;
+}
+extern "C" double msomn_get_param(msomn_t *m, const char *k) {
+  if (!m || !k) return NAN;
+  if (!strcmp(k, "N")) return m->N;
+  if (!strcmp(k, "nl")) return m->nl;
+  if (!strcmp(k, "L0")) return m->p.L0;
+  if (!strcmp(k, "DT")) return m->p.DT;
+  if (!strcmp(k, "tend")) return m->p.tend;
+  if (!strcmp(k, "dtout")) return m->p.dtout;
+  if (!strcmp(k, "nlevels")) return m->nlev;
+  if (!strcmp(k, "iRd2_low")) return m->iRd2_low;
+  if (!strcmp(k, "bc_fac")) return m->p.bc_fac;
+  if (!strncmp(k, "idh0_", 5)) { int l = atoi(k + 5); return l >= 0 && l < MSOM_MAXNL ? m->lc.idh0[l] : NAN; }
+  if (!strncmp(k, "idh1_", 5)) { int l = atoi(k + 5); return l >= 0 && l < MSOM_MAXNL ? m->lc.idh1[l] : NAN; }
+  return NAN;
+}
+#define NEED_FIELD(m, f) if (!(m) || (f) < 0 || (f) >= MSOMN_NFIELDS) { msom_set_error("bad field id %d", (int)(f)); return MSOM_ERR_ARG; }
+#define NEED_NCONST(m) if (!(m)) return MSOM_ERR_ARG; if (!(m)->const_set) { msom_set_error("call msomn_set_const first"); return MSOM_ERR_STATE; }
+
+extern "C" int msomn_field_layers(msomn_t *m, int f) { NEED_FIELD(m, f); return m->fl[f]; }
+extern "C" int msomn_set_field(msomn_t *m, int f, const double *a) {
+  NEED_FIELD(m, f);
+  if (!a) return MSOM_ERR_ARG;
+  return upload_g(m, m->f[f], m->g, m->fl[f], a);
+}
+extern "C" int msomn_get_field(msomn_t *m, int f, double *a) {
+  NEED_FIELD(m, f);
+  if (!a) return MSOM_ERR_ARG;
+  return download_g(m, m->f[f], m->g, m->fl[f], a);
+}
+
+// ---- boundary conditions with set_bc_ms() in force (qg-node/qg.h:197-214, qg_baroclinic_ms.h:55-70)
+static double bcc(const msomn *m) { return 2 * m->p.bc_fac / (m->D * m->D); }
+static void bnd_psi(msomn *m) { launch_n_bnd_const(m->st, m->f[MSOMN_PSI], m->g, m->nl, m->psi_bc); }
+static void bnd_q(msomn *m, double *q) { launch_n_bnd_from(m->st, q, m->f[MSOMN_PSI], m->g, m->nl, bcc(m), 0, m->psi_bc); }
+static void bnd_tmp(msomn *m) { launch_n_bnd_from(m->st, m->f[MSOMN_TMP], m->f[MSOMN_ZETA], m->g, m->nl, bcc(m), 1, 0.); }
+
+static int read_scalar(msomn *m, int slot, double *out) {
+  HIPCHK(hipMemcpyAsync(m->h_scal + slot, m->d_scal + slot, sizeof(double), hipMemcpyDeviceToHost, m->st));
+  HIPCHK(hipStreamSynchronize(m->st));
+  *out = m->h_scal[slot];
+  return MSOM_OK;
+}
+
+// comp_q_baroclinic / comp_q_barotropic
+static int comp_q(msomn *m, const double *psi, double *q) {
+  if (m->nl == 1) launch_n_helm(m->st, psi, q, m->g, m->D, m->iRd2_low);
+  else {
+    launch_n_del2(m->st, psi, q, m->g, m->nl, 0., 1., m->D);
+    launch_n_stretch(m->st, psi, q, m->f[MSOMN_S2], m->g, m->nl, 1., 1., m->lc);
+  }
+  bnd_q(m, q);
+  HIPCHK(hipGetLastError());
+  return MSOM_OK;
+}
+
+// rhs_pv_baroclinic qg_baroclinic_ms.h:104-196 / rhs_pv_barotropic qg_barotropic.h:16-29
+static int rhs_pv(msomn *m, double *q, double *dq) {
+  const NodeParams &p = m->p;
+  const int nl = m->nl;
+  const double drag = p.hEkb * p.f0 / (2 * p.dh[nl - 1]);
+  if (nl == 1) {
+    launch_n_rhs_barotropic(m->st, m->f[MSOMN_PSI], q, m->f[MSOMN_QFORC], dq, m->g, m->D, p.beta, drag, p.nu);
+    HIPCHK(hipGetLastError());
+    return MSOM_OK;
+  }
+  double *psi = m->f[MSOMN_PSI], *zeta = m->f[MSOMN_ZETA], *tmp = m->f[MSOMN_TMP], *S2 = m->f[MSOMN_S2];
+  launch_n_mul_mask(m->st, q, psi, m->f[MSOMN_MASK], m->g, nl);                 // :110-116
+  launch_n_del2(m->st, psi, zeta, m->g, nl, 0., 1., m->D);                      // comp_del2(psi, zeta, 0, 1)
+  bnd_q(m, zeta);
+  launch_n_rhs_main(m->st, psi, zeta, m->f[MSOMN_PSIPG], S2, m->f[MSOMN_TOPO], dq, m->g, nl, 1, 1, m->D, p.beta, drag, p.f0, p.dh[nl - 1], m->lc);
+  launch_n_stretch(m->st, zeta, dq, S2, m->g, nl, 1., p.nu, m->lc);            // :160
+  launch_n_del2(m->st, zeta, tmp, m->g, nl, 0., 1.0, m->D);                     // :162 + boundary(tmp)
+  bnd_tmp(m);
+  launch_n_axpy(m->st, dq, tmp, m->g, nl, p.nu);                               // :164-167
+  const double minus_nu4 = -p.nu4;
+  launch_n_stretch(m->st, tmp, dq, S2, m->g, nl, 1., minus_nu4, m->lc);        // :172
+  launch_n_del2(m->st, tmp, dq, m->g, nl, 1., minus_nu4, m->D);                 // :173
+  launch_n_add2d(m->st, dq, m->f[MSOMN_QFORC], m->g);                           // :176-180 surface forcing
+  launch_n_mul_mask(m->st, dq, nullptr, m->f[MSOMN_MASK], m->g, nl);            // :186-190
+  HIPCHK(hipGetLastError());
+  return MSOM_OK;
+}
+
+// ---- nodal multigrid
+static void relax_level(msomn *m, int k, double *da, const double *res) {
+  NLevel &L = m->lev[k];
+  for (int c = 0; c < 2; c++) launch_n_relax(m->st, da, res, L.mask, L.S2, L.g, m->nl, c, L.D, m->iRd2_low, m->lc);
+}
+static int build_levels(msomn *m) {
+  launch_n_bnd_const(m->st, m->f[MSOMN_MASK], m->g, 1, 0.);
+  for (int k = 1; k < m->nlev; k++) {
+    launch_n_restrict(m->st, m->lev[k - 1].mask, m->lev[k - 1].g, m->lev[k].mask, m->lev[k].g, 1, 1);
+    launch_n_bnd_const(m->st, m->lev[k].mask, m->lev[k].g, 1, 0.);
+    if (m->nl > 1) launch_n_restrict(m->st, m->lev[k - 1].S2, m->lev[k - 1].g, m->lev[k].S2, m->lev[k].g, m->nlm, 2);
+  }
+  HIPCHK(hipGetLastError());
+  return MSOM_OK;
+}
+// vpoisson, nodal-poisson.h:19-143: residual first, then (unless converged) one cycle
+static int vpoisson(msomn *m, double *a, const double *b) {
+  msom_mgstats mg;
+  mg.sum = HUGE_VAL; mg.resa = HUGE_VAL; mg.resb = 0; mg.nrelax = m->nrelax;
+  const int nl = m->nl, nlev = m->nlev;
+  for (mg.i = 0; mg.i < m->nitermax; mg.i++) {
+    HIPCHK(hipMemsetAsync(m->d_scal + NSC_RES, 0, sizeof(double), m->st));
+    launch_n_residual(m->st, a, b, m->lev[0].mask, m->lev[0].S2, m->lev[0].res, m->d_scal + NSC_RES, m->g, nl, m->D, m->iRd2_low, m->lc);
+    double max;
+    int r = read_scalar(m, NSC_RES, &max);
+    if (r) return r;
+    mg.resa = max;
+    if (mg.i == 0) mg.resb = max;
+    if (max < m->tolerance && mg.i >= m->nitermin) break;
+    launch_n_bnd_const(m->st, m->lev[0].res, m->g, nl, 0.);
+    for (int k = 1; k < nlev; k++) {  // the boundary vertices of every level end up 0 (boundary_level)
+      launch_n_restrict(m->st, m->lev[k - 1].res, m->lev[k - 1].g, m->lev[k].res, m->lev[k].g, nl, 0);
+      launch_n_bnd_const(m->st, m->lev[k].res, m->lev[k].g, nl, 0.);
+    }
+    HIPCHK(hipMemsetAsync(m->lev[nlev - 1].da, 0, m->lev[nlev - 1].g.ls * nl * sizeof(double), m->st));
+    for (int k = nlev - 1; k >= 0; k--) {
+      for (int s = 0; s < mg.nrelax; s++) relax_level(m, k, m->lev[k].da, m->lev[k].res);
+      if (k > 0) launch_n_prolong(m->st, m->lev[k].da, m->lev[k].g, m->lev[k - 1].da, m->lev[k - 1].g, nl);
+    }
+    launch_n_correct(m->st, a, m->lev[0].da, m->g, nl, m->psi_bc);
+  }
+  HIPCHK(hipGetLastError());
+  if (mg.resa > m->tolerance && !m->quiet)
+    fprintf(stderr, "Convergence for psi not reached.\nmg.i = %d, mg.resb: %g mg.resa: %g\n", mg.i, mg.resb, mg.resa);
+  m->mg = mg;
+  return MSOM_OK;
+}
+static int invert_q(msomn *m, double *q) {
+  int r = vpoisson(m, m->f[MSOMN_PSI], q);
+  if (r) return r;
+  bnd_psi(m);
+  bnd_q(m, q);
+  return MSOM_OK;
+}
+// adjust_dt qg-node/qg.h:258-284 with the `previous` memory of Basilisk's timestep()
+static int adjust_dt(msomn *m, double dtmax, double *out) {
+  HIPCHK(hipMemsetAsync(m->d_scal + NSC_UMAX, 0, sizeof(double), m->st));
+  launch_n_umax(m->st, m->f[MSOMN_PSI], m->d_scal + NSC_UMAX, m->g, m->nl, m->D);
+  double um;
+  int r = read_scalar(m, NSC_UMAX, &um);
+  if (r) return r;
+  dtmax /= m->p.CFL;
+  if (um != 0.) { const double dt = m->D / um; if (dt < dtmax) dtmax = dt; }
+  dtmax *= m->p.CFL;
+  if (dtmax > m->previous) dtmax = (m->previous + 0.1 * dtmax) / 1.1;
+  m->previous = dtmax;
+  *out = dtmax;
+  return MSOM_OK;
+}
+
+extern "C" int msomn_set_const(msomn_t *m) {
+  if (!m) return MSOM_ERR_ARG;
+  NodeParams &p = m->p;
+  const int nl = m->nl, N = m->N;
+  const size_t n1 = N + 1;
+  int r;
+  if (nl > 1) {
+    for (int l = 0; l < nl; l++) if (p.dh[l] == 0.) { msom_set_error("thickness = 0: check the definition of dh in params.in"); return MSOM_ERR_CONFIG; }
+    double dhc[MSOM_MAXNL];
+    for (int l = 0; l < nl - 1; l++) dhc[l] = 0.5 * (p.dh[l] + p.dh[l + 1]);
+    m->lc.idh0[0] = 0.; m->lc.idh1[0] = 1. / (dhc[0] * p.dh[0]);
+    for (int l = 1; l < nl - 1; l++) { m->lc.idh0[l] = 1. / (dhc[l - 1] * p.dh[l]); m->lc.idh1[l] = 1. / (dhc[l] * p.dh[l]); }
+    m->lc.idh0[nl - 1] = 1. / (dhc[nl - 2] * p.dh[nl - 1]); m->lc.idh1[nl - 1] = 0.;
+    // S2: N^2 -> f^2 / N^2 with f = f0 + flag_ms beta (y - L0/2)  (qg_baroclinic_ms.h:501-505); init-time host pass
+    std::vector<double> h(n1 * n1 * m->nlm);
+    if ((r = download_g(m, m->f[MSOMN_S2], m->g, m->nlm, h.data()))) return r;
+    for (int l = 0; l < nl - 1; l++) for (size_t j = 0; j < n1; j++) {
+      const double f = p.f0 + p.flag_ms * p.beta * (j * m->D - 0.5 * p.L0);
+      for (size_t i = 0; i < n1; i++) { double &s = h[(l * n1 + j) * n1 + i]; s = f * f / s; }
+    }
+    if ((r = upload_g(m, m->f[MSOMN_S2], m->g, m->nlm, h.data()))) return r;
+    if (p.scale_topo != 1.) {
+      std::vector<double> tp(n1 * n1);
+      if ((r = download_g(m, m->f[MSOMN_TOPO], m->g, 1, tp.data()))) return r;
+      for (double &v : tp) v *= p.scale_topo;
+      if ((r = upload_g(m, m->f[MSOMN_TOPO], m->g, 1, tp.data()))) return r;
+    }
+  } else if (p.gp_low != 0.) m->iRd2_low = p.f0 * p.f0 / (p.gp_low * p.dh[nl - 1]);
+  if ((r = build_levels(m))) return r;
+  bnd_psi(m);
+  if (p.nu != 0) p.DT = 0.5 * fmin(p.DT, m->D * m->D / p.nu / 4.);  // qg-node/qg.h:511-512
+  if (p.beta != 0) p.DT = fmin(p.DT, 1 / (2. * p.beta * p.L0));
+  if ((r = comp_q(m, m->f[MSOMN_PSI], m->f[MSOMN_Q]))) return r;
+  HIPCHK(hipStreamSynchronize(m->st));
+  m->const_set = 1;
+  return MSOM_OK;
+}
+
+extern "C" int msomn_update(msomn_t *m, int qf, int dqf, double dtmax, double *dt_out) {
+  NEED_NCONST(m); NEED_FIELD(m, qf); NEED_FIELD(m, dqf);
+  int r;
+  if ((r = invert_q(m, m->f[qf])) || (r = rhs_pv(m, m->f[qf], m->f[dqf]))) return r;
+  double dt;
+  if ((r = adjust_dt(m, dtmax, &dt))) return r;
+  if (dt_out) *dt_out = dt;
+  return MSOM_OK;
+}
+extern "C" int msomn_advance(msomn_t *m, int out, int in, int dq, double dt) {
+  NEED_FIELD(m, out); NEED_FIELD(m, in); NEED_FIELD(m, dq);
+  launch_advance(m->st, m->f[out], m->f[in], m->f[dq], nullptr, m->g, m->nl, dt, 0.);
+  HIPCHK(hipGetLastError());
+  return MSOM_OK;
+}
+extern "C" int msomn_invert_q(msomn_t *m, int qf, msom_mgstats *st) {
+  NEED_NCONST(m); NEED_FIELD(m, qf);
+  int r = invert_q(m, m->f[qf]);
+  if (st) *st = m->mg;
+  if (!r) HIPCHK(hipStreamSynchronize(m->st));
+  return r;
+}
+extern "C" int msomn_comp_q(msomn_t *m, int pf, int qf) { NEED_NCONST(m); NEED_FIELD(m, pf); NEED_FIELD(m, qf); return comp_q(m, m->f[pf], m->f[qf]); }
+extern "C" int msomn_rhs_pv(msomn_t *m, int qf, int dqf) { NEED_NCONST(m); NEED_FIELD(m, qf); NEED_FIELD(m, dqf); return rhs_pv(m, m->f[qf], m->f[dqf]); }
+extern "C" int msomn_dbg_del2_zeta(msomn_t *m) {
+  NEED_NCONST(m);
+  launch_n_del2(m->st, m->f[MSOMN_PSI], m->f[MSOMN_ZETA], m->g, m->nl, 0., 1., m->D);
+  bnd_q(m, m->f[MSOMN_ZETA]);
+  HIPCHK(hipGetLastError());
+  return MSOM_OK;
+}
+// event forcing (i++), qg-node/qg.c:136-145: q_forcing depends on y and t only -> one row on the host
+extern "C" int msomn_forcing(msomn_t *m) {
+  if (!m) return MSOM_ERR_ARG;
+  const NodeParams &p = m->p;
+  const double L0 = p.L0, t = m->t;
+  HIPCHK(hipStreamSynchronize(m->st));
+  for (int j = 0; j <= m->N; j++) {
+    const double y = j * m->D;
+    m->h_row[j] = -(p.tau0 + p.tau1 * cos(2 * M_PI * t / p.tf1)) / p.dh[0] * p.forc_mode * M_PI / L0 *
+                  sin(p.forc_mode * M_PI * (y + y * (y - L0) * 2 / (L0 * L0) * p.dy_ws * sin(2 * M_PI * t / p.tf2)) / L0);
+  }
+  HIPCHK(hipMemcpyAsync(m->d_row, m->h_row, (m->N + 1) * sizeof(double), hipMemcpyHostToDevice, m->st));
+  launch_n_rowfill(m->st, m->f[MSOMN_QFORC], m->d_row, m->g);
+  HIPCHK(hipGetLastError());
+  return MSOM_OK;
+}
+static double dtnext(msomn *m, double dt, double *tnext_out) {  // dtnext() [Basilisk, SURVEY App. B]
+  double tnext = m->tnext, t = m->t;
+  if (tnext != HUGE_VAL && tnext > t) {
+    unsigned int n = (unsigned int)((tnext - t) / dt);
+    if (n == 0) dt = tnext - t;
+    else {
+      double dt1 = (tnext - t) / n;
+      if (dt1 > dt * (1. + 1e-9)) dt = (tnext - t) / (n + 1);
+      else if (dt1 < dt) dt = dt1;
+      tnext = t + dt;
+    }
+  } else
+    tnext = t + dt;
+  *tnext_out = tnext;
+  return dt;
+}
+extern "C" int msomn_step(msomn_t *m, int with_forcing_event) {
+  NEED_NCONST(m);
+  int r;
+  double d, tn;
+  if (with_forcing_event && (r = msomn_forcing(m))) return r;
+  if ((r = msomn_update(m, MSOMN_Q, MSOMN_DQ, m->p.DT, &d))) return r;
+  m->dt = dtnext(m, d, &tn);
+  if ((r = msomn_advance(m, MSOMN_QPRED, MSOMN_Q, MSOMN_DQ, m->dt / 2.))) return r;
+  if ((r = msomn_update(m, MSOMN_QPRED, MSOMN_DQ, m->dt, &d))) return r;
+  if ((r = msomn_advance(m, MSOMN_Q, MSOMN_Q, MSOMN_DQ, m->dt))) return r;
+  m->t = tn;
+  m->iter++;
+  return MSOM_OK;
+}
+extern "C" int msomn_set_tnext(msomn_t *m, double t) { if (!m) return MSOM_ERR_ARG; m->tnext = t; return MSOM_OK; }
+extern "C" double msomn_time(msomn_t *m) { return m ? m->t : NAN; }
+extern "C" double msomn_dt(msomn_t *m) { return m ? m->dt : NAN; }
+extern "C" int msomn_iter(msomn_t *m) { return m ? m->iter : MSOM_ERR_ARG; }
+extern "C" int msomn_last_mgstats(msomn_t *m, msom_mgstats *s) { if (!m || !s) return MSOM_ERR_ARG; *s = m->mg; return MSOM_OK; }
+extern "C" int msomn_ke(msomn_t *m, double *ke) {
+  if (!m || !ke) return MSOM_ERR_ARG;
+  launch_n_ke(m->st, m->f[MSOMN_PSI], m->partial, m->d_scal + NSC_KE, m->g, m->D);
+  double v;
+  int r = read_scalar(m, NSC_KE, &v);
+  if (r) return r;
+  *ke = -v;
+  return MSOM_OK;
+}
+
+// ---- raw multigrid pieces (parity tests)
+#define NEED_LEVEL(m, k) if (!(m) || (k) < 0 || (k) >= (m)->nlev) { msom_set_error("bad level %d", (int)(k)); return MSOM_ERR_ARG; }
+extern "C" int msomn_dbg_relax(msomn_t *m, int k, double *da, const double *res, int nsweeps) {
+  NEED_NCONST(m); NEED_LEVEL(m, k);
+  NLevel &L = m->lev[k];
+  int r;
+  if ((r = upload_g(m, L.da, L.g, m->nl, da)) || (r = upload_g(m, L.res, L.g, m->nl, res))) return r;
+  launch_n_bnd_const(m->st, L.da, L.g, m->nl, 0.);
+  for (int s = 0; s < nsweeps; s++) relax_level(m, k, L.da, L.res);
+  HIPCHK(hipGetLastError());
+  return download_g(m, L.da, L.g, m->nl, da);
+}
+extern "C" int msomn_dbg_residual(msomn_t *m, const double *a, const double *b, double *res, double *maxres) {
+  NEED_NCONST(m);
+  int r;
+  if ((r = upload_g(m, m->f[MSOMN_TMP], m->g, m->nl, a)) || (r = upload_g(m, m->f[MSOMN_DQ], m->g, m->nl, b))) return r;
+  HIPCHK(hipMemsetAsync(m->d_scal + NSC_RES, 0, sizeof(double), m->st));
+  launch_n_residual(m->st, m->f[MSOMN_TMP], m->f[MSOMN_DQ], m->lev[0].mask, m->lev[0].S2, m->lev[0].res, m->d_scal + NSC_RES, m->g, m->nl, m->D, m->iRd2_low,
+                    m->lc);
+  double mx;
+  if ((r = read_scalar(m, NSC_RES, &mx))) return r;
+  if (maxres) *maxres = mx;
+  return download_g(m, m->lev[0].res, m->g, m->nl, res);
+}
+extern "C" int msomn_dbg_restrict(msomn_t *m, int k, const double *fine, double *coarse) {
+  NEED_NCONST(m); NEED_LEVEL(m, k); NEED_LEVEL(m, k + 1);
+  int r;
+  if ((r = upload_g(m, m->lev[k].res, m->lev[k].g, m->nl, fine))) return r;
+  launch_n_bnd_const(m->st, m->lev[k].res, m->lev[k].g, m->nl, 0.);
+  launch_n_restrict(m->st, m->lev[k].res, m->lev[k].g, m->lev[k + 1].res, m->lev[k + 1].g, m->nl, 0);
+  launch_n_bnd_const(m->st, m->lev[k + 1].res, m->lev[k + 1].g, m->nl, 0.);
+  return download_g(m, m->lev[k + 1].res, m->lev[k + 1].g, m->nl, coarse);
+}
+extern "C" int msomn_dbg_prolong(msomn_t *m, int k, const double *coarse, double *fine) {
+  NEED_NCONST(m); NEED_LEVEL(m, k); NEED_LEVEL(m, k - 1);
+  int r;
+  if ((r = upload_g(m, m->lev[k].da, m->lev[k].g, m->nl, coarse))) return r;
+  launch_n_bnd_const(m->st, m->lev[k].da, m->lev[k].g, m->nl, 0.);
+  launch_n_prolong(m->st, m->lev[k].da, m->lev[k].g, m->lev[k - 1].da, m->lev[k - 1].g, m->nl);
+  return download_g(m, m->lev[k - 1].da, m->lev[k - 1].g, m->nl, fine);
+}
+extern "C" int msomn_dbg_level_mask(msomn_t *m, int k, double *out) {
+  NEED_NCONST(m); NEED_LEVEL(m, k);
+  return download_g(m, m->lev[k].mask, m->lev[k].g, 1, out);
+}
+
+// ---- NetCDF-3 IO of vertex fields (qg-node/netcdf_vertex_bas.h:95-424)
+extern "C" int msomn_write_nc(msomn_t *m, const char *path) {
+  if (!m || !path) return MSOM_ERR_ARG;
+  const size_t n1 = m->N + 1, sz = n1 * n1 * m->nl;
+  std::vector<double> psi(sz), q(sz);
+  int r;
+  if ((r = download_g(m, m->f[MSOMN_PSI], m->g, m->nl, psi.data())) || (r = download_g(m, m->f[MSOMN_Q], m->g, m->nl, q.data()))) return r;
+  const char *names[2] = {"psi", "q"};
+  struct stat sb;
+  if (stat(path, &sb) != 0 && msom_nc_create2(path, m->nl, (int)n1, (int)n1, m->p.L0, 2, names, 1)) return MSOM_ERR_IO;
+  const double *fields[2] = {psi.data(), q.data()};
+  return msom_nc_append(path, m->nl, (int)n1, (int)n1, 2, names, m->t, fields) < 0 ? MSOM_ERR_IO : MSOM_OK;
+}
+extern "C" int msomn_read_nc(msomn_t *m, int field, const char *path, const char *varname, int record) {
+  NEED_FIELD(m, field);
+  if (!path || !varname) return MSOM_ERR_ARG;
+  const size_t n1 = m->N + 1;
+  std::vector<double> h(n1 * n1 * m->fl[field]);
+  if (msom_nc_read(path, varname, record, m->fl[field], (int)n1, (int)n1, h.data(), nullptr)) return MSOM_ERR_IO;
+  return upload_g(m, m->f[field], m->g, m->fl[field], h.data());
+}
+
+// main() + events of qg-node/qg.c:58-181
+extern "C" int msomn_run(msomn_t *m, const char *workdir, long nsteps_max) {
+  if (!m) return MSOM_ERR_ARG;
+  const NodeParams &p = m->p;
+  const char *wd = workdir ? workdir : ".";
+  char dpath[600] = "", name[800];
+  int r;
+  const size_t n1 = m->N + 1;
+  for (int i = 1; i < 10000; i++) {  // create_outdir, extra.h:122-135
+    snprintf(dpath, sizeof dpath, "%s/outdir_%04d/", wd, i);
+    if (mkdir(dpath, 0777) == 0) { fprintf(stdout, "Writing output in %s\n", dpath); break; }
+  }
+  snprintf(name, sizeof name, "%sparams.in", dpath);  // backup_config
+  if (FILE *fp = fopen(name, "w")) { fwrite(m->params_text.data(), 1, m->params_text.size(), fp); fclose(fp); }
+  if (!m->const_set) {
+    // init (qg_baroclinic_ms.h:478-492): optional input file, variables N2, psi_pg, mask, topo, q_forcing
+    if (m->nl > 1) {
+      snprintf(name, sizeof name, "%s/input_vars_%dl_N%d.nc", wd, m->nl, m->N);
+      struct stat sb;
+      if (stat(name, &sb) == 0) {
+        fprintf(stdout, "Read input files:\n");
+        const struct { int f; const char *v; } in[] = {{MSOMN_S2, "N2"}, {MSOMN_PSIPG, "psi_pg"}, {MSOMN_MASK, "mask"}, {MSOMN_TOPO, "topo"}, {MSOMN_QFORC, "q_forcing"}};
+        for (auto &e : in) (void)msomn_read_nc(m, e.f, name, e.v, 0);  // absent variables keep their defaults
+        fprintf(stdout, "%s .. ok\n", name);
+      }
+    }
+    // set_const qg-node/qg.h:475-479: psi = noise_init (noise() + sin(2 pi y / L0)); noise() in [-1, 1]
+    std::vector<double> h(n1 * n1 * m->nl);
+    for (size_t j = 0; j < n1; j++) for (size_t i = 0; i < n1; i++) for (int l = 0; l < m->nl; l++)
+      h[(l * n1 + j) * n1 + i] = p.noise_init * ((1. - 2. * rand() / (double)RAND_MAX) + sin(2 * M_PI * (j * m->D) / p.L0));
+    if ((r = upload_g(m, m->f[MSOMN_PSI], m->g, m->nl, h.data()))) return r;
+    snprintf(name, sizeof name, "%s/restart.nc", wd);
+    struct stat sb;
+    if (stat(name, &sb) == 0) {
+      fprintf(stdout, "Read restart file:\n");
+      if ((r = msomn_read_nc(m, MSOMN_PSI, name, "psi", -1))) return r;
+      fprintf(stdout, "%s .. ok\n", name);
+    }
+    if ((r = msomn_set_const(m))) return r;
+  }
+  snprintf(name, sizeof name, "%svars.nc", dpath);
+  double tout = 0.;
+  long steps = 0;
+  for (;;) {
+    if ((r = msomn_forcing(m))) return r;  // forcing (i++)
+    bool pending = tout <= p.tend + 1e-10;
+    if (pending && m->t >= tout - 1e-12 * fmax(1., fabs(tout))) {  // output (t = 0; t <= tend + 1e-10; t += dtout)
+      fprintf(stdout, "write file\n");
+      if (m->iter == 0 && (r = invert_q(m, m->f[MSOMN_Q]))) return r;
+      if ((r = msomn_write_nc(m, name))) return r;
+      fprintf(stdout, "file written \n");
+      tout += p.dtout;
+      pending = tout <= p.tend + 1e-10;
+    }
+    double ke;
+    if ((r = msomn_ke(m, &ke))) return r;
+    fprintf(stdout, "i = %i, dt = %g, t = %g, ke_1 = %g\n", m->iter, m->dt, m->t, ke);  // writestdout
+    if (!pending) break;
+    if (nsteps_max >= 0 && steps >= nsteps_max) break;
+    m->tnext = tout;
+    if ((r = msomn_step(m, 0))) return r;
+    steps++;
+  }
+  fflush(stdout);
+  return m->iter;
+}

@@ -34,9 +34,23 @@ int msom_bas_read(const char *path, double *a, int nl, int n, double L0);
 /* netcdf3.c: NetCDF-3 classic writer/reader replacing libnetcdf's create_nc/write_nc/read_nc
  * (newqg/netcdf_bas.h:42-244, qg-node/netcdf_vertex_bas.h:315-424).  Fields are [level][y][x] fp64. */
 int msom_nc_create(const char *path, int nl, int ny, int nx, double L0, int nvars, const char *const *names);
+int msom_nc_create2(const char *path, int nl, int ny, int nx, double L0, int nvars, const char *const *names, int vertex);
 int msom_nc_append(const char *path, int nl, int ny, int nx, int nvars, const char *const *names, double time, const double *const *fields);
 int msom_nc_read(const char *path, const char *name, int rec, int nl, int ny, int nx, double *out, double *time_out);
 void msom_set_error(const char *fmt, ...);
+
+/* parameters of the vertex-grid variant: qg-node/qg.c:72-107 (add_param list), defaults
+ * qg-node/qg.h:104-127,164 and qg.c:61-66 */
+struct NodeParams {
+  int N, nl, flag_ms;
+  double L0, f0, beta, nu, nu4, hEkb, gp_low, scale_topo, tau0, tau1, tf1, tf2, dy_ws, forc_mode, noise_init;
+  double Lfmax, Lfmin, fac_filt_Rd, dtflt, bc_fac, DT, tend, dtout, CFL, TOLERANCE, dtdiag;
+  double dh[MSOM_MAXARR], N2[MSOM_MAXARR];
+};
+/* params.c: restates read_params of qg-node/extra.h:83-116 */
+void msom_node_params_defaults(struct NodeParams *p);
+int msom_node_params_parse_text(struct NodeParams *p, const char *text);
+int msom_node_params_parse_file(struct NodeParams *p, const char *path);
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,10 @@ static buf make_header(int nl, int ny, int nx, int nvars, const char *const *nam
 
 /* create_nc, newqg/netcdf_bas.h:42-134 */
 int msom_nc_create(const char *path, int nl, int ny, int nx, double L0, int nvars, const char *const *names) {
+  return msom_nc_create2(path, nl, ny, nx, L0, nvars, names, 0);
+}
+/* vertex = 1: ny = nx = N + 1 vertex coordinates i * L0 / N (qg-node/netcdf_vertex_bas.h:145-150) */
+int msom_nc_create2(const char *path, int nl, int ny, int nx, double L0, int nvars, const char *const *names, int vertex) {
   layout L;
   memset(&L, 0, sizeof L);
   buf h = make_header(nl, ny, nx, nvars, names, 0, &L);
@@ -96,10 +100,10 @@ int msom_nc_create(const char *path, int nl, int ny, int nx, double L0, int nvar
   if (!fp) { free(h.b); msom_set_error("cannot create %s", path); return -2; }
   fwrite(h.b, 1, h.n, fp);
   free(h.b);
-  const double Delta = L0 * 1.0 / nx;
+  const double Delta = L0 * 1.0 / (vertex ? nx - 1 : nx), off = vertex ? 0. : 0.5;
   unsigned char t[4];
-  for (int i = 0; i < ny; i++) { putf(t, (float)(0. + (i + 0.5) * Delta)); fwrite(t, 1, 4, fp); }
-  for (int i = 0; i < nx; i++) { putf(t, (float)(0. + (i + 0.5) * Delta)); fwrite(t, 1, 4, fp); }
+  for (int i = 0; i < ny; i++) { putf(t, (float)(0. + (i + off) * Delta)); fwrite(t, 1, 4, fp); }
+  for (int i = 0; i < nx; i++) { putf(t, (float)(0. + (i + off) * Delta)); fwrite(t, 1, 4, fp); }
   fclose(fp);
   return 0;
 }

@@ -64,7 +64,7 @@ static void parse_array(const char *v, double *out) {
   }
 }
 
-static void parse_line(struct Params *p, const char *line) {
+static void parse_line_tab(void *p, const keydef *keys, size_t nkeys, const char *line) {
   char buf[300];
   size_t n = 0;
   for (const char *s = line; *s && *s != '\n' && *s != '\r' && n < sizeof buf - 1; s++)
@@ -76,15 +76,16 @@ static void parse_line(struct Params *p, const char *line) {
   char *val = eq + 1, *eq2 = strchr(val, '=');
   if (eq2) *eq2 = '\0';
   if (!*val) return;
-  for (size_t k = 0; k < sizeof KEYS / sizeof KEYS[0]; k++) {
-    if (strcmp(buf, KEYS[k].key)) continue;
-    char *dst = (char *)p + KEYS[k].off;
-    if (KEYS[k].type == T_INT) *(int *)dst = atoi(val);
-    else if (KEYS[k].type == T_DBL) *(double *)dst = atof(val);
+  for (size_t k = 0; k < nkeys; k++) {
+    if (strcmp(buf, keys[k].key)) continue;
+    char *dst = (char *)p + keys[k].off;
+    if (keys[k].type == T_INT) *(int *)dst = atoi(val);
+    else if (keys[k].type == T_DBL) *(double *)dst = atof(val);
     else parse_array(val, (double *)dst);
     return;
   }
 }
+static void parse_line(struct Params *p, const char *line) { parse_line_tab(p, KEYS, sizeof KEYS / sizeof KEYS[0], line); }
 
 int msom_params_parse_text(struct Params *p, const char *text) {
   const char *s = text;
@@ -126,4 +127,47 @@ void msom_params_derive(struct Params *p) {
     p->ptr_ir[nt] = p->ptr_r[nt] == 0 ? 0. : 1 / p->ptr_r[nt];
     p->iPe[nt] = p->Pe[nt] == 0 ? 0. : 1 / p->Pe[nt];
   }
+}
+
+/* ---- vertex-grid variant: parameter list of qg-node/qg.c:72-107, parser qg-node/extra.h:83-116 (same
+ * line rules as above: blanks removed, split at '=', atoi/atof, arrays [a,b,c]) */
+#define KN(name, type, member) { name, type, offsetof(struct NodeParams, member) }
+static const keydef NODE_KEYS[] = {
+  KN("N", T_INT, N), KN("nl", T_INT, nl), KN("flag_ms", T_INT, flag_ms), KN("L0", T_DBL, L0), KN("f0", T_DBL, f0),
+  KN("beta", T_DBL, beta), KN("nu", T_DBL, nu), KN("nu4", T_DBL, nu4), KN("hEkb", T_DBL, hEkb), KN("gp_low", T_DBL, gp_low),
+  KN("scale_topo", T_DBL, scale_topo), KN("tau0", T_DBL, tau0), KN("tau1", T_DBL, tau1), KN("tf1", T_DBL, tf1), KN("tf2", T_DBL, tf2),
+  KN("dy_ws", T_DBL, dy_ws), KN("forc_mode", T_DBL, forc_mode), KN("noise_init", T_DBL, noise_init), KN("Lfmax", T_DBL, Lfmax),
+  KN("Lfmin", T_DBL, Lfmin), KN("fac_filt_Rd", T_DBL, fac_filt_Rd), KN("dtflt", T_DBL, dtflt), KN("dh", T_ARR, dh), KN("N2", T_ARR, N2),
+  KN("bc_fac", T_DBL, bc_fac), KN("DT", T_DBL, DT), KN("tend", T_DBL, tend), KN("dtout", T_DBL, dtout), KN("CFL", T_DBL, CFL),
+  KN("TOLERANCE", T_DBL, TOLERANCE), KN("dtdiag", T_DBL, dtdiag),
+};
+/* defaults: qg-node/qg.h:104-127,164; qg.c:61-66; Basilisk globals N = 64, L0 = 1, DT = 1e10, CFL = 0.5, TOLERANCE = 1e-3 */
+void msom_node_params_defaults(struct NodeParams *p) {
+  memset(p, 0, sizeof *p);
+  p->N = 64; p->nl = 1; p->L0 = 1.; p->f0 = 1.; p->scale_topo = 1.; p->tf1 = 1.; p->tf2 = 1.; p->dy_ws = 1.; p->forc_mode = 2.0;
+  p->dh[0] = 1.; p->N2[0] = 1.; p->DT = 1e10; p->tend = 100; p->dtout = 1; p->CFL = 0.5; p->TOLERANCE = 1e-3; p->dtdiag = -1;
+  p->Lfmax = 1e10; p->dtflt = -1;
+}
+int msom_node_params_parse_text(struct NodeParams *p, const char *text) {
+  const char *s = text;
+  while (*s) {
+    const char *e = strchr(s, '\n');
+    size_t len = e ? (size_t)(e - s) : strlen(s);
+    char line[300];
+    if (len > sizeof line - 1) len = sizeof line - 1;
+    memcpy(line, s, len);
+    line[len] = '\0';
+    parse_line_tab(p, NODE_KEYS, sizeof NODE_KEYS / sizeof NODE_KEYS[0], line);
+    if (!e) break;
+    s = e + 1;
+  }
+  return 0;
+}
+int msom_node_params_parse_file(struct NodeParams *p, const char *path) {
+  FILE *fp = fopen(path, "rt");
+  if (!fp) { msom_set_error("file %s not found", path); return -2; } /* reference: message + exit(0), extra.h:111-114 */
+  char line[300];
+  while (fgets(line, sizeof line, fp)) parse_line_tab(p, NODE_KEYS, sizeof NODE_KEYS / sizeof NODE_KEYS[0], line);
+  fclose(fp);
+  return 0;
 }

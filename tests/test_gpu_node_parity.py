@@ -1,0 +1,194 @@
+"""GPU parity of the vertex-grid variant (msomn_* C ABI, kernels_node.hip) against the CPU oracle
+oracle/qgnode_oracle.c run with the same red-black smoother.
+
+strict build (-ffp-contract=off, reference expression order): bit-exact (np.array_equal).
+fast build (FMA contraction, reciprocal multiplies): relative tolerance 1e-9 on the fields after
+the elliptic solve converged to the same TOLERANCE (stated per test)."""
+import numpy as np
+import pytest
+
+import orn
+from msom_amd import NodeQG
+
+pytestmark = pytest.mark.gpu
+
+
+def land_mask(N):
+    """an island and a ragged coast: mask = 0 on land vertices and on the boundary vertices"""
+    m = np.ones((1, N + 1, N + 1))
+    m[0, N // 4: N // 4 + N // 8 + 1, N // 2: N // 2 + N // 8] = 0
+    m[0, : N // 6, : N // 5] = 0
+    m[0, 0, :] = m[0, -1, :] = m[0, :, 0] = m[0, :, -1] = 0
+    return m
+
+
+def topo_field(N):
+    x = np.arange(N + 1) / N
+    return 0.05 * np.outer(np.cos(2 * np.pi * x), np.sin(np.pi * x))[None]
+
+
+def make_pair(N, nl, strict, bc_fac=0.0, nu4=0.0, mask=False, topo=False, pg=False, extra="", **opts):
+    par = orn.node_params(N, nl, bc_fac=bc_fac, nu4=nu4, extra=extra)
+    o = orn.NodeOracle(par, smoother=orn.GS_RB, quiet=1, **opts)
+    g = NodeQG(par, strict=strict)
+    g.set_option("quiet", 1)
+    for k, v in opts.items():
+        g.set_option(k, v)
+    psi = orn.node_psi(nl, N)
+    if mask:
+        mk = land_mask(N)
+        psi = psi * mk
+        o.set(orn.MASK, mk); g.set("MASK", mk)
+    if topo and nl > 1:
+        tp = topo_field(N)
+        o.set(orn.TOPO, tp); g.set("TOPO", tp)
+    if pg and nl > 1:
+        pgf = 0.3 * orn.node_psi(nl, N)[::-1].copy()
+        o.set(orn.PSIPG, pgf); g.set("PSIPG", pgf)
+    o.set(orn.PSI, psi); g.set("PSI", psi)
+    o.set_const(); g.set_const()
+    return o, g
+
+
+def same(a, b, strict, rtol=1e-9):
+    if strict:
+        assert np.array_equal(a, b), f"max diff {np.abs(a - b).max():g}"
+    else:
+        assert np.abs(a - b).max() <= rtol * max(np.abs(b).max(), 1e-300), f"rel diff {np.abs(a - b).max() / np.abs(b).max():g}"
+
+
+FIELDS = [("PSI", orn.PSI), ("Q", orn.Q)]
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nl", [1, 2, 3, 4])
+def test_set_const_and_comp_q(nl, strict):
+    o, g = make_pair(32, nl, strict, bc_fac=0.5, mask=True, extra="flag_ms = 1\ngp_low = 0.02\n")
+    assert g.param("DT") == o.param("DT")
+    assert g.param("iRd2_low") == o.param("iRd2_low")
+    for l in range(nl):
+        assert g.param(f"idh0_{l}") == o.param(f"idh0_{l}") and g.param(f"idh1_{l}") == o.param(f"idh1_{l}")
+    if nl > 1:
+        same(g.get("S2"), o.get(orn.S2), True)
+    same(g.get("Q"), o.get(orn.Q), strict, 1e-12)
+    for k in range(g.nlevels):
+        assert np.array_equal(g.dbg_level_mask(k), o.level_mask(k))
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nl", [1, 3])
+def test_multigrid_pieces(nl, strict):
+    N = 32
+    o, g = make_pair(N, nl, strict, mask=True, extra="gp_low = 0.02\n")
+    rng = np.random.default_rng(5)
+    for k in range(g.nlevels):
+        n1 = (N >> k) + 1
+        da, res = rng.standard_normal((nl, n1, n1)), rng.standard_normal((nl, n1, n1))
+        same(g.dbg_relax(k, da, res, 2), o.relax(k, da, res, 2), strict, 1e-11)
+        if k + 1 < g.nlevels:
+            same(g.dbg_restrict(k, res), o.restrict(k, res), strict, 1e-13)
+        if k > 0:
+            same(g.dbg_prolong(k, da), o.prolong(k, da), strict, 1e-13)
+    a, b = rng.standard_normal((nl, N + 1, N + 1)), rng.standard_normal((nl, N + 1, N + 1))
+    rg, mg = g.dbg_residual(a, b)
+    ro, mo = o.residual(a, b)
+    same(rg, ro, strict, 1e-12)
+    assert mg == np.abs(rg).max()
+    if strict:
+        assert mg == mo
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nl,bc_fac,mask", [(1, 0.0, False), (1, 1.0, True), (2, 0.0, True), (3, 1.0, False), (4, 0.5, True)])
+def test_invert_and_rhs(nl, bc_fac, mask, strict):
+    o, g = make_pair(32, nl, strict, bc_fac=bc_fac, nu4=2.0, mask=mask, topo=True, pg=True, extra="gp_low = 0.02\n", TOLERANCE=1e-9)
+    o.forcing(); g.forcing()
+    same(g.get("QFORC"), o.get(orn.QFORC), True)
+    so, sg = o.invert_q(), g.invert_q()
+    if strict:
+        assert (sg.i, sg.resb, sg.resa) == (so.i, so.resb, so.resa)
+    else:
+        assert abs(sg.i - so.i) <= 1 and sg.resa < 1e-9
+    same(g.get("PSI"), o.get(orn.PSI), strict, 1e-7)
+    o.rhs_pv(); g.rhs_pv()
+    if nl > 1:
+        same(g.get("ZETA"), o.get(orn.ZETA), strict, 1e-7)
+    same(g.get("DQ"), o.get(orn.DQ), strict, 1e-6)
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nl,N", [(1, 64), (3, 32), (4, 64)])
+def test_time_steps(nl, N, strict):
+    o, g = make_pair(N, nl, strict, bc_fac=1.0, nu4=1.0, mask=True, topo=True, extra="gp_low = 0.02\ntau1 = 5e-4\ntf1 = 0.3\ntf2 = 0.7\n", TOLERANCE=1e-8)
+    o.set_tnext(0.11); g.set_tnext(0.11)
+    for it in range(6):
+        o.step(True); g.step(True)
+        if strict:
+            assert (g.t, g.dt) == (o.t, o.dt)
+            assert g.mgstats().i == o.mgstats().i
+        else:
+            assert abs(g.t - o.t) <= 1e-12 * o.t and abs(g.dt - o.dt) <= 1e-9 * o.dt
+    for gf, of in FIELDS:
+        same(g.get(gf), o.get(of), strict, 1e-6)
+    ke_o = o.ke()
+    assert abs(g.ke() - ke_o) <= 1e-10 * abs(ke_o)
+    assert g.iter == 6
+
+
+def test_full_size_properties():
+    """2048^2 x 3 vertex grid with an island: the elliptic solve converges, q -> psi -> q closes, KE finite"""
+    N, nl = 2048, 3
+    par = orn.node_params(N, nl, bc_fac=1.0)
+    g = NodeQG(par)
+    g.set_option("quiet", 1)
+    g.set_option("TOLERANCE", 1e-7)
+    mk = land_mask(N)
+    psi = orn.node_psi(nl, N) * mk
+    g.set("MASK", mk)
+    g.set("PSI", psi)
+    g.set_const()
+    q0 = g.get("Q")
+    g.set("PSI", np.zeros_like(psi))
+    st = g.invert_q()
+    assert st.resa < 1e-7 and st.i < 30
+    inner = mk[0] == 1
+    p1 = g.get("PSI")
+    assert np.all(p1[:, ~inner] == 0)
+    g.comp_q()
+    q1 = g.get("Q")
+    assert np.abs((q1 - q0)[:, inner]).max() <= 2e-7
+    for _ in range(2):
+        g.step(True)
+    assert np.isfinite(g.ke()) and g.t > 0
+
+
+def test_netcdf_round_trip_and_driver(tmp_path):
+    from scipy.io import netcdf_file
+    N, nl = 32, 2
+    par = orn.node_params(N, nl, extra="noise_init = 1e-3\ntend = 0.2\ndtout = 0.1\n")
+    g = NodeQG(par)
+    g.set_option("quiet", 1)
+    n = g.run(str(tmp_path))
+    assert n > 0 and abs(g.t - 0.2) < 1e-12
+    out = tmp_path / "outdir_0001"
+    assert (out / "params.in").read_text() == par
+    with netcdf_file(str(out / "vars.nc"), "r", mmap=False) as nc:
+        assert nc.variables["psi"].shape == (3, nl, N + 1, N + 1)
+        assert np.allclose(nc.variables["time"][:], [0, 0.1, 0.2])
+        assert np.allclose(nc.variables["x"][:], np.arange(N + 1) * 100.0 / N)
+        last = np.array(nc.variables["psi"][-1], dtype=np.float64)
+    assert np.allclose(last, g.get("PSI"), rtol=1e-6, atol=1e-9)
+    g2 = NodeQG(par)
+    g2.read_nc("PSI", str(out / "vars.nc"), "psi")
+    assert np.allclose(g2.get("PSI"), last)
+
+
+def test_error_convention():
+    from msom_amd import MsomError
+    with pytest.raises(MsomError, match="power of two"):
+        NodeQG(orn.node_params(48, 2))
+    with pytest.raises(MsomError, match="periodic"):
+        NodeQG(orn.node_params(32, 2, bc_fac=-1))
+    g = NodeQG(orn.node_params(16, 2))
+    with pytest.raises(MsomError, match="set_const"):
+        g.step()
