@@ -174,6 +174,9 @@ int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, double add, doub
 int msom_profile_read(msom_t *m, const char *kernel, double *avg_ms, long *launches);
 int msom_profile_reset(msom_t *m);
 int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double *avg_ms);
+/* one-rank RCCL communicator on the current device: grouped send/recv to self, all-reduce and
+ * all-gather through the library's transport code (wiring check on a single GPU) */
+int msom_dbg_rccl_selftest(void);
 
 /* ======================================================================================
  * Vertex-grid (masked-domain) variant: qg-node/qg.h + qg_baroclinic_ms.h (nl >= 2) /

@@ -86,6 +86,7 @@ def load_library(strict=False):
         "msom_profile_read": (ci, [vp, cs, _dp, C.POINTER(C.c_long)]),
         "msom_profile_reset": (ci, [vp]),
         "msom_bench_kernel": (ci, [vp, cs, ci, _dp]),
+        "msom_dbg_rccl_selftest": (ci, []),
         # vertex-grid variant (qg-node/)
         "msomn_create": (vp, [cs]),
         "msomn_create_str": (vp, [cs]),

@@ -355,3 +355,44 @@ void launch_split_unpack_strip(hipStream_t st, double *f, const SplitGeom &g, in
 void launch_split_wall_corners(hipStream_t st, double *f, const SplitGeom &g, int nl, int walls) {
   hipLaunchKernelGGL(k_split_wall_corners, dim3(1), dim3(64), 0, st, f, g, nl, walls);
 }
+
+// ------------------------------------------------------------------ RCCL wiring self-test
+// One-rank communicator on the current device: grouped ncclSend/ncclRecv to self (two messages,
+// as one exchange posts them), max/sum all-reduce and all-gather, through exactly the code paths
+// above.  Checks the dlopen()ed entry points, enum values and stream ordering on a single GPU,
+// where a 2-rank communicator cannot be formed.
+extern "C" int msom_dbg_rccl_selftest(void) {
+  int r = rccl_load();
+  if (r) return r;
+  ncclUniqueId id;
+  NCCLCHK(g_rccl.GetUniqueId(&id));
+  hipStream_t st;
+  HIPCHKC(hipStreamCreate(&st));
+  Comm c;
+  c.kind = COMM_RCCL; c.rank = 0; c.n = 1; c.st = st;
+  NCCLCHK(g_rccl.CommInitRank(&c.nccl, 1, id, 0));
+  const int n = 1000;
+  double *d = nullptr;
+  HIPCHKC(hipMalloc(&d, 6 * n * sizeof(double)));
+  std::vector<double> h(6 * n, 0.);
+  for (int k = 0; k < 2 * n; k++) h[k] = 1.5 * k - 7.;
+  HIPCHKC(hipMemcpyAsync(d, h.data(), 6 * n * sizeof(double), hipMemcpyHostToDevice, st));
+  Xfer x[2] = {{0, DIR_W, d, d + 2 * n, (size_t)n}, {0, DIR_E, d + n, d + 3 * n, (size_t)n}};
+  if ((r = comm_exchange(&c, x, 2))) return r;
+  if ((r = comm_allgather(&c, d, d + 4 * n, n))) return r;
+  double hs[2];
+  if ((r = comm_allreduce(&c, d + 1, hs, 2, RED_MAX))) return r;
+  if ((r = comm_allreduce(&c, d + 1, hs, 2, RED_SUM))) return r;
+  HIPCHKC(hipMemcpyAsync(h.data(), d, 6 * n * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHKC(hipStreamSynchronize(st));
+  int bad = 0;
+  for (int k = 0; k < 2 * n; k++) bad += h[2 * n + k] != 1.5 * k - 7.;
+  for (int k = 0; k < n; k++) bad += h[4 * n + k] != 1.5 * k - 7.;
+  bad += hs[0] != 1.5 * 1 - 7. || hs[1] != 1.5 * 2 - 7.;
+  g_rccl.CommDestroy(c.nccl);
+  c.nccl = nullptr;
+  (void)hipFree(d);
+  (void)hipStreamDestroy(st);
+  if (bad) { msom_set_error("RCCL self-test: %d wrong values", bad); return MSOM_ERR_COMM; }
+  return MSOM_OK;
+}

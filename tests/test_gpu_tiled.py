@@ -143,6 +143,15 @@ def test_rccl_library_resolves():
     assert L.msom_set_device(0) == 0
 
 
+def test_rccl_transport_selftest():
+    """one-rank RCCL communicator: grouped ncclSend/ncclRecv to self, all-reduce, all-gather through
+    comm_exchange / comm_allreduce / comm_allgather (the transport bench.py --gpus N uses)"""
+    from msom_amd import load_library
+    L = load_library()
+    assert L.msom_set_device(0) == 0
+    assert L.msom_dbg_rccl_selftest() == 0, L.msom_last_error().decode()
+
+
 @pytest.mark.parametrize("px,py,tile,nl", [(2, 2, 32, 3), (2, 4, 16, 6), (2, 1, 64, 2)])
 @pytest.mark.parametrize("agg_size,expect_level", [(64, 0), (8, None), (0, -1)])
 @pytest.mark.parametrize("strict", [True, False])
