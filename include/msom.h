@@ -54,7 +54,9 @@ enum {
   MSOM_PTR_RELAX = 16, /* ptr_relaxl                         */
   MSOM_DPTR = 17,      /* tracer part of `updates`           */
   MSOM_PTR_PRED = 18,  /* tracer part of the predictor       */
-  MSOM_NFIELDS = 19
+  MSOM_RD = 19,        /* Rd, deformation radius of the filter scale, 1 layer (msqg/qg.h:47,913,963-968) */
+  MSOM_QOF = 20,       /* qofl, filter mean (msqg/qg.h:27,549); allocated on first use           */
+  MSOM_NFIELDS = 21
 };
 
 /* mgstats of Basilisk (text: mspg/elliptic.h:118-123), kept by the reference in `mgpsi`
@@ -147,6 +149,18 @@ int msom_read_bas(msom_t *m, int field, const char *path);
  * (restart: "psi" -> MSOM_PSI, then msom_set_const). */
 int msom_write_nc(msom_t *m, const char *path);
 int msom_read_nc(msom_t *m, int field, const char *path, const char *varname, int record);
+
+/* ---- wavelet scale filter, the "multiple scale" part of msom (msqg/qg.h:509-560; event filter :655-658;
+ * coefficients sig_lev from sig_filt = min(afilt * Rd, Lfmax), :1059-1090).  Saves q in tmp, inverts
+ * q -> psi, removes from every layer of psi the wavelet details selected by sig_lev, recomputes q and
+ * sets qof = (q_before - q_after) / dtflt; dtflt < 0 (energy diagnostics, qg_energy.h:213) restores q.
+ * Single tile only. */
+int msom_wavelet_filter(msom_t *m, double dtflt);
+/* pieces for the parity tests: number of pyramid levels (level 0 = finest ... 1 x 1 cell), sig_lev of
+ * one level [ny>>level][nx>>level], and the bare transform-scale-inverse applied to a field */
+int msom_dbg_wavelet_levels(msom_t *m);
+int msom_dbg_siglev(msom_t *m, int level, double *out);
+int msom_dbg_wavelet_apply(msom_t *m, int field);
 
 /* select the HIP device of the calling thread before msom_create* (one process per GPU:
  * device = LOCAL_RANK) */

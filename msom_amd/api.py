@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBDIR = os.path.join(_HERE, "lib")
 
 FIELDS = dict(PSI=0, Q=1, ZETA=2, PSIPG=3, ZETAPG=4, QFORC=5, TMP=6, FR=7, S=8, DQ=9, RO=10, TOPO=11,
-              QPRED=12, NOISE=13, SIGMA=14, PTR=15, PTR_RELAX=16, DPTR=17, PTR_PRED=18)
+              QPRED=12, NOISE=13, SIGMA=14, PTR=15, PTR_RELAX=16, DPTR=17, PTR_PRED=18, RD=19, QOF=20)
 
 
 class MsomError(RuntimeError):
@@ -87,6 +87,10 @@ def load_library(strict=False):
         "msom_profile_reset": (ci, [vp]),
         "msom_bench_kernel": (ci, [vp, cs, ci, _dp]),
         "msom_dbg_rccl_selftest": (ci, []),
+        "msom_wavelet_filter": (ci, [vp, cd]),
+        "msom_dbg_wavelet_levels": (ci, [vp]),
+        "msom_dbg_siglev": (ci, [vp, ci, vp]),
+        "msom_dbg_wavelet_apply": (ci, [vp, ci]),
         # vertex-grid variant (qg-node/)
         "msomn_create": (vp, [cs]),
         "msomn_create_str": (vp, [cs]),
@@ -282,6 +286,24 @@ class QG:
 
     def run(self, workdir=".", nsteps_max=-1):
         self._chk(self.L.msom_run(self.h, workdir.encode(), nsteps_max))
+
+    # wavelet scale filter (msqg/qg.h:509-560)
+    def wavelet_filter(self, dtflt):
+        self._chk(self.L.msom_wavelet_filter(self.h, dtflt))
+
+    def wavelet_levels(self):
+        n = self.L.msom_dbg_wavelet_levels(self.h)
+        if n < 0:
+            self._chk(n)
+        return n
+
+    def siglev(self, level):
+        a = np.empty((1, self.ny >> level, self.nx >> level))
+        self._chk(self.L.msom_dbg_siglev(self.h, level, _ptr(a)))
+        return a
+
+    def wavelet_apply(self, field):
+        self._chk(self.L.msom_dbg_wavelet_apply(self.h, field))
 
     def write_bas(self, field, path):
         self._chk(self.L.msom_write_bas(self.h, field, path.encode()))

@@ -83,6 +83,13 @@ void launch_relax_red_prolong(hipStream_t st, double *da, const double *coarse, 
                               const SplitGeom &sg, int nl, const RelaxCoef &rc, int uniformS, int walls);
 void launch_correct(hipStream_t st, double *a, const NatGeom &g, const double *da, const SplitGeom &sg, int nl, int walls);
 
+// ---- kernels_wavelet.hip
+void launch_wv_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl);
+void launch_wv_recon(hipStream_t st, const double *s, const double *sc, const double *rc, const double *sig, double *out, const NatGeom &fg,
+                     const NatGeom &cg, int nl);
+void launch_wv_root(hipStream_t st, const double *s, const double *sig, double *r, const NatGeom &g, int nl);
+void launch_wv_qof(hipStream_t st, double *qof, double *q, const double *tmp, const NatGeom &g, int nl, double dtflt, int nbar, int restore);
+
 // ---- kernels_node.hip (vertex-grid variant, qg-node/)
 void launch_n_bnd_from(hipStream_t st, double *f, const double *g, const NatGeom &ge, int nl, double c, int use_g_bnd, double gbc);
 void launch_n_bnd_const(hipStream_t st, double *f, const NatGeom &ge, int nl, double v);

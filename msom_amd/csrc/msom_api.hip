@@ -96,6 +96,10 @@ struct msom {
   int fused = 1;  // one-pass PV tendency kernel (kernels_fused.hip) when the configuration allows
   unsigned seed = 1, noise_draw = 0;
   int quiet = 0;
+  // wavelet scale filter (msqg/qg.h:509-560): pyramids s (restricted psi), r (filtered), sig_lev
+  int wv_nlev = 0, wv_ready = 0;
+  std::vector<NatGeom> wv_g;
+  std::vector<double *> wv_s, wv_r, wv_sig;
   // time loop
   double t = 0, dt = 1., tnext = HUGE_VAL, previous = 0;
   int iter = 0;
@@ -283,9 +287,11 @@ static int alloc_all(msom *m) {
     m->flayers[k] = m->nl * (m->p.nptr > 0 ? m->p.nptr : 1);
     m->fbc[k] = m->bc == BC_PERIODIC ? BC_PERIODIC : BC_NEUMANN;
   }
+  m->flayers[MSOM_RD] = 1;
+  m->fbc[MSOM_RD] = m->bc == BC_PERIODIC ? BC_PERIODIC : BC_NEUMANN;
   for (int k = 0; k < MSOM_NFIELDS; k++) {
-    if (k == MSOM_NOISE || k == MSOM_SIGMA) continue;  // allocated when "stochastic" is switched on
-    if (k >= MSOM_PTR && m->p.nptr <= 0) continue;
+    if (k == MSOM_NOISE || k == MSOM_SIGMA || k == MSOM_QOF) continue;  // allocated when "stochastic" is switched on / on the first filter call
+    if (k >= MSOM_PTR && k <= MSOM_PTR_PRED && m->p.nptr <= 0) continue;
     size_t bytes = m->g.ls * m->flayers[k] * sizeof(double);
     HIPCHK(hipMalloc(&m->f[k], bytes));
     HIPCHK(hipMemsetAsync(m->f[k], 0, bytes, m->st));
@@ -354,6 +360,9 @@ static int set_vars(msom *m) {
   // Ro[] = Rom, topo = 0  (:911-915)
   for (size_t k = 0; k < (size_t)m->nx * m->ny; k++) h[k] = p.Rom;
   r = msom_set_field(m, MSOM_RO, h.data());
+  if (r) return r;
+  for (size_t k = 0; k < (size_t)m->nx * m->ny; k++) h[k] = 1.;  // Rd[] = 1. (:913)
+  r = msom_set_field(m, MSOM_RD, h.data());
   m->fr_uniform = 1;
   return r;
 }
@@ -455,6 +464,11 @@ extern "C" int msom_destroy(msom_t *m) {
     if (m->S[k]) hipFree(m->S[k]);
   }
   free_agglomeration(m);
+  for (size_t k = 0; k < m->wv_sig.size(); k++) {
+    if (k > 0 && m->wv_s[k]) hipFree(m->wv_s[k]);
+    if (k > 0 && m->wv_r[k]) hipFree(m->wv_r[k]);
+    if (m->wv_sig[k]) hipFree(m->wv_sig[k]);
+  }
   if (m->psi_alt) hipFree(m->psi_alt);
   if (m->staging) hipFree(m->staging);
   if (m->partial) hipFree(m->partial);
@@ -589,10 +603,13 @@ extern "C" int msom_field_layers(msom_t *m, int field) {
   return m->flayers[field];
 }
 
+static int ensure_field(msom *m, int field);
 extern "C" int msom_set_field(msom_t *m, int field, const double *a) {
+  if (m && field == MSOM_QOF && ensure_field(m, field)) return MSOM_ERR_HIP;
   if (check_field(m, field) || !a) return MSOM_ERR_ARG;
   int r = upload(m, field, a);
   if (r) return r;
+  if (field == MSOM_RD) m->wv_ready = 0;
   if (field == MSOM_FR || field == MSOM_RO || field == MSOM_S) { m->fr_uniform = 0; m->const_set = 0; }
   if (field == MSOM_PSIPG) m->have_pg = 1;
   if (field == MSOM_ZETAPG) m->have_zpg = 1;
@@ -601,6 +618,7 @@ extern "C" int msom_set_field(msom_t *m, int field, const double *a) {
   return sync_stream(m);
 }
 extern "C" int msom_get_field(msom_t *m, int field, double *a) {
+  if (m && field == MSOM_QOF && ensure_field(m, field)) return MSOM_ERR_HIP;
   if (check_field(m, field) || !a) return MSOM_ERR_ARG;
   return download(m, field, a);
 }
@@ -762,6 +780,7 @@ extern "C" int msom_set_const(msom_t *m) {
   if (!m) return MSOM_ERR_ARG;
   int rr = build_coefs(m);
   if (rr) return rr;
+  m->wv_ready = 0;  // sig_filt / sig_lev are rebuilt from Rd on the next filter call (msqg/qg.h:1059-1090)
   const Params &p = m->p;
   const int nl = m->nl;
   const double D = p.L0 / m->gnx;
@@ -1334,6 +1353,153 @@ extern "C" double msom_ke(msom_t *m) {
   return -m->h_scal[SC_KE];
 }
 
+// ------------------------------------------------------------------ wavelet scale filter (msqg/qg.h:509-560)
+
+static int ensure_field(msom *m, int field) {
+  if (m->f[field]) return MSOM_OK;
+  const size_t bytes = m->g.ls * m->flayers[field] * sizeof(double);
+  HIPCHK(hipMalloc(&m->f[field], bytes));
+  HIPCHK(hipMemsetAsync(m->f[field], 0, bytes, m->st));
+  return MSOM_OK;
+}
+// pyramid geometry + filter coefficients sig_lev (set_const, msqg/qg.h:1059-1090): init-time host pass
+static int wavelet_setup(msom *m) {
+  if (m->wv_ready) return MSOM_OK;
+  if (m->nranks > 1) { msom_set_error("the wavelet filter needs a single-tile grid"); return MSOM_ERR_STATE; }
+  const Params &p = m->p;
+  int r;
+  if (m->wv_nlev == 0) {
+    int n = 1;
+    while ((m->nx >> n) >= 1 && (m->ny >> n) >= 1 && ((m->nx >> n) << n) == m->nx && ((m->ny >> n) << n) == m->ny) n++;
+    m->wv_nlev = n;  // Basilisk levels depth() ... 0
+    m->wv_g.resize(n); m->wv_s.assign(n, nullptr); m->wv_r.assign(n, nullptr); m->wv_sig.assign(n, nullptr);
+    for (int k = 0; k < n; k++) {
+      m->wv_g[k] = make_nat(m->nx >> k, m->ny >> k);
+      const size_t ls = m->wv_g[k].ls;
+      HIPCHK(hipMalloc(&m->wv_sig[k], ls * sizeof(double)));
+      HIPCHK(hipMemsetAsync(m->wv_sig[k], 0, ls * sizeof(double), m->st));
+      if (k == 0) continue;  // level 0 works in place on the field
+      HIPCHK(hipMalloc(&m->wv_s[k], ls * m->nl * sizeof(double)));
+      HIPCHK(hipMalloc(&m->wv_r[k], ls * m->nl * sizeof(double)));
+      HIPCHK(hipMemsetAsync(m->wv_s[k], 0, ls * m->nl * sizeof(double), m->st));
+      HIPCHK(hipMemsetAsync(m->wv_r[k], 0, ls * m->nl * sizeof(double), m->st));
+    }
+  }
+  const int K = m->wv_nlev;
+  std::vector<std::vector<double>> sf(K), sl(K);
+  sf[0].resize((size_t)m->nx * m->ny);
+  HIPCHK(hipStreamSynchronize(m->st));
+  launch_unpack(m->st, m->f[MSOM_RD], m->staging, m->g, 1);
+  HIPCHK(hipMemcpyAsync(sf[0].data(), m->staging, sf[0].size() * sizeof(double), hipMemcpyDeviceToHost, m->st));
+  HIPCHK(hipStreamSynchronize(m->st));
+  for (double &v : sf[0]) v = fmin(p.afilt * v, p.Lfmax);  // sig_filt = min(afilt * Rd, Lfmax) :1060
+  for (int k = 1; k < K; k++) {  // restriction({sig_filt}) :1063
+    const int nx = m->nx >> k, ny = m->ny >> k, fx = nx * 2;
+    sf[k].resize((size_t)nx * ny);
+    for (int j = 0; j < ny; j++)
+      for (int i = 0; i < nx; i++) {
+        double sum = 0.;
+        sum += sf[k - 1][(size_t)(2 * j) * fx + 2 * i]; sum += sf[k - 1][(size_t)(2 * j + 1) * fx + 2 * i];
+        sum += sf[k - 1][(size_t)(2 * j) * fx + 2 * i + 1]; sum += sf[k - 1][(size_t)(2 * j + 1) * fx + 2 * i + 1];
+        sf[k][(size_t)j * nx + i] = sum / 4;
+      }
+  }
+  for (int k = 0; k < K; k++) {  // low pass, from the finest level down :1066-1083
+    const int nx = m->nx >> k, ny = m->ny >> k, fx = nx * 2;
+    const double Delta = p.L0 / (double)(m->gnx >> k);
+    sl[k].resize((size_t)nx * ny);
+    for (int j = 0; j < ny; j++)
+      for (int i = 0; i < nx; i++) {
+        double ref_flag = 0;
+        if (k > 0) {
+          ref_flag += sl[k - 1][(size_t)(2 * j) * fx + 2 * i]; ref_flag += sl[k - 1][(size_t)(2 * j + 1) * fx + 2 * i];
+          ref_flag += sl[k - 1][(size_t)(2 * j) * fx + 2 * i + 1]; ref_flag += sl[k - 1][(size_t)(2 * j + 1) * fx + 2 * i + 1];
+        }
+        const double s = sf[k][(size_t)j * nx + i];
+        double v;
+        if (ref_flag > 0) v = 1;
+        else if (s > 2 * Delta) v = 0;
+        else if (s <= 2 * Delta && s > Delta) v = 1 - (s - Delta) / Delta;
+        else v = 1;
+        sl[k][(size_t)j * nx + i] = v;
+      }
+  }
+  for (int k = 0; k < K; k++) {  // high pass :1086-1090, then to the device
+    for (double &v : sl[k]) v = 1 - v;
+    const NatGeom &g = m->wv_g[k];
+    HIPCHK(hipMemcpy2DAsync(m->wv_sig[k] + nat_idx(g, 0, 0, 0), g.pitch * sizeof(double), sl[k].data(), g.nx * sizeof(double), g.nx * sizeof(double), g.ny,
+                            hipMemcpyHostToDevice, m->st));
+  }
+  HIPCHK(hipStreamSynchronize(m->st));
+  (void)r;
+  m->wv_ready = 1;
+  return MSOM_OK;
+}
+static void wv_fill(msom *m, double *f, const NatGeom &g) {
+  if (m->bc == BC_PERIODIC) launch_fill_periodic(m->st, f, g, m->nl, 1);
+  else launch_fill_ghost(m->st, f, g, m->nl, m->bc, m->walls);
+}
+// field <- inverse_wavelet(sig_lev * wavelet(field)), all layers (msqg/qg.h:524-539)
+static int wavelet_apply(msom *m, double *f) {
+  int r = wavelet_setup(m);
+  if (r) return r;
+  const int K = m->wv_nlev, nl = m->nl;
+  wv_fill(m, f, m->g);
+  for (int k = 1; k < K; k++) {
+    launch_wv_restrict(m->st, k == 1 ? f : m->wv_s[k - 1], m->wv_g[k - 1], m->wv_s[k], m->wv_g[k], nl);
+    wv_fill(m, m->wv_s[k], m->wv_g[k]);
+  }
+  if (K == 1) launch_wv_root(m->st, f, m->wv_sig[0], f, m->g, nl);
+  else launch_wv_root(m->st, m->wv_s[K - 1], m->wv_sig[K - 1], m->wv_r[K - 1], m->wv_g[K - 1], nl);
+  if (K > 1) wv_fill(m, m->wv_r[K - 1], m->wv_g[K - 1]);
+  for (int k = K - 2; k >= 0; k--) {
+    double *s = k == 0 ? f : m->wv_s[k], *out = k == 0 ? f : m->wv_r[k];
+    launch_wv_recon(m->st, s, m->wv_s[k + 1], m->wv_r[k + 1], m->wv_sig[k], out, m->wv_g[k], m->wv_g[k + 1], nl);
+    wv_fill(m, out, m->wv_g[k]);
+  }
+  HIPCHK(hipGetLastError());
+  return MSOM_OK;
+}
+extern "C" int msom_wavelet_filter(msom_t *m, double dtflt) {
+  NEED_CONST(m);
+  int r;
+  if ((r = wavelet_setup(m)) || (r = ensure_field(m, MSOM_QOF))) return r;
+  const int nl = m->nl;
+  // tmp = q (interior; the saved copy is restored into q when dtflt < 0)
+  HIPCHK(hipMemcpyAsync(m->f[MSOM_TMP], m->f[MSOM_Q], m->g.ls * nl * sizeof(double), hipMemcpyDeviceToDevice, m->st));
+  if ((r = invertq(m, m->f[MSOM_Q]))) return r;
+  if ((r = wavelet_apply(m, m->f[MSOM_PSI]))) return r;
+  m->umax_ready = 0;
+  comp_del2(m, MSOM_PSI, MSOM_Q, 0., 1.);
+  comp_stretch(m, MSOM_PSI, MSOM_Q, 1., 1.);
+  // `nbar` is a by-value argument in the reference (msqg/qg.h:510,558): the running mean never advances
+  launch_wv_qof(m->st, m->f[MSOM_QOF], m->f[MSOM_Q], m->f[MSOM_TMP], m->g, nl, dtflt, 0, dtflt < 0.0);
+  if (dtflt < 0.0) fill_bc(m, MSOM_Q);
+  fill_bc(m, MSOM_QOF);
+  return sync_stream(m);
+}
+extern "C" int msom_dbg_wavelet_levels(msom_t *m) {
+  if (!m) return MSOM_ERR_ARG;
+  int r = wavelet_setup(m);
+  return r ? r : m->wv_nlev;
+}
+extern "C" int msom_dbg_siglev(msom_t *m, int level, double *out) {
+  if (!m || !out) return MSOM_ERR_ARG;
+  int r = wavelet_setup(m);
+  if (r) return r;
+  if (level < 0 || level >= m->wv_nlev) { msom_set_error("bad level %d", level); return MSOM_ERR_ARG; }
+  const NatGeom &g = m->wv_g[level];
+  HIPCHK(hipMemcpy2DAsync(out, g.nx * sizeof(double), m->wv_sig[level] + nat_idx(g, 0, 0, 0), g.pitch * sizeof(double), g.nx * sizeof(double), g.ny,
+                          hipMemcpyDefault, m->st));
+  return sync_stream(m);
+}
+extern "C" int msom_dbg_wavelet_apply(msom_t *m, int field) {
+  NEED_CONST(m);
+  if (field < 0 || field >= MSOM_NFIELDS || !m->f[field] || m->flayers[field] != m->nl) { msom_set_error("bad field id %d", field); return MSOM_ERR_ARG; }
+  int r = wavelet_apply(m, m->f[field]);
+  return r ? r : sync_stream(m);
+}
+
 // ------------------------------------------------------------------ .bas IO and the qg.c driver loop
 
 extern "C" int msom_write_bas(msom_t *m, int field, const char *path) {
@@ -1397,7 +1563,8 @@ extern "C" int msom_read_inputs(msom_t *m, const char *dir) {
     if (!m->quiet) fprintf(stdout, "%s .. ok\n", name);
   }
   struct { const char *fmt; int field; } files[] = {
-      {"%s/psipg_%dl_N%d.bas", MSOM_PSIPG}, {"%s/frpg_%dl_N%d.bas", MSOM_FR}, {"%s/qforc_%dl_N%d.bas", MSOM_QFORC}};
+      {"%s/psipg_%dl_N%d.bas", MSOM_PSIPG}, {"%s/frpg_%dl_N%d.bas", MSOM_FR}, {"%s/rdpg_%dl_N%d.bas", MSOM_RD},
+      {"%s/qforc_%dl_N%d.bas", MSOM_QFORC}};
   for (auto &f : files) {
     snprintf(name, sizeof name, f.fmt, d, nl, N);
     if (file_exists(name)) {
@@ -1443,15 +1610,15 @@ static int backup_config(msom *m, const char *dpath) {
     msom_set_error("cannot write %s", name);
     return MSOM_ERR_IO;
   }
-  // sig_filt = min(afilt * Rd, Lfmax) with Rd = 1 (msqg/qg.h:913,1060); Rd itself
-  std::vector<double> h(n2 * nl, 0.);
-  for (size_t k = 0; k < n2; k++) h[k] = fmin(m->p.afilt * 1., m->p.Lfmax);
+  // sig_filt = min(afilt * Rd, Lfmax) (msqg/qg.h:1060) and Rd itself (:794-810)
+  std::vector<double> h(n2 * nl, 0.), rd(n2);
+  int r;
+  if ((r = download(m, MSOM_RD, rd.data()))) return r;
+  for (size_t k = 0; k < n2; k++) h[k] = fmin(m->p.afilt * rd[k], m->p.Lfmax);
   snprintf(name, sizeof name, "%ssig_filt.bas", dpath);
   if (msom_bas_write(name, h.data(), 1, m->nx, m->p.L0)) return MSOM_ERR_IO;
-  for (size_t k = 0; k < n2; k++) h[k] = 1.;
   snprintf(name, sizeof name, "%srdpg_%dl_N%d.bas", dpath, nl, N);
-  if (msom_bas_write(name, h.data(), 1, m->nx, m->p.L0)) return MSOM_ERR_IO;
-  int r;
+  if (msom_bas_write(name, rd.data(), 1, m->nx, m->p.L0)) return MSOM_ERR_IO;
   snprintf(name, sizeof name, "%spsipg_%dl_N%d.bas", dpath, nl, N);
   if ((r = msom_write_bas(m, MSOM_PSIPG, name))) return r;
   // Frl has nl layers in the reference (nl - 1 used, the last one stays 0)
@@ -1489,10 +1656,17 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
     }
   }
   double tout = 0.;  // next output event: t = 0; t <= tend + 1e-10; t += dtout
+  double tflt = p.dtflt;  // next filter event: t = dtflt; t <= tend + 1e-10; t += dtflt (msqg/qg.h:655-658)
+  const bool filtering = p.dtflt > 0;
   long steps = 0;
   int r;
   if (m->iter == 0 && (r = backup_config(m, dpath))) return r;  // event write_const (t = 0)
   for (;;) {
+    if (filtering && tflt <= p.tend + 1e-10 && m->t >= tflt - 1e-12 * fmax(1., fabs(tflt))) {
+      fprintf(stdout, "Filter solution\n");
+      if ((r = msom_wavelet_filter(m, p.dtflt))) return r;
+      tflt += p.dtflt;
+    }
     // writestdout, msqg/qg.c:101-109
     fprintf(stdout, "i = %i, dt = %g, t = %g, ke_1 = %g\n", m->iter, m->dt, m->t, msom_ke(m));
     // output, msqg/qg.c:112-122
@@ -1504,6 +1678,21 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
       if ((r = msom_write_bas(m, MSOM_PSI, name))) return r;
       snprintf(name, sizeof name, "%sqo%09d.bas", dpath, m->iter);
       if ((r = msom_write_bas(m, MSOM_Q, name))) return r;
+      if (filtering) {  // msqg/qg.c:124-129: psi of the filter mean, tmpl = invertq(qofl)
+        if ((r = ensure_field(m, MSOM_QOF))) return r;
+        double *keep = m->f[MSOM_PSI];
+        const msom_mgstats mgkeep = m->mg;
+        m->f[MSOM_PSI] = m->f[MSOM_TMP];  // invertq(tmpl, qofl): tmp is the unknown (and the first guess)
+        r = invertq(m, m->f[MSOM_QOF]);
+        double *solved = m->f[MSOM_PSI];
+        if (solved != m->f[MSOM_TMP]) { m->psi_alt = m->f[MSOM_TMP]; m->f[MSOM_TMP] = solved; }  // the fused correction swaps buffers
+        m->f[MSOM_PSI] = keep;
+        m->mg = mgkeep;
+        m->umax_ready = 0;
+        if (r) return r;
+        snprintf(name, sizeof name, "%spf%09d.bas", dpath, m->iter);
+        if ((r = msom_write_bas(m, MSOM_TMP, name))) return r;
+      }
       if (p.nptr > 0) {  // msqg/qg.c:168-171
         snprintf(name, sizeof name, "%sptr%09d.bas", dpath, m->iter);
         if ((r = msom_write_bas(m, MSOM_PTR, name))) return r;
@@ -1513,7 +1702,7 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
     }
     if (!out_pending) break;  // no scheduled event left: run() ends
     if (nsteps_max >= 0 && steps >= nsteps_max) break;
-    m->tnext = tout;
+    m->tnext = filtering && tflt <= p.tend + 1e-10 ? fmin(tout, tflt) : tout;
     if ((r = msom_step(m, nullptr))) return r;
     steps++;
   }

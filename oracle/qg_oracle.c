@@ -27,7 +27,7 @@
 
 enum { BC_DIRICHLET0 = 0, BC_NEUMANN = 1, BC_PERIODIC = 2, BC_DIRICHLET_LIN = 3 };
 
-typedef struct {
+typedef struct fld_s {
   int nx, ny, nl, bc;
   double *d;
   /* BC_DIRICHLET_LIN: value vpg[l]*x - upg[l]*y imposed on the wall faces (msqg/qg.h:1105-1114) */
@@ -43,6 +43,9 @@ struct orc {
   int nx, ny, nl;
   double L0, Rom, Ekb, Eks, tau0, Re, Re4, iRe, iRe4, sbc, beta, DT, CFL, tend, dtout;
   int varRo, flsrv, flag_topo, nptr;
+  double afilt, Lfmax, dtflt;   /* wavelet filter, msqg/qg.h:53,83,85 */
+  int wnlev;                    /* wavelet pyramid: level 0 = finest ... wnlev-1 = 1 cell on the short side */
+  struct fld_s *ws, *ww, *wsig, *wsf; /* s, w, sig_lev, sig_filt on every level */
   double ptr_r[ORC_MAXNL], ptr_ir[ORC_MAXNL], Pe[ORC_MAXNL], iPe[ORC_MAXNL];
   double Frm[ORC_MAXNL], dhu[ORC_MAXNL], upg[ORC_MAXNL], vpg[ORC_MAXNL];
   double dhf[ORC_MAXNL], dhc[ORC_MAXNL], idh0[ORC_MAXNL], idh1[ORC_MAXNL];
@@ -194,7 +197,24 @@ static void parse_line(orc_t *o, char *buf, int *N, int *Ny) {
   else if (!strcmp(k, "vpg")) str2array(v, o->vpg);
   else if (!strcmp(k, "tr_stoch")) o->tr_stoch = atof(v);
   else if (!strcmp(k, "amp_stoch")) o->amp_stoch = atof(v);
+  else if (!strcmp(k, "afilt")) o->afilt = atof(v);
+  else if (!strcmp(k, "Lfmax")) o->Lfmax = atof(v);
+  else if (!strcmp(k, "dtflt")) o->dtflt = atof(v);
   else if (!strcmp(k, "MGLEVELS")) o->mglevels = atoi(v); /* extension: cap on MG levels */
+}
+
+/* wavelet pyramid: Basilisk levels depth() ... 0 (1 x 1 cell) */
+static void build_wavelet_levels(orc_t *o) {
+  int n = 1, nx = o->nx, ny = o->ny;
+  while ((nx >> n) >= 1 && (ny >> n) >= 1 && ((nx >> n) << n) == nx && ((ny >> n) << n) == ny) n++;
+  o->wnlev = n;
+  o->ws = (fld *)calloc(n, sizeof(fld)); o->ww = (fld *)calloc(n, sizeof(fld));
+  o->wsig = (fld *)calloc(n, sizeof(fld)); o->wsf = (fld *)calloc(n, sizeof(fld));
+  int bc = o->sbc == -1 ? BC_PERIODIC : BC_DIRICHLET0, bcn = o->sbc == -1 ? BC_PERIODIC : BC_NEUMANN;
+  for (int k = 0; k < n; k++) {
+    fld_alloc(&o->ws[k], nx >> k, ny >> k, o->nl, bc); fld_alloc(&o->ww[k], nx >> k, ny >> k, o->nl, bcn);
+    fld_alloc(&o->wsig[k], nx >> k, ny >> k, 1, bcn); fld_alloc(&o->wsf[k], nx >> k, ny >> k, 1, bcn);
+  }
 }
 
 static void build_levels(orc_t *o) {
@@ -222,7 +242,7 @@ orc_t *orc_create_str(const char *text) {
   int N = 64, Ny = 0;
   /* defaults msqg/qg.h:63-106 and Basilisk globals */
   o->nl = 1; o->L0 = 1.; o->beta = 0.5; o->DT = 1e10; o->CFL = 0.5; o->tend = 1; o->dtout = 1;
-  o->amp_stoch = 1;
+  o->amp_stoch = 1; o->afilt = 10.; o->Lfmax = 1e10; o->dtflt = -1;
   o->tolerance = 1e-3; o->nitermax = 100; o->nitermin = 1; o->smoother = ORC_GS_LEX;
   char *copy = strdup(text), *save = NULL;
   for (char *line = strtok_r(copy, "\n", &save); line; line = strtok_r(NULL, "\n", &save)) {
@@ -253,7 +273,8 @@ orc_t *orc_create_str(const char *text) {
     int layers = nl, b = bc;
     if (k == ORC_FR || k == ORC_S) { layers = nlm; b = bcn; }
     if (k == ORC_RO || k == ORC_TOPO) { layers = 1; b = bcn; }
-    if (k >= ORC_PTR) { layers = nl * (o->nptr > 0 ? o->nptr : 1); b = bcn; } /* qg.h:867-870 */
+    if (k >= ORC_PTR && k <= ORC_PTR_PRED) { layers = nl * (o->nptr > 0 ? o->nptr : 1); b = bcn; } /* qg.h:867-870 */
+    if (k == ORC_RD) { layers = 1; b = bcn; }
     fld_alloc(&o->f[k], o->nx, o->ny, layers, b);
   }
   if (o->sbc == -1) { /* msqg/qg.h:1105-1114: the large-scale stream function is not periodic */
@@ -273,8 +294,9 @@ orc_t *orc_create_str(const char *text) {
       }
   boundary(pp);
   for (int j = 0; j < o->ny; j++)
-    for (int i = 0; i < o->nx; i++) V(Ro, 0, i, j) = o->Rom;
+    for (int i = 0; i < o->nx; i++) { V(Ro, 0, i, j) = o->Rom; V(&o->f[ORC_RD], 0, i, j) = 1.; /* qg.h:913 */ }
   build_levels(o);
+  build_wavelet_levels(o);
   o->t = 0; o->iter = 0; o->dt = 1.; o->tnext_event = HUGE_VAL; o->previous = 0.;
   return o;
 }
@@ -283,6 +305,8 @@ void orc_destroy(orc_t *o) {
   if (!o) return;
   for (int k = 0; k < ORC_NFIELDS; k++) fld_free(&o->f[k]);
   for (int k = 0; k < o->nlev; k++) { fld_free(&o->da[k]); fld_free(&o->res[k]); fld_free(&o->S[k]); }
+  for (int k = 0; k < o->wnlev; k++) { fld_free(&o->ws[k]); fld_free(&o->ww[k]); fld_free(&o->wsig[k]); fld_free(&o->wsf[k]); }
+  free(o->ws); free(o->ww); free(o->wsig); free(o->wsf);
   free(o->da); free(o->res); free(o->S); free(o->delta);
   free(o);
 }
@@ -791,6 +815,91 @@ void orc_prolong_raw(orc_t *o, int lev_coarse, const double *coarse, double *fin
 /* ------------------------------------------------------------------ set_const */
 
 /* msqg/qg.h:931-1116 without the cwd file discovery (tests set fields through the API) */
+/* filter length scale and wavelet coefficients, msqg/qg.h:1059-1090 (MODE_PV_INVERT off) */
+static void build_siglev(orc_t *o) {
+  fld *Rd = &o->f[ORC_RD];
+  const int K = o->wnlev;
+  for (int j = 0; j < o->ny; j++)
+    for (int i = 0; i < o->nx; i++) V(&o->wsf[0], 0, i, j) = fmin(o->afilt * V(Rd, 0, i, j), o->Lfmax);
+  boundary(&o->wsf[0]);
+  for (int k = 1; k < K; k++) { restrict_fld(&o->wsf[k - 1], &o->wsf[k]); boundary(&o->wsf[k]); }   /* restriction({sig_filt}) */
+  for (int k = 0; k < K; k++) {  /* low pass: for (l = depth(); l >= 0; l--) */
+    fld *sl = &o->wsig[k], *sf = &o->wsf[k];
+    const double Delta = o->L0 / (double)(o->nx >> k);
+    for (int j = 0; j < sl->ny; j++)
+      for (int i = 0; i < sl->nx; i++) {
+        double ref_flag = 0;
+        if (k > 0) {  /* foreach_child(): x outer, y inner */
+          ref_flag += V(&o->wsig[k - 1], 0, 2 * i, 2 * j); ref_flag += V(&o->wsig[k - 1], 0, 2 * i, 2 * j + 1);
+          ref_flag += V(&o->wsig[k - 1], 0, 2 * i + 1, 2 * j); ref_flag += V(&o->wsig[k - 1], 0, 2 * i + 1, 2 * j + 1);
+        }
+        const double s = V(sf, 0, i, j);
+        if (ref_flag > 0) V(sl, 0, i, j) = 1;
+        else if (s > 2 * Delta) V(sl, 0, i, j) = 0;
+        else if (s <= 2 * Delta && s > Delta) V(sl, 0, i, j) = 1 - (s - Delta) / Delta;
+        else V(sl, 0, i, j) = 1;
+      }
+    boundary(sl);
+  }
+  for (int k = 0; k < K; k++) {  /* high pass */
+    fld *sl = &o->wsig[k];
+    for (int j = 0; j < sl->ny; j++) for (int i = 0; i < sl->nx; i++) V(sl, 0, i, j) = 1 - V(sl, 0, i, j);
+    boundary(sl);
+  }
+}
+
+/* [BASILISK RULE] wavelet() / inverse_wavelet() of grid/multigrid-common.h (not in the tree, restated
+ * from the published source): s restricted to all levels (mean of 4 children, BC on every level);
+ * detail w_k = s_k - bilinear(s_{k+1}) on levels finer than the root, w_root = s_root; inverse:
+ * s_root = w_root, s_k = bilinear(s_{k+1}) + w_k with boundary_level after each level.
+ * Here with the scaling by sig_lev in between (msqg/qg.h:532-538), all layers at once. */
+static void wavelet_apply(orc_t *o, fld *po) {
+  const int K = o->wnlev;
+  const size_t sz = (size_t)po->nl * (po->nx + 2) * (po->ny + 2) * sizeof(double);
+  memcpy(o->ws[0].d, po->d, sz);
+  boundary(&o->ws[0]);
+  for (int k = 1; k < K; k++) { restrict_fld(&o->ws[k - 1], &o->ws[k]); boundary(&o->ws[k]); }
+  for (int k = 0; k < K - 1; k++) {
+    fld *w = &o->ww[k], *s = &o->ws[k];
+    prolong_fld(&o->ws[k + 1], w);   /* sp */
+    for (int l = 0; l < w->nl; l++) for (int j = 0; j < w->ny; j++) for (int i = 0; i < w->nx; i++) {
+      double d = V(s, l, i, j); d -= V(w, l, i, j);      /* w[] = s[]; w[] -= sp */
+      V(w, l, i, j) = d * V(&o->wsig[k], 0, i, j);       /* w[] *= sig_lev[] */
+    }
+  }
+  { fld *w = &o->ww[K - 1], *s = &o->ws[K - 1];
+    for (int l = 0; l < w->nl; l++) for (int j = 0; j < w->ny; j++) for (int i = 0; i < w->nx; i++) V(w, l, i, j) = V(s, l, i, j) * V(&o->wsig[K - 1], 0, i, j); }
+  memcpy(o->ws[K - 1].d, o->ww[K - 1].d, (size_t)po->nl * (o->ws[K - 1].nx + 2) * (o->ws[K - 1].ny + 2) * sizeof(double));
+  boundary(&o->ws[K - 1]);
+  for (int k = K - 2; k >= 0; k--) {
+    fld *s = &o->ws[k], *w = &o->ww[k];
+    prolong_fld(&o->ws[k + 1], s);
+    for (int l = 0; l < s->nl; l++) for (int j = 0; j < s->ny; j++) for (int i = 0; i < s->nx; i++) V(s, l, i, j) += V(w, l, i, j);
+    boundary(s);
+  }
+  memcpy(po->d, o->ws[0].d, sz);
+}
+static orc_mgstats invertq(orc_t *o, fld *po, fld *qo);
+static void comp_q(orc_t *o, fld *po, fld *qo);
+/* wavelet_filter msqg/qg.h:509-560.  `nbar` is passed by value there, so the caller's counter
+ * never advances: qof = (tmp - q) / dtflt on every call. */
+void orc_wavelet_filter(orc_t *o, double dtflt) {
+  fld *q = &o->f[ORC_Q], *po = &o->f[ORC_PSI], *tmp = &o->f[ORC_TMP], *qof = &o->f[ORC_QOF];
+  const int nbar = 0;
+  const size_t sz = (size_t)q->nl * (q->nx + 2) * (q->ny + 2) * sizeof(double);
+  for (int l = 0; l < q->nl; l++) for (int j = 0; j < q->ny; j++) for (int i = 0; i < q->nx; i++) V(tmp, l, i, j) = V(q, l, i, j);
+  invertq(o, po, q);
+  wavelet_apply(o, po);
+  comp_q(o, po, q);
+  for (int l = 0; l < q->nl; l++) for (int j = 0; j < q->ny; j++) for (int i = 0; i < q->nx; i++)
+    V(qof, l, i, j) = (V(qof, l, i, j) * nbar + (V(tmp, l, i, j) - V(q, l, i, j)) / dtflt) / (nbar + 1);
+  if (dtflt < 0.0) { memcpy(q->d, tmp->d, sz); }   /* list_copy_deep(tmpl, qol) incl. ghosts */
+  boundary(qof);
+}
+int orc_wavelet_levels(orc_t *o) { return o->wnlev; }
+void orc_get_siglev(orc_t *o, int lev, double *a) { fld_to_array(&o->wsig[lev], a); }
+void orc_wavelet_apply(orc_t *o, int field) { wavelet_apply(o, &o->f[field]); }
+
 void orc_set_const(orc_t *o) {
   const int nl = o->nl;
   for (int l = 0; l < nl - 1; l++) o->dhc[l] = 0.5 * (o->dhf[l] + o->dhf[l + 1]);
@@ -818,6 +927,7 @@ void orc_set_const(orc_t *o) {
         V(S, l, i, j) = r * r;
       }
   boundary(Ro); boundary(Fr); boundary(S);
+  build_siglev(o);                                               /* :1059-1090 */
   comp_q(o, &o->f[ORC_PSI], &o->f[ORC_Q]);                       /* :1092 */
   if (o->flsrv == 1) comp_del2(o, &o->f[ORC_PSIPG], &o->f[ORC_ZETAPG], 0., 1.0); /* :1094-1097 */
   for (int k = 0; k < ORC_NFIELDS; k++) boundary(&o->f[k]);      /* :1103 */

@@ -29,7 +29,8 @@ enum {
   ORC_RO = 10 /* 1 layer */, ORC_TOPO = 11 /* 1 layer */, ORC_QPRED = 12,
   ORC_NOISE = 13, ORC_SIGMA = 14,
   /* passive tracers, nl*nptr layers, index l*nptr + nt (msqg/qg.h:100-101,574-588) */
-  ORC_PTR = 15, ORC_PTR_RELAX = 16, ORC_DPTR = 17, ORC_PTR_PRED = 18, ORC_NFIELDS = 19
+  ORC_PTR = 15, ORC_PTR_RELAX = 16, ORC_DPTR = 17, ORC_PTR_PRED = 18,
+  ORC_RD = 19 /* Rd, 1 layer (msqg/qg.h:47,913) */, ORC_QOF = 20 /* qofl: filter mean (qg.h:27) */, ORC_NFIELDS = 21
 };
 
 enum { ORC_GS_LEX = 0, ORC_GS_RB = 1 };
@@ -89,6 +90,12 @@ void   orc_set_tnext(orc_t *o, double tnext); /* time of next t-scheduled event 
 void orc_pystep_bfn(orc_t *o, const double *q_in, double *tend, double direction, int vartype);
 void orc_pyq2p(orc_t *o, double *psi_out, const double *q_in);
 void orc_pyp2q(orc_t *o, const double *psi_in, double *q_out);
+
+/* wavelet scale filter msqg/qg.h:509-560 (filter coefficients sig_lev: qg.h:1059-1090); dtflt < 0: q restored */
+void orc_wavelet_filter(orc_t *o, double dtflt);
+int  orc_wavelet_levels(orc_t *o);                       /* depth() + 1; level 0 = finest here */
+void orc_get_siglev(orc_t *o, int lev, double *a);       /* [ny>>lev][nx>>lev] */
+void orc_wavelet_apply(orc_t *o, int field);             /* field <- inverse_wavelet(sig_lev * wavelet(field)) */
 
 /* .bas IO  msqg/auxiliar_input.h:24-59,101-149 (square grids only) */
 int orc_write_bas(orc_t *o, int field, const char *path);

@@ -10,6 +10,7 @@ _ROOT = os.path.dirname(_HERE)
 _LIB = os.path.join(_ROOT, "oracle", "_build", "liborc.so")
 
 PSI, Q, ZETA, PSIPG, ZETAPG, QFORC, TMP, FR, S, DQ, RO, TOPO, QPRED, NOISE, SIGMA, PTR, PTR_RELAX, DPTR, PTR_PRED = range(19)
+RD, QOF = 19, 20
 GS_LEX, GS_RB = 0, 1
 
 
@@ -95,6 +96,10 @@ def lib():
         L.orc_write_bas.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
         L.orc_read_bas.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
         L.orc_num_threads.restype = C.c_int
+        L.orc_wavelet_filter.argtypes = [C.c_void_p, C.c_double]
+        L.orc_wavelet_levels.argtypes = [C.c_void_p]
+        L.orc_get_siglev.argtypes = [C.c_void_p, C.c_int, dp]
+        L.orc_wavelet_apply.argtypes = [C.c_void_p, C.c_int]
     return _lib
 
 
@@ -257,6 +262,20 @@ class Oracle:
         q = np.empty_like(p)
         self.L.orc_pyp2q(self.h, _p(p), _p(q))
         return q
+
+    def wavelet_filter(self, dtflt):
+        self.L.orc_wavelet_filter(self.h, dtflt)
+
+    def wavelet_levels(self):
+        return self.L.orc_wavelet_levels(self.h)
+
+    def siglev(self, lev):
+        a = np.empty((1, self.ny >> lev, self.nx >> lev))
+        self.L.orc_get_siglev(self.h, lev, _p(a))
+        return a
+
+    def wavelet_apply(self, field):
+        self.L.orc_wavelet_apply(self.h, field)
 
     def write_bas(self, field, path):
         return self.L.orc_write_bas(self.h, field, path.encode())
