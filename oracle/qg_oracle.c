@@ -42,7 +42,7 @@ struct orc {
   /* parameters, msqg/qg.h:63-106 */
   int nx, ny, nl;
   double L0, Rom, Ekb, Eks, tau0, Re, Re4, iRe, iRe4, sbc, beta, DT, CFL, tend, dtout;
-  int varRo, flsrv, flag_topo, nptr;
+  int varRo, flsrv, flag_topo, nptr, ediag, nme_ft;
   double afilt, Lfmax, dtflt;   /* wavelet filter, msqg/qg.h:53,83,85 */
   int wnlev;                    /* wavelet pyramid: level 0 = finest ... wnlev-1 = 1 cell on the short side */
   struct fld_s *ws, *ww, *wsig, *wsf; /* s, w, sig_lev, sig_filt on every level */
@@ -197,6 +197,7 @@ static void parse_line(orc_t *o, char *buf, int *N, int *Ny) {
   else if (!strcmp(k, "vpg")) str2array(v, o->vpg);
   else if (!strcmp(k, "tr_stoch")) o->tr_stoch = atof(v);
   else if (!strcmp(k, "amp_stoch")) o->amp_stoch = atof(v);
+  else if (!strcmp(k, "ediag")) o->ediag = atoi(v);
   else if (!strcmp(k, "afilt")) o->afilt = atof(v);
   else if (!strcmp(k, "Lfmax")) o->Lfmax = atof(v);
   else if (!strcmp(k, "dtflt")) o->dtflt = atof(v);
@@ -242,7 +243,7 @@ orc_t *orc_create_str(const char *text) {
   int N = 64, Ny = 0;
   /* defaults msqg/qg.h:63-106 and Basilisk globals */
   o->nl = 1; o->L0 = 1.; o->beta = 0.5; o->DT = 1e10; o->CFL = 0.5; o->tend = 1; o->dtout = 1;
-  o->amp_stoch = 1; o->afilt = 10.; o->Lfmax = 1e10; o->dtflt = -1;
+  o->amp_stoch = 1; o->afilt = 10.; o->Lfmax = 1e10; o->dtflt = -1; o->ediag = -1;
   o->tolerance = 1e-3; o->nitermax = 100; o->nitermin = 1; o->smoother = ORC_GS_LEX;
   char *copy = strdup(text), *save = NULL;
   for (char *line = strtok_r(copy, "\n", &save); line; line = strtok_r(NULL, "\n", &save)) {
@@ -883,8 +884,8 @@ static orc_mgstats invertq(orc_t *o, fld *po, fld *qo);
 static void comp_q(orc_t *o, fld *po, fld *qo);
 /* wavelet_filter msqg/qg.h:509-560.  `nbar` is passed by value there, so the caller's counter
  * never advances: qof = (tmp - q) / dtflt on every call. */
-void orc_wavelet_filter(orc_t *o, double dtflt) {
-  fld *q = &o->f[ORC_Q], *po = &o->f[ORC_PSI], *tmp = &o->f[ORC_TMP], *qof = &o->f[ORC_QOF];
+static void wavelet_filter(orc_t *o, fld *qof, double dtflt) {
+  fld *q = &o->f[ORC_Q], *po = &o->f[ORC_PSI], *tmp = &o->f[ORC_TMP];
   const int nbar = 0;
   const size_t sz = (size_t)q->nl * (q->nx + 2) * (q->ny + 2) * sizeof(double);
   for (int l = 0; l < q->nl; l++) for (int j = 0; j < q->ny; j++) for (int i = 0; i < q->nx; i++) V(tmp, l, i, j) = V(q, l, i, j);
@@ -896,6 +897,7 @@ void orc_wavelet_filter(orc_t *o, double dtflt) {
   if (dtflt < 0.0) { memcpy(q->d, tmp->d, sz); }   /* list_copy_deep(tmpl, qol) incl. ghosts */
   boundary(qof);
 }
+void orc_wavelet_filter(orc_t *o, double dtflt) { wavelet_filter(o, &o->f[ORC_QOF], dtflt); }
 int orc_wavelet_levels(orc_t *o) { return o->wnlev; }
 void orc_get_siglev(orc_t *o, int lev, double *a) { fld_to_array(&o->wsig[lev], a); }
 void orc_wavelet_apply(orc_t *o, int field) { wavelet_apply(o, &o->f[field]); }
@@ -931,6 +933,116 @@ void orc_set_const(orc_t *o) {
   comp_q(o, &o->f[ORC_PSI], &o->f[ORC_Q]);                       /* :1092 */
   if (o->flsrv == 1) comp_del2(o, &o->f[ORC_PSIPG], &o->f[ORC_ZETAPG], 0., 1.0); /* :1094-1097 */
   for (int k = 0; k < ORC_NFIELDS; k++) boundary(&o->f[k]);      /* :1103 */
+}
+
+/* ------------------------------------------------------------------ energy diagnostics, msqg/qg_energy.h */
+#define EW(po, l, i, j) (-V(po, l, i, j) * (1 - ediag) + ediag)
+static void comp_del2(orc_t *o, fld *po, fld *zeta, double add, double fac);
+static void comp_stretch(orc_t *o, fld *po, fld *st, double add, double fac);
+/* advection_de :28-158 (called with qol = zetal); ENERGY_CONSERV off; the _LS_RV term uses zeta_pg, which
+ * is identically 0 unless flsrv = 1 */
+static void advection_de(orc_t *o, fld *qo, fld *po, fld *j1, fld *j2, fld *j3, double dt, double ediag) {
+  const int nl = o->nl;
+  const double D = o->L0 / o->nx;
+  fld *pp = &o->f[ORC_PSIPG], *qp = &o->f[ORC_ZETAPG], *S = &o->f[ORC_S];
+  const double *idh0 = o->idh0, *idh1 = o->idh1;
+#pragma omp parallel for
+  for (int j = 0; j < po->ny; j++)
+    for (int i = 0; i < po->nx; i++) {
+      if (nl > 1) {
+        double ju_1, jd_1, ju_2, jd_2, ju_3, jd_3, jc;
+        int l = 0;
+        jd_1 = jacobian(po, l, po, l + 1, i, j, D);
+        jd_2 = jacobian(pp, l, po, l + 1, i, j, D);
+        jd_3 = jacobian(po, l, pp, l + 1, i, j, D);
+        jc = jacobian(po, l, pp, l, i, j, D);
+        V(j1, l, i, j) += (jacobian(po, l, qo, l, i, j, D) + V(S, l, i, j) * jd_1 * idh1[l]) * dt * EW(po, l, i, j);
+        V(j2, l, i, j) += (jacobian(pp, l, qo, l, i, j, D) + V(S, l, i, j) * (jd_2 + jc) * idh1[l]) * dt * EW(po, l, i, j);
+        V(j3, l, i, j) += (BETA_EFFECT(po, l, i, j) + V(S, l, i, j) * (jd_3 - jc) * idh1[l]) * dt * EW(po, l, i, j);
+        V(j3, l, i, j) += jacobian(po, l, qp, l, i, j, D) * dt * EW(po, l, i, j);
+        for (l = 1; l < nl - 1; l++) {
+          ju_1 = -jd_1; ju_2 = -jd_3; ju_3 = -jd_2; /* swap, :96-98 */
+          jd_1 = jacobian(po, l, po, l + 1, i, j, D);
+          jd_2 = jacobian(pp, l, po, l + 1, i, j, D);
+          jd_3 = jacobian(po, l, pp, l + 1, i, j, D);
+          jc = jacobian(po, l, pp, l, i, j, D);
+          V(j1, l, i, j) += (jacobian(po, l, qo, l, i, j, D) + V(S, l - 1, i, j) * ju_1 * idh0[l] + V(S, l, i, j) * jd_1 * idh1[l]) * dt * EW(po, l, i, j);
+          V(j2, l, i, j) += (jacobian(pp, l, qo, l, i, j, D) + V(S, l - 1, i, j) * (ju_2 + jc) * idh0[l] + V(S, l, i, j) * (jd_2 + jc) * idh1[l]) * dt * EW(po, l, i, j);
+          V(j3, l, i, j) += (BETA_EFFECT(po, l, i, j) + V(S, l - 1, i, j) * (ju_3 - jc) * idh0[l] + V(S, l, i, j) * (jd_3 - jc) * idh1[l]) * dt * EW(po, l, i, j);
+          V(j3, l, i, j) += jacobian(po, l, qp, l, i, j, D) * dt * EW(po, l, i, j);
+        }
+        l = nl - 1;
+        ju_1 = -jd_1; ju_2 = -jd_3; ju_3 = -jd_2;
+        jc = jacobian(po, l, pp, l, i, j, D);
+        V(j1, l, i, j) += (jacobian(po, l, qo, l, i, j, D) + V(S, l - 1, i, j) * ju_1 * idh0[l]) * dt * EW(po, l, i, j);
+        V(j2, l, i, j) += (jacobian(pp, l, qo, l, i, j, D) + V(S, l - 1, i, j) * (ju_2 + jc) * idh0[l]) * dt * EW(po, l, i, j);
+        V(j3, l, i, j) += (BETA_EFFECT(po, l, i, j) + V(S, l - 1, i, j) * (ju_3 - jc) * idh0[l]) * dt * EW(po, l, i, j);
+        V(j3, l, i, j) += jacobian(po, l, qp, l, i, j, D) * dt * EW(po, l, i, j);
+      } else { V(j1, 0, i, j) = 0; V(j2, 0, i, j) = 0; V(j3, 0, i, j) = 0; }
+    }
+}
+/* dissip_de :161-191 */
+static void dissip_de(orc_t *o, fld *zeta, fld *dqo, fld *po, double dt, double ediag) {
+  fld *tmp = &o->f[ORC_TMP], *tmp2 = &o->f[ORC_TMP2];
+  const double D = o->L0 / o->nx, D2 = D * D;
+  comp_del2(o, zeta, tmp, 0., 1.);
+  comp_stretch(o, zeta, tmp2, 0., 1.);
+  for (int l = 0; l < o->nl; l++) for (int j = 0; j < po->ny; j++) for (int i = 0; i < po->nx; i++) {
+    V(dqo, l, i, j) += (V(tmp, l, i, j) + V(tmp2, l, i, j)) * o->iRe * dt * EW(po, l, i, j);
+    V(dqo, l, i, j) += o->iRe4 * LAP(tmp, l, i, j, D2) * dt * EW(po, l, i, j);
+  }
+  comp_stretch(o, tmp, tmp2, 0., 1.);
+  for (int l = 0; l < o->nl; l++) for (int j = 0; j < po->ny; j++) for (int i = 0; i < po->nx; i++)
+    V(dqo, l, i, j) += o->iRe4 * (V(tmp2, l, i, j)) * dt * EW(po, l, i, j);
+}
+/* ekman_friction_de :193-206 */
+static void ekman_friction_de(orc_t *o, fld *zeta, fld *dqo, fld *po, double dt, double ediag) {
+  const int b = o->nl - 1;
+  for (int j = 0; j < po->ny; j++) for (int i = 0; i < po->nx; i++) {
+    V(dqo, 0, i, j) -= o->Eks / (o->Rom * 2 * o->dhf[0]) * V(zeta, 0, i, j) * dt * EW(po, 0, i, j);
+    V(dqo, b, i, j) -= o->Ekb / (o->Rom * 2 * o->dhf[b]) * V(zeta, b, i, j) * dt * EW(po, b, i, j);
+  }
+}
+/* filter_de :208-225 */
+static void filter_de(orc_t *o, fld *pm, double dtflt, double ediag) {
+  fld *tmp2 = &o->f[ORC_TMP2], *ft = &o->f[ORC_DE_FT];
+  wavelet_filter(o, tmp2, -dtflt);
+  for (int l = 0; l < o->nl; l++) for (int j = 0; j < ft->ny; j++) for (int i = 0; i < ft->nx; i++) {
+    V(ft, l, i, j) += V(tmp2, l, i, j) * dtflt * (-V(pm, l, i, j) * (1 - ediag) + ediag);
+    V(pm, l, i, j) = 0;
+  }
+  o->nme_ft = 0;
+}
+void orc_filter_de(orc_t *o, int pm_field, double dtflt) { filter_de(o, &o->f[pm_field], dtflt, (double)o->ediag); }
+/* energy_tend :227-241 */
+void orc_energy_tend(orc_t *o, double dt) {
+  fld *po = &o->f[ORC_PSI], *zeta = &o->f[ORC_ZETA], *pm = &o->f[ORC_PO_MFT];
+  const double ediag = (double)o->ediag;
+  comp_del2(o, po, zeta, 0., 1.0);
+  advection_de(o, zeta, po, &o->f[ORC_DE_J1], &o->f[ORC_DE_J2], &o->f[ORC_DE_J3], dt, ediag);
+  dissip_de(o, zeta, &o->f[ORC_DE_VD], po, dt, ediag);
+  ekman_friction_de(o, zeta, &o->f[ORC_DE_BF], po, dt, ediag);
+  for (int l = 0; l < o->nl; l++) for (int j = 0; j < po->ny; j++) for (int i = 0; i < po->nx; i++)
+    V(pm, l, i, j) = (V(pm, l, i, j) * o->nme_ft + V(po, l, i, j)) / (o->nme_ft + 1);
+  o->nme_ft += 1;
+}
+void orc_reset_de(orc_t *o) { for (int k = ORC_DE_BF; k <= ORC_DE_FT; k++) fld_zero(&o->f[k]); }
+/* pystep_de :296-349: ediag = 1 and dt = 1 are locals there; filter_de runs with po_mft = pol (so pol is zeroed)
+ * and the global dtflt */
+void orc_pystep_de(orc_t *o, const double *po_in, double *bf, double *vd, double *j1, double *j2, double *j3, double *ft, int onlyKE) {
+  fld *po = &o->f[ORC_PSI], *zeta = &o->f[ORC_ZETA];
+  const double ediag = 1., dt = 1.;
+  fld_from_array(po, po_in);
+  orc_reset_de(o);
+  comp_del2(o, po, zeta, 0., 1.0);
+  comp_q(o, po, &o->f[ORC_Q]);
+  if (onlyKE == 1) { fld *S = &o->f[ORC_S]; for (int l = 0; l < o->nl - 1; l++) for (int j = 0; j < S->ny; j++) for (int i = 0; i < S->nx; i++) V(S, l, i, j) = 0.; }
+  advection_de(o, zeta, po, &o->f[ORC_DE_J1], &o->f[ORC_DE_J2], &o->f[ORC_DE_J3], dt, ediag);
+  dissip_de(o, zeta, &o->f[ORC_DE_VD], po, dt, ediag);
+  ekman_friction_de(o, zeta, &o->f[ORC_DE_BF], po, dt, ediag);
+  filter_de(o, po, o->dtflt, ediag);
+  fld_to_array(&o->f[ORC_DE_BF], bf); fld_to_array(&o->f[ORC_DE_VD], vd); fld_to_array(&o->f[ORC_DE_J1], j1);
+  fld_to_array(&o->f[ORC_DE_J2], j2); fld_to_array(&o->f[ORC_DE_J3], j3); fld_to_array(&o->f[ORC_DE_FT], ft);
 }
 
 /* ------------------------------------------------------------------ time stepping */

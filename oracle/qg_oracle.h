@@ -30,7 +30,10 @@ enum {
   ORC_NOISE = 13, ORC_SIGMA = 14,
   /* passive tracers, nl*nptr layers, index l*nptr + nt (msqg/qg.h:100-101,574-588) */
   ORC_PTR = 15, ORC_PTR_RELAX = 16, ORC_DPTR = 17, ORC_PTR_PRED = 18,
-  ORC_RD = 19 /* Rd, 1 layer (msqg/qg.h:47,913) */, ORC_QOF = 20 /* qofl: filter mean (qg.h:27) */, ORC_NFIELDS = 21
+  ORC_RD = 19 /* Rd, 1 layer (msqg/qg.h:47,913) */, ORC_QOF = 20 /* qofl: filter mean (qg.h:27) */,
+  /* energy diagnostics msqg/qg_energy.h:7-15, nl layers each */
+  ORC_DE_BF = 21, ORC_DE_VD = 22, ORC_DE_J1 = 23, ORC_DE_J2 = 24, ORC_DE_J3 = 25, ORC_DE_FT = 26, ORC_TMP2 = 27, ORC_PO_MFT = 28,
+  ORC_NFIELDS = 29
 };
 
 enum { ORC_GS_LEX = 0, ORC_GS_RB = 1 };
@@ -96,6 +99,12 @@ void orc_wavelet_filter(orc_t *o, double dtflt);
 int  orc_wavelet_levels(orc_t *o);                       /* depth() + 1; level 0 = finest here */
 void orc_get_siglev(orc_t *o, int lev, double *a);       /* [ny>>lev][nx>>lev] */
 void orc_wavelet_apply(orc_t *o, int field);             /* field <- inverse_wavelet(sig_lev * wavelet(field)) */
+
+/* energy / PV budgets msqg/qg_energy.h (ediag: 0 = terms x (-psi), 1 = PV terms) */
+void orc_energy_tend(orc_t *o, double dt);               /* :227-241, event comp_diag :289-291 */
+void orc_filter_de(orc_t *o, int pm_field, double dtflt);/* :208-225 */
+void orc_reset_de(orc_t *o);                             /* reset_layer_var of the six budgets, qg.c:153-159 */
+void orc_pystep_de(orc_t *o, const double *po, double *bf, double *vd, double *j1, double *j2, double *j3, double *ft, int onlyKE); /* :296-349 */
 
 /* .bas IO  msqg/auxiliar_input.h:24-59,101-149 (square grids only) */
 int orc_write_bas(orc_t *o, int field, const char *path);

@@ -11,6 +11,7 @@ _LIB = os.path.join(_ROOT, "oracle", "_build", "liborc.so")
 
 PSI, Q, ZETA, PSIPG, ZETAPG, QFORC, TMP, FR, S, DQ, RO, TOPO, QPRED, NOISE, SIGMA, PTR, PTR_RELAX, DPTR, PTR_PRED = range(19)
 RD, QOF = 19, 20
+DE_BF, DE_VD, DE_J1, DE_J2, DE_J3, DE_FT, TMP2, PO_MFT = range(21, 29)
 GS_LEX, GS_RB = 0, 1
 
 
@@ -97,6 +98,10 @@ def lib():
         L.orc_read_bas.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
         L.orc_num_threads.restype = C.c_int
         L.orc_wavelet_filter.argtypes = [C.c_void_p, C.c_double]
+        L.orc_energy_tend.argtypes = [C.c_void_p, C.c_double]
+        L.orc_filter_de.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        L.orc_reset_de.argtypes = [C.c_void_p]
+        L.orc_pystep_de.argtypes = [C.c_void_p] + [dp] * 7 + [C.c_int]
         L.orc_wavelet_levels.argtypes = [C.c_void_p]
         L.orc_get_siglev.argtypes = [C.c_void_p, C.c_int, dp]
         L.orc_wavelet_apply.argtypes = [C.c_void_p, C.c_int]
@@ -268,6 +273,21 @@ class Oracle:
 
     def wavelet_levels(self):
         return self.L.orc_wavelet_levels(self.h)
+
+    def energy_tend(self, dt):
+        self.L.orc_energy_tend(self.h, dt)
+
+    def filter_de(self, pm_field, dtflt):
+        self.L.orc_filter_de(self.h, pm_field, dtflt)
+
+    def reset_de(self):
+        self.L.orc_reset_de(self.h)
+
+    def pystep_de(self, po, onlyKE=0):
+        po = np.ascontiguousarray(po, dtype=np.float64)
+        outs = [np.empty_like(po) for _ in range(6)]
+        self.L.orc_pystep_de(self.h, _p(po), *[_p(a) for a in outs], onlyKE)
+        return outs
 
     def siglev(self, lev):
         a = np.empty((1, self.ny >> lev, self.nx >> lev))
