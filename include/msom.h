@@ -56,7 +56,10 @@ enum {
   MSOM_PTR_PRED = 18,  /* tracer part of the predictor       */
   MSOM_RD = 19,        /* Rd, deformation radius of the filter scale, 1 layer (msqg/qg.h:47,913,963-968) */
   MSOM_QOF = 20,       /* qofl, filter mean (msqg/qg.h:27,549); allocated on first use           */
-  MSOM_NFIELDS = 21
+  /* energy / PV budgets (msqg/qg_energy.h:7-15), nl layers each, allocated on first use */
+  MSOM_DE_BF = 21, MSOM_DE_VD = 22, MSOM_DE_J1 = 23, MSOM_DE_J2 = 24, MSOM_DE_J3 = 25, MSOM_DE_FT = 26,
+  MSOM_TMP2 = 27, MSOM_PO_MFT = 28,
+  MSOM_NFIELDS = 29
 };
 
 /* mgstats of Basilisk (text: mspg/elliptic.h:118-123), kept by the reference in `mgpsi`
@@ -156,6 +159,20 @@ int msom_read_nc(msom_t *m, int field, const char *path, const char *varname, in
  * sets qof = (q_before - q_after) / dtflt; dtflt < 0 (energy diagnostics, qg_energy.h:213) restores q.
  * Single tile only. */
 int msom_wavelet_filter(msom_t *m, double dtflt);
+/* ---- energy / PV budgets, msqg/qg_energy.h (params key ediag: -1 off, 0: terms x (-psi), 1: PV terms).
+ * msom_energy_tend = energy_tend (:227-241, event comp_diag :289-291): accumulates de_j1/j2/j3, de_vd,
+ * de_bf from the current psi with weight dt and updates the running mean po_mft; msom_filter_de =
+ * filter_de (:208-225) with po_mft = field `pm_field`; msom_reset_de zeroes the six budgets
+ * (msqg/qg.c:153-159); pystep_de = the Python entry point (:296-349, msqg/qg_energy.i:31), same
+ * argument order (+ handle).  msom_run drives the events and writes de_*%09d.bas (qg.c:131-160). */
+int msom_energy_tend(msom_t *m, double dt);
+int msom_filter_de(msom_t *m, int pm_field, double dtflt);
+int msom_reset_de(msom_t *m);
+int pystep_de(msom_t *m, const double *po_py, int len1, int len2, int len3, double *de_bf_py, int len4, int len5, int len6,
+              double *de_vd_py, int len7, int len8, int len9, double *de_j1_py, int len10, int len11, int len12,
+              double *de_j2_py, int len13, int len14, int len15, double *de_j3_py, int len16, int len17, int len18,
+              double *de_ft_py, int len19, int len20, int len21, int onlyKE);
+
 /* pieces for the parity tests: number of pyramid levels (level 0 = finest ... 1 x 1 cell), sig_lev of
  * one level [ny>>level][nx>>level], and the bare transform-scale-inverse applied to a field */
 int msom_dbg_wavelet_levels(msom_t *m);

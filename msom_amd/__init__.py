@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     pyp2q,
     pyq2p,
     pystep_bfn,
+    pystep_de,
     read_params,
     set_const,
     set_vars,
@@ -28,5 +29,5 @@ from .api import (  # noqa: F401
 
 __all__ = [
     "QG", "NodeQG", "NODE_FIELDS", "MGStats", "MsomError", "FIELDS", "load_library", "read_params", "init_grid", "set_vars",
-    "set_vars_bfn", "set_const", "pystep_bfn", "pyq2p", "pyp2q", "trash_vars", "trash_vars_bfn",
+    "set_vars_bfn", "set_const", "pystep_bfn", "pystep_de", "pyq2p", "pyp2q", "trash_vars", "trash_vars_bfn",
 ]

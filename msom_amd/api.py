@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBDIR = os.path.join(_HERE, "lib")
 
 FIELDS = dict(PSI=0, Q=1, ZETA=2, PSIPG=3, ZETAPG=4, QFORC=5, TMP=6, FR=7, S=8, DQ=9, RO=10, TOPO=11,
-              QPRED=12, NOISE=13, SIGMA=14, PTR=15, PTR_RELAX=16, DPTR=17, PTR_PRED=18, RD=19, QOF=20)
+              QPRED=12, NOISE=13, SIGMA=14, PTR=15, PTR_RELAX=16, DPTR=17, PTR_PRED=18, RD=19, QOF=20,
+              DE_BF=21, DE_VD=22, DE_J1=23, DE_J2=24, DE_J3=25, DE_FT=26, TMP2=27, PO_MFT=28)
 
 
 class MsomError(RuntimeError):
@@ -88,6 +89,10 @@ def load_library(strict=False):
         "msom_bench_kernel": (ci, [vp, cs, ci, _dp]),
         "msom_dbg_rccl_selftest": (ci, []),
         "msom_wavelet_filter": (ci, [vp, cd]),
+        "msom_energy_tend": (ci, [vp, cd]),
+        "msom_filter_de": (ci, [vp, ci, cd]),
+        "msom_reset_de": (ci, [vp]),
+        "pystep_de": (ci, [vp] + [vp, ci, ci, ci] * 7 + [ci]),
         "msom_dbg_wavelet_levels": (ci, [vp]),
         "msom_dbg_siglev": (ci, [vp, ci, vp]),
         "msom_dbg_wavelet_apply": (ci, [vp, ci]),
@@ -291,6 +296,24 @@ class QG:
     def wavelet_filter(self, dtflt):
         self._chk(self.L.msom_wavelet_filter(self.h, dtflt))
 
+    # energy / PV budgets (msqg/qg_energy.h)
+    def energy_tend(self, dt):
+        self._chk(self.L.msom_energy_tend(self.h, dt))
+
+    def filter_de(self, pm_field, dtflt):
+        self._chk(self.L.msom_filter_de(self.h, pm_field, dtflt))
+
+    def reset_de(self):
+        self._chk(self.L.msom_reset_de(self.h))
+
+    def pystep_de(self, po, bf, vd, j1, j2, j3, ft, onlyKE=0):
+        """bas.pystep_de(p, bf, vd, j1, j2, j3, ft, flag_keonly) of msqg/scripts/energy_offline.py:113"""
+        arrs = [_f64(po, (self.nl, self.ny, self.nx))] + [a for a in (bf, vd, j1, j2, j3, ft)]
+        args = []
+        for a in arrs:
+            args += [_ptr(a), self.nl, self.ny, self.nx]
+        self._chk(self.L.pystep_de(self.h, *args, int(onlyKE)))
+
     def wavelet_levels(self):
         n = self.L.msom_dbg_wavelet_levels(self.h)
         if n < 0:
@@ -413,6 +436,11 @@ def pyq2p(p, q):
 
 def pyp2q(p, q):
     _state["model"].pyp2q(p, q)
+
+
+def pystep_de(p, bf, vd, j1, j2, j3, ft, onlyKE=0):
+    """msqg/qg_energy.i:31, called as bas.pystep_de(p,bf,vd,j1,j2,j3,ft,flag_keonly) (msqg/scripts/energy_offline.py:113)"""
+    _state["model"].pystep_de(p, bf, vd, j1, j2, j3, ft, onlyKE)
 
 
 def trash_vars():

@@ -55,6 +55,16 @@ void launch_noise(hipStream_t st, double *n, const double *sigma, const NatGeom 
 void launch_ptr_rhs(hipStream_t st, const double *psi, const double *c, const double *rel, double *dp, const NatGeom &g, int nl, int np,
                     const double *iPe, const double *ptr_ir, double D);
 
+// energy / PV budgets (msqg/qg_energy.h)
+void launch_advection_de(hipStream_t st, const double *zeta, const double *psi, const double *psipg, const double *zetapg, const double *S, double *j1,
+                         double *j2, double *j3, const NatGeom &g, int nl, double D, double beta, double dt, double ediag, const LayerCoef &lc);
+void launch_dissip_de(hipStream_t st, const double *p4, const double *str, const double *po, double *dq, const NatGeom &g, int nl, double iRe,
+                      double iRe4, double dt, double ediag, double D, int stage);
+void launch_ekman_de(hipStream_t st, const double *zeta, const double *po, double *dq, const NatGeom &g, int nl, double cs, double cb, double dt,
+                     double ediag);
+void launch_running_mean(hipStream_t st, double *pm, const double *po, const NatGeom &g, int nl, int n);
+void launch_filter_de(hipStream_t st, double *ft, const double *tmp2, double *pm, const NatGeom &g, int nl, double dtflt, double ediag);
+
 // ---- kernels_fused.hip
 int rhs_fused_blocks(const NatGeom &g);
 void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq,

@@ -596,3 +596,116 @@ void launch_ptr_rhs(hipStream_t st, const double *psi, const double *c, const do
   for (int k = 0; k < MSOM_MAXNL; k++) { pc.iPe[k] = k < np ? iPe[k] : 0.; pc.ptr_ir[k] = k < np ? ptr_ir[k] : 0.; }
   hipLaunchKernelGGL(k_ptr_rhs, grid2d(g.nx, g.ny), block2d(), 0, st, psi, c, rel, dp, g, nl, np, pc, D);
 }
+
+// ------------------------------------------------------------------ energy / PV budgets, msqg/qg_energy.h
+// Every term of the PV equation times dt * w, w = -psi (1 - ediag) + ediag, accumulated into
+// de_j1 / de_j2 / de_j3 (advection_de :28-158), de_vd (dissip_de :161-191), de_bf
+// (ekman_friction_de :193-206).  Diagnostics: straightforward one-thread-per-column kernels.
+#define EWGT(po, c) (-(po)[c] * (1 - ediag) + ediag)
+struct AdvDeArgs {
+  const double *zeta, *psi, *psipg, *zetapg, *S;
+  double *j1, *j2, *j3;
+  NatGeom g;
+  int nl;
+  double D, beta, dt, ediag;
+  LayerCoef lc;
+};
+__global__ void k_advection_de(AdvDeArgs a) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= a.g.nx || j >= a.g.ny) return;
+  const int pitch = a.g.pitch, nl = a.nl;
+  const size_t ls = a.g.ls;
+  const double D12 = 12. * a.D * a.D, rD12 = 1. / D12, D2x = 2 * a.D, rD2x = 1. / D2x, dt = a.dt, ediag = a.ediag;
+  size_t c = nat_idx(a.g, 0, j, i);
+  const double *po = a.psi, *qo = a.zeta, *pp = a.psipg, *qp = a.zetapg;
+  if (nl == 1) { a.j1[c] = 0; a.j2[c] = 0; a.j3[c] = 0; return; }  // :150-157
+  double ju_1, jd_1 = 0., ju_2, jd_2 = 0., ju_3, jd_3 = 0.;
+  for (int l = 0; l < nl; l++, c += ls) {
+    ju_1 = -jd_1; ju_2 = -jd_3; ju_3 = -jd_2;  // swap, :96-98
+    if (l < nl - 1) {
+      jd_1 = mjac(po, po + ls, c, pitch, D12, rD12);
+      jd_2 = mjac(pp, po + ls, c, pitch, D12, rD12);
+      jd_3 = mjac(po, pp + ls, c, pitch, D12, rD12);
+    }
+    const double jc = mjac(po, pp, c, pitch, D12, rD12), w = EWGT(po, c);
+    const double be = DIVC(a.beta * (po[c - 1] - po[c + 1]), D2x, rD2x);
+    double t1 = mjac(po, qo, c, pitch, D12, rD12), t2 = mjac(pp, qo, c, pitch, D12, rD12), t3 = be;
+    if (l > 0) {
+      const double s0 = a.S[c - ls], i0 = a.lc.idh0[l];
+      t1 = t1 + s0 * ju_1 * i0; t2 = t2 + s0 * (ju_2 + jc) * i0; t3 = t3 + s0 * (ju_3 - jc) * i0;
+    }
+    if (l < nl - 1) {
+      const double s1 = a.S[c], i1 = a.lc.idh1[l];
+      t1 = t1 + s1 * jd_1 * i1; t2 = t2 + s1 * (jd_2 + jc) * i1; t3 = t3 + s1 * (jd_3 - jc) * i1;
+    }
+    a.j1[c] += t1 * dt * w;
+    a.j2[c] += t2 * dt * w;
+    double v3 = a.j3[c];
+    v3 += t3 * dt * w;
+    v3 += mjac(po, qp, c, pitch, D12, rD12) * dt * w;
+    a.j3[c] = v3;
+  }
+}
+void launch_advection_de(hipStream_t st, const double *zeta, const double *psi, const double *psipg, const double *zetapg, const double *S, double *j1,
+                         double *j2, double *j3, const NatGeom &g, int nl, double D, double beta, double dt, double ediag, const LayerCoef &lc) {
+  AdvDeArgs a;
+  a.zeta = zeta; a.psi = psi; a.psipg = psipg; a.zetapg = zetapg; a.S = S; a.j1 = j1; a.j2 = j2; a.j3 = j3; a.g = g; a.nl = nl; a.D = D; a.beta = beta;
+  a.dt = dt; a.ediag = ediag; a.lc = lc;
+  hipLaunchKernelGGL(k_advection_de, grid2d(g.nx, g.ny), block2d(), 0, st, a);
+}
+// stage 0: dq += (p4 + str) iRe dt w; dq += iRe4 lap(p4) dt w   stage 1: dq += iRe4 str dt w
+__global__ void k_dissip_de(const double *__restrict__ p4, const double *__restrict__ str, const double *__restrict__ po, double *dq, NatGeom g, int nl,
+                            double iRe, double iRe4, double dt, double ediag, double D2, double rD2, int stage) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  size_t c = nat_idx(g, 0, j, i);
+  for (int l = 0; l < nl; l++, c += g.ls) {
+    const double w = EWGT(po, c);
+    double d = dq[c];
+    if (stage == 0) {
+      d += (p4[c] + str[c]) * iRe * dt * w;
+      d += iRe4 * DIVC(LAPV(p4, c, g.pitch), D2, rD2) * dt * w;
+    } else
+      d += iRe4 * (str[c]) * dt * w;
+    dq[c] = d;
+  }
+}
+void launch_dissip_de(hipStream_t st, const double *p4, const double *str, const double *po, double *dq, const NatGeom &g, int nl, double iRe,
+                      double iRe4, double dt, double ediag, double D, int stage) {
+  hipLaunchKernelGGL(k_dissip_de, grid2d(g.nx, g.ny), block2d(), 0, st, p4, str, po, dq, g, nl, iRe, iRe4, dt, ediag, D * D, 1. / (D * D), stage);
+}
+__global__ void k_ekman_de(const double *__restrict__ zeta, const double *__restrict__ po, double *dq, NatGeom g, int nl, double cs, double cb, double dt,
+                           double ediag) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  const size_t c0 = nat_idx(g, 0, j, i), cbt = c0 + (size_t)(nl - 1) * g.ls;
+  dq[c0] -= cs * zeta[c0] * dt * EWGT(po, c0);
+  dq[cbt] -= cb * zeta[cbt] * dt * EWGT(po, cbt);
+}
+void launch_ekman_de(hipStream_t st, const double *zeta, const double *po, double *dq, const NatGeom &g, int nl, double cs, double cb, double dt,
+                     double ediag) {
+  hipLaunchKernelGGL(k_ekman_de, grid2d(g.nx, g.ny), block2d(), 0, st, zeta, po, dq, g, nl, cs, cb, dt, ediag);
+}
+// pm = (pm * n + po) / (n + 1)   energy_tend :234-239
+__global__ void k_running_mean(double *pm, const double *__restrict__ po, NatGeom g, int nl, int n) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  size_t c = nat_idx(g, 0, j, i);
+  for (int l = 0; l < nl; l++, c += g.ls) pm[c] = (pm[c] * n + po[c]) / (n + 1);
+}
+void launch_running_mean(hipStream_t st, double *pm, const double *po, const NatGeom &g, int nl, int n) {
+  hipLaunchKernelGGL(k_running_mean, grid2d(g.nx, g.ny), block2d(), 0, st, pm, po, g, nl, n);
+}
+// de_ft += tmp2 dtflt (-pm (1 - ediag) + ediag); pm = 0   filter_de :214-223
+__global__ void k_filter_de(double *ft, const double *__restrict__ tmp2, double *pm, NatGeom g, int nl, double dtflt, double ediag) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  size_t c = nat_idx(g, 0, j, i);
+  for (int l = 0; l < nl; l++, c += g.ls) {
+    ft[c] += tmp2[c] * dtflt * (-pm[c] * (1 - ediag) + ediag);
+    pm[c] = 0;
+  }
+}
+void launch_filter_de(hipStream_t st, double *ft, const double *tmp2, double *pm, const NatGeom &g, int nl, double dtflt, double ediag) {
+  hipLaunchKernelGGL(k_filter_de, grid2d(g.nx, g.ny), block2d(), 0, st, ft, tmp2, pm, g, nl, dtflt, ediag);
+}

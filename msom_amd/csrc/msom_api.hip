@@ -98,6 +98,8 @@ struct msom {
   int quiet = 0;
   // wavelet scale filter (msqg/qg.h:509-560): pyramids s (restricted psi), r (filtered), sig_lev
   int wv_nlev = 0, wv_ready = 0;
+  int nme_ft = 0;  // msqg/qg_energy.h:17
+  int s_zero = 0;  // pystep_de(onlyKE = 1) zeroed the stretching field S (msqg/qg_energy.h:319-325); undone by msom_set_const
   std::vector<NatGeom> wv_g;
   std::vector<double *> wv_s, wv_r, wv_sig;
   // time loop
@@ -290,7 +292,7 @@ static int alloc_all(msom *m) {
   m->flayers[MSOM_RD] = 1;
   m->fbc[MSOM_RD] = m->bc == BC_PERIODIC ? BC_PERIODIC : BC_NEUMANN;
   for (int k = 0; k < MSOM_NFIELDS; k++) {
-    if (k == MSOM_NOISE || k == MSOM_SIGMA || k == MSOM_QOF) continue;  // allocated when "stochastic" is switched on / on the first filter call
+    if (k == MSOM_NOISE || k == MSOM_SIGMA || k == MSOM_QOF || k >= MSOM_DE_BF) continue;  // allocated when "stochastic" is switched on / on the first filter call
     if (k >= MSOM_PTR && k <= MSOM_PTR_PRED && m->p.nptr <= 0) continue;
     size_t bytes = m->g.ls * m->flayers[k] * sizeof(double);
     HIPCHK(hipMalloc(&m->f[k], bytes));
@@ -605,7 +607,7 @@ extern "C" int msom_field_layers(msom_t *m, int field) {
 
 static int ensure_field(msom *m, int field);
 extern "C" int msom_set_field(msom_t *m, int field, const double *a) {
-  if (m && field == MSOM_QOF && ensure_field(m, field)) return MSOM_ERR_HIP;
+  if (m && (field == MSOM_QOF || (field >= MSOM_DE_BF && field < MSOM_NFIELDS)) && ensure_field(m, field)) return MSOM_ERR_HIP;
   if (check_field(m, field) || !a) return MSOM_ERR_ARG;
   int r = upload(m, field, a);
   if (r) return r;
@@ -618,7 +620,7 @@ extern "C" int msom_set_field(msom_t *m, int field, const double *a) {
   return sync_stream(m);
 }
 extern "C" int msom_get_field(msom_t *m, int field, double *a) {
-  if (m && field == MSOM_QOF && ensure_field(m, field)) return MSOM_ERR_HIP;
+  if (m && (field == MSOM_QOF || (field >= MSOM_DE_BF && field < MSOM_NFIELDS)) && ensure_field(m, field)) return MSOM_ERR_HIP;
   if (check_field(m, field) || !a) return MSOM_ERR_ARG;
   return download(m, field, a);
 }
@@ -650,7 +652,7 @@ static void make_relax_coef(msom *m, int k) {
   if (nl < 2) return;
   double t0[MSOM_MAXNL], t1[MSOM_MAXNL], t2[MSOM_MAXNL];
   for (int l = 0; l < nl - 1; l++) {
-    const double r = m->p.Frm[l] / m->p.Rom;
+    const double r = m->s_zero ? 0. : m->p.Frm[l] / m->p.Rom;
     rc.S[l] = r * r;
   }
   for (int l = 0; l < nl; l++) {
@@ -747,6 +749,7 @@ static int build_coefs(msom *m) {
   // S = (Fr/Ro)^2 :1043-1048, then restricted to every level (hoisted out of the solve:
   // the reference redoes it on every poisson_layer call, msqg/poisson_layer.h:284)
   launch_make_S(m->st, m->f[MSOM_FR], m->f[MSOM_RO], m->f[MSOM_S], m->g, m->nlm);
+  if (m->s_zero) HIPCHK(hipMemsetAsync(m->f[MSOM_S], 0, m->g.ls * m->nlm * sizeof(double), m->st));
   fill_bc(m, MSOM_S);
   launch_nat_to_split(m->st, m->f[MSOM_S], m->g, m->S[0], m->sg[0], m->nlm);
   for (int k = 1; k < m->nlev; k++) launch_restrict(m->st, m->S[k - 1], m->sg[k - 1], m->S[k], m->sg[k], m->nlm);
@@ -778,6 +781,7 @@ static int build_coefs(msom *m) {
 
 extern "C" int msom_set_const(msom_t *m) {
   if (!m) return MSOM_ERR_ARG;
+  m->s_zero = 0;
   int rr = build_coefs(m);
   if (rr) return rr;
   m->wv_ready = 0;  // sig_filt / sig_lev are rebuilt from Rd on the next filter call (msqg/qg.h:1059-1090)
@@ -1460,10 +1464,10 @@ static int wavelet_apply(msom *m, double *f) {
   HIPCHK(hipGetLastError());
   return MSOM_OK;
 }
-extern "C" int msom_wavelet_filter(msom_t *m, double dtflt) {
+static int wavelet_filter(msom *m, int qof_field, double dtflt) {
   NEED_CONST(m);
   int r;
-  if ((r = wavelet_setup(m)) || (r = ensure_field(m, MSOM_QOF))) return r;
+  if ((r = wavelet_setup(m)) || (r = ensure_field(m, qof_field))) return r;
   const int nl = m->nl;
   // tmp = q (interior; the saved copy is restored into q when dtflt < 0)
   HIPCHK(hipMemcpyAsync(m->f[MSOM_TMP], m->f[MSOM_Q], m->g.ls * nl * sizeof(double), hipMemcpyDeviceToDevice, m->st));
@@ -1473,11 +1477,101 @@ extern "C" int msom_wavelet_filter(msom_t *m, double dtflt) {
   comp_del2(m, MSOM_PSI, MSOM_Q, 0., 1.);
   comp_stretch(m, MSOM_PSI, MSOM_Q, 1., 1.);
   // `nbar` is a by-value argument in the reference (msqg/qg.h:510,558): the running mean never advances
-  launch_wv_qof(m->st, m->f[MSOM_QOF], m->f[MSOM_Q], m->f[MSOM_TMP], m->g, nl, dtflt, 0, dtflt < 0.0);
+  launch_wv_qof(m->st, m->f[qof_field], m->f[MSOM_Q], m->f[MSOM_TMP], m->g, nl, dtflt, 0, dtflt < 0.0);
   if (dtflt < 0.0) fill_bc(m, MSOM_Q);
-  fill_bc(m, MSOM_QOF);
+  fill_bc(m, qof_field);
   return sync_stream(m);
 }
+extern "C" int msom_wavelet_filter(msom_t *m, double dtflt) { return wavelet_filter(m, MSOM_QOF, dtflt); }
+
+// ------------------------------------------------------------------ energy / PV budgets (msqg/qg_energy.h)
+
+static int ensure_de_fields(msom *m) {
+  for (int k = MSOM_DE_BF; k <= MSOM_PO_MFT; k++) {
+    int r = ensure_field(m, k);
+    if (r) return r;
+  }
+  return MSOM_OK;
+}
+// advection_de + dissip_de + ekman_friction_de on the current psi / zeta (energy_tend :229-232, pystep_de :327-329)
+static int de_terms(msom *m, double dt, double ediag) {
+  const Params &p = m->p;
+  const int nl = m->nl;
+  const double D = p.L0 / m->gnx;
+  launch_advection_de(m->st, m->f[MSOM_ZETA], m->f[MSOM_PSI], m->f[MSOM_PSIPG], m->f[MSOM_ZETAPG], m->f[MSOM_S], m->f[MSOM_DE_J1], m->f[MSOM_DE_J2],
+                      m->f[MSOM_DE_J3], m->g, nl, D, p.beta, dt, ediag, m->lc);
+  comp_del2(m, MSOM_ZETA, MSOM_TMP, 0., 1.);
+  comp_stretch(m, MSOM_ZETA, MSOM_TMP2, 0., 1.);
+  launch_dissip_de(m->st, m->f[MSOM_TMP], m->f[MSOM_TMP2], m->f[MSOM_PSI], m->f[MSOM_DE_VD], m->g, nl, p.iRe, p.iRe4, dt, ediag, D, 0);
+  comp_stretch(m, MSOM_TMP, MSOM_TMP2, 0., 1.);
+  launch_dissip_de(m->st, m->f[MSOM_TMP], m->f[MSOM_TMP2], m->f[MSOM_PSI], m->f[MSOM_DE_VD], m->g, nl, p.iRe, p.iRe4, dt, ediag, D, 1);
+  launch_ekman_de(m->st, m->f[MSOM_ZETA], m->f[MSOM_PSI], m->f[MSOM_DE_BF], m->g, nl, p.Eks / (p.Rom * 2 * m->dhf[0]),
+                  p.Ekb / (p.Rom * 2 * m->dhf[nl - 1]), dt, ediag);
+  HIPCHK(hipGetLastError());
+  return m->sticky;
+}
+extern "C" int msom_energy_tend(msom_t *m, double dt) {
+  NEED_CONST(m);
+  if (m->nranks > 1) { msom_set_error("energy diagnostics need a single-tile grid"); return MSOM_ERR_STATE; }
+  int r;
+  if ((r = ensure_de_fields(m))) return r;
+  comp_del2(m, MSOM_PSI, MSOM_ZETA, 0., 1.0);
+  if ((r = de_terms(m, dt, (double)m->p.ediag))) return r;
+  launch_running_mean(m->st, m->f[MSOM_PO_MFT], m->f[MSOM_PSI], m->g, m->nl, m->nme_ft);
+  m->nme_ft += 1;
+  return sync_stream(m);
+}
+static int filter_de(msom *m, int pm_field, double dtflt, double ediag) {
+  int r;
+  if ((r = ensure_de_fields(m))) return r;
+  if ((r = wavelet_filter(m, MSOM_TMP2, -dtflt))) return r;  // tmp2: tmp is used inside wavelet_filter (:210-213)
+  launch_filter_de(m->st, m->f[MSOM_DE_FT], m->f[MSOM_TMP2], m->f[pm_field], m->g, m->nl, dtflt, ediag);
+  m->nme_ft = 0;
+  return sync_stream(m);
+}
+extern "C" int msom_filter_de(msom_t *m, int pm_field, double dtflt) {
+  NEED_CONST(m);
+  if (pm_field < 0 || pm_field >= MSOM_NFIELDS || m->flayers[pm_field] != m->nl) { msom_set_error("bad field id %d", pm_field); return MSOM_ERR_ARG; }
+  int r = ensure_field(m, pm_field);
+  return r ? r : filter_de(m, pm_field, dtflt, (double)m->p.ediag);
+}
+extern "C" int msom_reset_de(msom_t *m) {
+  if (!m) return MSOM_ERR_ARG;
+  int r;
+  if ((r = ensure_de_fields(m))) return r;
+  for (int k = MSOM_DE_BF; k <= MSOM_DE_FT; k++) HIPCHK(hipMemsetAsync(m->f[k], 0, m->g.ls * m->nl * sizeof(double), m->st));
+  return sync_stream(m);
+}
+// pystep_de, msqg/qg_energy.h:296-349 (SWIG: msqg/qg_energy.i:31; caller msqg/scripts/energy_offline.py:113).
+// ediag = 1 and dt = 1 are locals of the reference routine; filter_de runs with po_mft = pol (so the
+// stream function is zeroed on exit) and the global dtflt.
+extern "C" int pystep_de(msom_t *m, const double *po_py, int len1, int len2, int len3, double *de_bf_py, int len4, int len5, int len6,
+                         double *de_vd_py, int len7, int len8, int len9, double *de_j1_py, int len10, int len11, int len12,
+                         double *de_j2_py, int len13, int len14, int len15, double *de_j3_py, int len16, int len17, int len18,
+                         double *de_ft_py, int len19, int len20, int len21, int onlyKE) {
+  NEED_CONST(m);
+  if (check_shape(m, len1, len2, len3) || check_shape(m, len4, len5, len6) || check_shape(m, len7, len8, len9) || check_shape(m, len10, len11, len12) ||
+      check_shape(m, len13, len14, len15) || check_shape(m, len16, len17, len18) || check_shape(m, len19, len20, len21))
+    return MSOM_ERR_ARG;
+  if (!po_py) return MSOM_ERR_ARG;
+  const double ediag = 1., dt = 1.;
+  int r;
+  if ((r = upload(m, MSOM_PSI, po_py)) || (r = msom_reset_de(m))) return r;
+  m->umax_ready = 0;
+  comp_del2(m, MSOM_PSI, MSOM_ZETA, 0., 1.0);
+  comp_del2(m, MSOM_PSI, MSOM_Q, 0., 1.);
+  comp_stretch(m, MSOM_PSI, MSOM_Q, 1., 1.);
+  if (onlyKE == 1 && !m->s_zero) {  // :319-325 strl = 0 (stays so until the next set_const)
+    m->s_zero = 1;
+    if ((r = build_coefs(m))) return r;
+  }
+  if ((r = de_terms(m, dt, ediag)) || (r = filter_de(m, MSOM_PSI, m->p.dtflt, ediag))) return r;
+  double *outs[6] = {de_bf_py, de_vd_py, de_j1_py, de_j2_py, de_j3_py, de_ft_py};
+  for (int k = 0; k < 6; k++)
+    if (outs[k] && (r = download(m, MSOM_DE_BF + k, outs[k]))) return r;
+  return MSOM_OK;
+}
+
 extern "C" int msom_dbg_wavelet_levels(msom_t *m) {
   if (!m) return MSOM_ERR_ARG;
   int r = wavelet_setup(m);
@@ -1663,10 +1757,13 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
   if (m->iter == 0 && (r = backup_config(m, dpath))) return r;  // event write_const (t = 0)
   for (;;) {
     if (filtering && tflt <= p.tend + 1e-10 && m->t >= tflt - 1e-12 * fmax(1., fabs(tflt))) {
+      // two events named `filter`: the later-defined one (qg_energy.h:269-272) runs first [BASILISK RULE 8]
+      if (p.ediag > -1 && (r = filter_de(m, MSOM_PO_MFT, p.dtflt, (double)p.ediag))) return r;
       fprintf(stdout, "Filter solution\n");
       if ((r = msom_wavelet_filter(m, p.dtflt))) return r;
       tflt += p.dtflt;
     }
+    if (p.ediag > -1 && (r = msom_energy_tend(m, m->dt))) return r;  // event comp_diag (i++), qg_energy.h:289-291
     // writestdout, msqg/qg.c:101-109
     fprintf(stdout, "i = %i, dt = %g, t = %g, ke_1 = %g\n", m->iter, m->dt, m->t, msom_ke(m));
     // output, msqg/qg.c:112-122
@@ -1692,6 +1789,18 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
         if (r) return r;
         snprintf(name, sizeof name, "%spf%09d.bas", dpath, m->iter);
         if ((r = msom_write_bas(m, MSOM_TMP, name))) return r;
+      }
+      if (p.ediag > -1) {  // msqg/qg.c:139-160: budgets scaled by 1/dtout, written, reset
+        const char *tags[6] = {"de_bf", "de_vd", "de_j1", "de_j2", "de_j3", "de_ft"};
+        std::vector<double> h((size_t)m->nl * m->nx * m->ny);
+        const double idtout = 1 / p.dtout;
+        for (int k = 0; k < 6; k++) {
+          if ((r = msom_get_field(m, MSOM_DE_BF + k, h.data()))) return r;
+          for (double &v : h) v *= idtout;
+          snprintf(name, sizeof name, "%s%s%09d.bas", dpath, tags[k], m->iter);
+          if (msom_bas_write(name, h.data(), m->nl, m->nx, p.L0)) return MSOM_ERR_IO;
+        }
+        if ((r = msom_reset_de(m))) return r;
       }
       if (p.nptr > 0) {  // msqg/qg.c:168-171
         snprintf(name, sizeof name, "%sptr%09d.bas", dpath, m->iter);
