@@ -282,17 +282,31 @@ __global__ void __launch_bounds__(FNT, MINW) k_rhs_fused(RhsArgs a) {
 }
 
 __global__ void k_max_final2(const double *partial, double *out, int nb, int nl) {
-  __shared__ double sm[256];
-  const int l = blockIdx.x;
-  double v = 0.;
-  for (int b = threadIdx.x; b < nb; b += 256) v = fmax(v, partial[(size_t)b * nl + l]);
-  sm[threadIdx.x] = v;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + o]);
-    __syncthreads();
+  // MAXF_BLOCKS blocks, each over a contiguous chunk of partial rows; thread = row, the nl values of a
+  // row are contiguous.  max of non-negative doubles is order-independent: atomicMax on the bit pattern
+  // (out[] zeroed by the launcher).
+  __shared__ double sm[MSOM_MAXNL][4];
+  const int per = (nb + gridDim.x - 1) / gridDim.x, b0 = blockIdx.x * per, b1 = min(nb, b0 + per);
+  double v[MSOM_MAXNL];
+#pragma unroll
+  for (int l = 0; l < MSOM_MAXNL; l++) v[l] = 0.;
+  for (int b = b0 + threadIdx.x; b < b1; b += 256) {
+    const double *row = partial + (size_t)b * nl;
+#pragma unroll
+    for (int l = 0; l < MSOM_MAXNL; l++)
+      if (l < nl) v[l] = fmax(v[l], row[l]);
   }
-  if (threadIdx.x == 0) out[l] = sm[0];
+#pragma unroll
+  for (int l = 0; l < MSOM_MAXNL; l++) {
+    double w = v[l];
+    for (int o = 32; o > 0; o >>= 1) w = fmax(w, __shfl_down(w, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[l][threadIdx.x >> 6] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < nl) {
+    const double w = fmax(fmax(sm[threadIdx.x][0], sm[threadIdx.x][1]), fmax(sm[threadIdx.x][2], sm[threadIdx.x][3]));
+    atomicMax((unsigned long long *)(out + threadIdx.x), (unsigned long long)__double_as_longlong(w));
+  }
 }
 
 // ------------------------------------------------------------------ software-pipelined variant
@@ -483,5 +497,8 @@ void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const 
     case 5: hipLaunchKernelGGL((k_rhs_fused<8, 256, 4>), gr, dim3(256), 0, st, a); break;
     default: hipLaunchKernelGGL((k_rhs_fused<32, 512, 2>), gr, dim3(512), 0, st, a); break;
   }
-  if (umax_partial) hipLaunchKernelGGL(k_max_final2, dim3(nl), dim3(256), 0, st, umax_partial, umax_out, (int)(gr.x * gr.y), nl);
+  if (umax_partial) {
+    (void)hipMemsetAsync(umax_out, 0, nl * sizeof(double), st);
+    hipLaunchKernelGGL(k_max_final2, dim3(64), dim3(256), 0, st, umax_partial, umax_out, (int)(gr.x * gr.y), nl);
+  }
 }

@@ -223,7 +223,7 @@ struct Res2Args {
   double *a_out, *res, *res_c, *maxres, *sum_partial, *umax_partial;
   NatGeom g;
   SplitGeom sg, cg;
-  int nl, uniformS, want_sum, walls;
+  int nl, uniformS, want_sum, walls, dbg;
   RelaxCoef rc;
 };
 
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
       }
       if (RESTRICT) { sr[l][threadIdx.y][threadIdx.x][0] = re; sr[l][threadIdx.y][threadIdx.x][1] = ro; }
       m = fmax(m, fmax(fabs(re), fabs(ro)));
-      if (CORRECT) {
+      if (CORRECT && !(p.dbg & 64)) {
         // face velocities of the corrected psi (comp_vel, msqg/qg.h:276-283): west and south face
         // of both cells; feeds the dt limiter so that dt is known before the tendency pass
         const double *d = p.da + (size_t)l * p.sg.ls;
@@ -360,19 +360,167 @@ __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
   }
 }
 
-// out[l] = max_b partial[b][l]
-__global__ void k_max_final_mg(const double *partial, double *out, int nb, int nl) {
-  __shared__ double sm[256];
-  const int l = blockIdx.x;
-  double v = 0.;
-  for (int b = threadIdx.x; b < nb; b += 256) v = fmax(v, partial[(size_t)b * nl + l]);
-  sm[threadIdx.x] = v;
+// LDS-tiled form of k_residual2<CORRECT = true, WRITE = false, RESTRICT = false> for the finest level:
+// a_new = a + da is formed ONCE per cell (own cells + a 1-cell halo ring) in a (CR_TR + 2) x 130 LDS tile,
+// double-buffered over the layers, and the 5-point residual, the vertical coupling and the face
+// velocities (which need the diagonal neighbours) all read it from there: 4 global loads per pair and
+// layer instead of ~20.  The arithmetic per cell is the same expression sequence as k_residual2, so the
+// results are identical bit for bit.  Thread (tx, ty) owns the column pair 2 tx, 2 tx + 1 of rows
+// ty, ty + 4, ...; one barrier per layer.
+#define CR_TR 16
+#define CR_TW 128
+#define CR_LP 132  // LDS row pitch (130 used)
+template <bool UNIFORM>
+__global__ void __launch_bounds__(BX *BY, 4) k_correct_residual(Res2Args p) {
+  __shared__ __align__(16) double T[2][CR_TR + 2][CR_LP];
+  __shared__ double smm[BY];
+  __shared__ double smu[MSOM_MAXNL][BY];
+  constexpr int NR = CR_TR / BY;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * BX + tx;
+  const int x0 = blockIdx.x * CR_TW, y0 = blockIdx.y * CR_TR;
+  const int nl = p.nl, nx = p.g.nx, ny = p.g.ny;
+  const int i = x0 + 2 * tx;
+  const double D = p.rc.D, rD = 1. / D;
+  const bool inx = i < nx;
+  // row k of this thread: j = y0 + ty + BY k; natural / split offsets advance by BY rows
+  const size_t c0 = nat_idx(p.g, 0, y0 + ty, inx ? i : 0), se0 = split_idx(p.sg, 0, y0 + ty, inx ? i : 0);
+  const size_t cstep = (size_t)BY * p.g.pitch, sstep = (size_t)BY * p.sg.rp;
+  // halo ring: rows -1 and CR_TR over columns -1..128, columns -1 and 128 over rows 0..CR_TR-1
+  constexpr int NH = 2 * (CR_TW + 2) + 2 * CR_TR;
+  double a0e[NR], a0o[NR], a1e[NR], a1o[NR], a2e[NR], a2o[NR];
+  // own cells of layer l -> registers (xe, xo) and LDS buffer b; halo cells -> LDS
+  auto stage = [&](int l, int b, double *xe, double *xo) {
+    const double *al = p.a + (size_t)l * p.g.ls, *dl = p.da + (size_t)l * p.sg.ls;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      double e = 0., o = 0.;
+      if (inx && y0 + ty + BY * k < ny) {
+        const double2 v = *reinterpret_cast<const double2 *>(al + c0 + k * cstep);
+        e = v.x + dl[se0 + k * sstep];
+        o = v.y + dl[se0 + k * sstep + p.sg.hp];
+      }
+      xe[k] = e; xo[k] = o;
+      *reinterpret_cast<double2 *>(&T[b][ty + BY * k + 1][2 * tx + 2]) = make_double2(e, o);
+    }
+    for (int h = tid; h < NH; h += BX * BY) {
+      int r, cc;
+      if (h < CR_TW + 2) { r = -1; cc = h - 1; }
+      else if (h < 2 * (CR_TW + 2)) { r = CR_TR; cc = h - (CR_TW + 2) - 1; }
+      else if (h < 2 * (CR_TW + 2) + CR_TR) { r = h - 2 * (CR_TW + 2); cc = -1; }
+      else { r = h - 2 * (CR_TW + 2) - CR_TR; cc = CR_TW; }
+      const int gx = x0 + cc, gy = y0 + r;
+      double v = 0.;
+      if (gx <= nx && gy <= ny) v = al[nat_idx(p.g, 0, gy, gx)] + dl[split_idx(p.sg, 0, gy, gx)];
+      T[b][r + 1][cc + 2] = v;
+    }
+  };
+  double m = 0.;
+  double s1e[NR], s1o[NR], s0e[NR], s0o[NR];  // UNIFORM: unused (the layer constants are scalars)
+#pragma unroll
+  for (int k = 0; k < NR; k++) { a0e[k] = a0o[k] = a2e[k] = a2o[k] = 0.; s0e[k] = s0o[k] = s1e[k] = s1o[k] = 0.; }
+  stage(0, 0, a1e, a1o);
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + o]);
+  for (int l = 0; l < nl; l++) {
+    const int b = l & 1;
+    if (l < nl - 1) stage(l + 1, b ^ 1, a2e, a2o);
+    const double su0 = l > 0 ? p.rc.S[l - 1] : 0., su1 = l < nl - 1 ? p.rc.S[l] : 0.;
+    const double i0 = p.rc.idh0[l], i1 = p.rc.idh1[l];
+    double uu = 0.;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      const int j = y0 + ty + BY * k;
+      if (inx && j < ny) {
+        const int r = ty + BY * k + 1, cx = 2 * tx + 2;  // LDS coordinates of the even cell
+        const size_t cl = c0 + k * cstep + (size_t)l * p.g.ls;
+        const double2 bv = *reinterpret_cast<const double2 *>(p.b + cl);
+        const double be = bv.x, bo = bv.y;
+        double z0e, z0o, z1e, z1o;
+        if (UNIFORM) { z0e = z0o = su0; z1e = z1o = su1; }
+        else {
+          if (l < nl - 1) { const double2 sv = *reinterpret_cast<const double2 *>(p.S + cl); s1e[k] = sv.x; s1o[k] = sv.y; }
+          z0e = s0e[k]; z0o = s0o[k]; z1e = s1e[k]; z1o = s1o[k];
+        }
+        const double e1 = a1e[k], o1 = a1o[k];
+        const double a1w = T[b][r][cx - 1], a1ee = T[b][r][cx + 2];
+        const double2 sv2 = *reinterpret_cast<const double2 *>(&T[b][r - 1][cx]), nv2 = *reinterpret_cast<const double2 *>(&T[b][r + 1][cx]);
+        const double a1se = sv2.x, a1so = sv2.y, a1ne = nv2.x, a1no = nv2.y;
+        double re = be, ro = bo;
+        if (nl > 1) {
+          if (l == 0) {
+            re = be + z1e * (e1 - a2e[k]) * i1;
+            ro = bo + z1o * (o1 - a2o[k]) * i1;
+          } else if (l < nl - 1) {
+            re = be + z0e * (e1 - a0e[k]) * i0 - z1e * (a2e[k] - e1) * i1;
+            ro = bo + z0o * (o1 - a0o[k]) * i0 - z1o * (a2o[k] - o1) * i1;
+          } else {
+            re = be + z0e * (e1 - a0e[k]) * i0;
+            ro = bo + z0o * (o1 - a0o[k]) * i0;
+          }
+        }
+        re += DIVC(DIVC(e1 - a1w, D, rD) - DIVC(o1 - e1, D, rD), D, rD);
+        re += DIVC(DIVC(e1 - a1se, D, rD) - DIVC(a1ne - e1, D, rD), D, rD);
+        ro += DIVC(DIVC(o1 - e1, D, rD) - DIVC(a1ee - o1, D, rD), D, rD);
+        ro += DIVC(DIVC(o1 - a1so, D, rD) - DIVC(a1no - o1, D, rD), D, rD);
+        *reinterpret_cast<double2 *>(p.a_out + cl) = make_double2(e1, o1);
+        nat_write_ghosts(p.a_out, p.g, l, j, i, e1, p.walls);
+        nat_write_ghosts(p.a_out, p.g, l, j, i + 1, o1, p.walls);
+        m = fmax(m, fmax(fabs(re), fabs(ro)));
+        // face velocities of the corrected psi (comp_vel, msqg/qg.h:276-283): west and south faces of both cells
+        const double nw = T[b][r + 1][cx - 1], sw = T[b][r - 1][cx - 1], se2 = T[b][r - 1][cx + 2];
+        const double ue = fabs(DIVC(0.25 * (a1ne - a1se + nw - sw), D, rD)), ve = fabs(DIVC(0.25 * (o1 - a1w + a1so - sw), D, rD));
+        const double uo = fabs(DIVC(0.25 * (a1no - a1so + a1ne - a1se), D, rD)), vo = fabs(DIVC(0.25 * (a1ee - e1 + se2 - a1se), D, rD));
+        uu = fmax(uu, fmax(fmax(ue, ve), fmax(uo, vo)));
+        a0e[k] = e1; a0o[k] = o1;
+        if (!UNIFORM) { s0e[k] = s1e[k]; s0o[k] = s1o[k]; }
+        a1e[k] = a2e[k]; a1o[k] = a2o[k];
+      }
+    }
+    uu = wave_max(uu);
+    if (tx == 0) smu[l][ty] = uu;
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[l] = sm[0];
+  m = wave_max(m);
+  if (tx == 0) smm[ty] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double mm = smm[0];
+    for (int k = 1; k < BY; k++) mm = fmax(mm, smm[k]);
+    atomicMax((unsigned long long *)p.maxres, (unsigned long long)__double_as_longlong(mm));
+  }
+  if (ty == 0 && tx < nl) {
+    double v = smu[tx][0];
+    for (int k = 1; k < BY; k++) v = fmax(v, smu[tx][k]);
+    p.umax_partial[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * nl + tx] = v;
+  }
+}
+
+// out[l] = max_b partial[b][l]
+__global__ void k_max_final_mg(const double *partial, double *out, int nb, int nl) {
+  // MAXF_BLOCKS blocks, each over a contiguous chunk of partial rows; thread = row, the nl values of a
+  // row are contiguous.  max of non-negative doubles is order-independent: atomicMax on the bit pattern
+  // (out[] zeroed by the launcher).
+  __shared__ double sm[MSOM_MAXNL][4];
+  const int per = (nb + gridDim.x - 1) / gridDim.x, b0 = blockIdx.x * per, b1 = min(nb, b0 + per);
+  double v[MSOM_MAXNL];
+#pragma unroll
+  for (int l = 0; l < MSOM_MAXNL; l++) v[l] = 0.;
+  for (int b = b0 + threadIdx.x; b < b1; b += 256) {
+    const double *row = partial + (size_t)b * nl;
+#pragma unroll
+    for (int l = 0; l < MSOM_MAXNL; l++)
+      if (l < nl) v[l] = fmax(v[l], row[l]);
+  }
+#pragma unroll
+  for (int l = 0; l < MSOM_MAXNL; l++) {
+    double w = v[l];
+    for (int o = 32; o > 0; o >>= 1) w = fmax(w, __shfl_down(w, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[l][threadIdx.x >> 6] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < nl) {
+    const double w = fmax(fmax(sm[threadIdx.x][0], sm[threadIdx.x][1]), fmax(sm[threadIdx.x][2], sm[threadIdx.x][3]));
+    atomicMax((unsigned long long *)(out + threadIdx.x), (unsigned long long)__double_as_longlong(w));
+  }
 }
 
 int residual2_blocks(const NatGeom &g) {
@@ -384,14 +532,22 @@ void launch_residual2(hipStream_t st, int mode, const double *a, const double *d
                       const NatGeom &g, double *res, const SplitGeom &sg, double *res_c, const SplitGeom &cg, int nl, const RelaxCoef &rc,
                       int uniformS, int walls, double *maxres, double *sum_partial, int want_sum, double *umax_partial, double *umax_out) {
   Res2Args p;
+  extern int g_rhs_dbg;
+  p.dbg = g_rhs_dbg;
   p.umax_partial = umax_partial;
   p.a = a; p.b = b; p.S = S; p.da = da; p.a_out = a_out; p.res = res; p.res_c = res_c; p.maxres = maxres; p.sum_partial = sum_partial;
   p.g = g; p.sg = sg; p.cg = cg; p.nl = nl; p.uniformS = uniformS; p.want_sum = want_sum; p.walls = walls; p.rc = rc;
   dim3 gr = grid2d(g.nx / 2, g.ny);
   switch (mode) {
     case 1:
-      hipLaunchKernelGGL((k_residual2<true, false, false>), gr, block2d(), 0, st, p);
-      hipLaunchKernelGGL(k_max_final_mg, dim3(nl), dim3(256), 0, st, umax_partial, umax_out, (int)(gr.x * gr.y), nl);
+      if (g.nx % 2 == 0 && g.nx >= CR_TW && g.ny >= CR_TR && !(p.dbg & 128)) {
+        gr = dim3((g.nx + CR_TW - 1) / CR_TW, (g.ny + CR_TR - 1) / CR_TR);
+        if (uniformS) hipLaunchKernelGGL(k_correct_residual<true>, gr, block2d(), 0, st, p);
+        else hipLaunchKernelGGL(k_correct_residual<false>, gr, block2d(), 0, st, p);
+      } else
+        hipLaunchKernelGGL((k_residual2<true, false, false>), gr, block2d(), 0, st, p);
+      (void)hipMemsetAsync(umax_out, 0, nl * sizeof(double), st);
+      hipLaunchKernelGGL(k_max_final_mg, dim3(64), dim3(256), 0, st, umax_partial, umax_out, (int)(gr.x * gr.y), nl);
       break;
     case 2: hipLaunchKernelGGL((k_residual2<false, true, false>), gr, block2d(), 0, st, p); break;
     case 6: hipLaunchKernelGGL((k_residual2<false, true, true>), gr, block2d(), 0, st, p); break;

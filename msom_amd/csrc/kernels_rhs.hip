@@ -492,7 +492,29 @@ __global__ void k_sum_final(const double *partial, double *out, int n) {
   }
   if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
 }
+// n > 4096: two stages (SUM_CHUNKS blocks over contiguous chunks, then one block over the chunk sums),
+// fixed shape => deterministic.  The chunk sums live behind the partials (the caller's array holds
+// at least n + SUM_CHUNKS entries).
+#define SUM_CHUNKS 64
+__global__ void k_sum_chunks(double *partial, int n) {
+  __shared__ double sm[256];
+  const int per = (n + SUM_CHUNKS - 1) / SUM_CHUNKS, k0 = blockIdx.x * per, k1 = min(n, k0 + per);
+  double s = 0.;
+  for (int k = k0 + threadIdx.x; k < k1; k += 256) s += partial[k];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[n + blockIdx.x] = sm[0];
+}
 void launch_sum_final(hipStream_t st, const double *partial, double *out, int n) {
+  if (n > 4096) {
+    hipLaunchKernelGGL(k_sum_chunks, dim3(SUM_CHUNKS), dim3(256), 0, st, const_cast<double *>(partial), n);
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, st, partial + n, out, SUM_CHUNKS);
+    return;
+  }
   hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, st, partial, out, n);
 }
 int partial_count(const NatGeom &g) {

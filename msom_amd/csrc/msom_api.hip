@@ -320,7 +320,7 @@ static int alloc_all(msom *m) {
   HIPCHK(hipMalloc(&m->psi_alt, m->g.ls * m->nl * sizeof(double)));
   HIPCHK(hipMemsetAsync(m->psi_alt, 0, m->g.ls * m->nl * sizeof(double), m->st));
   HIPCHK(hipMalloc(&m->staging, (size_t)m->nl * (m->p.nptr > 1 ? m->p.nptr : 1) * m->nx * m->ny * sizeof(double)));
-  HIPCHK(hipMalloc(&m->partial, (size_t)partial_count(m->g) * m->nl * sizeof(double)));
+  HIPCHK(hipMalloc(&m->partial, ((size_t)partial_count(m->g) * m->nl + 64) * sizeof(double)));  // + chunk sums of launch_sum_final
   {
     size_t nb = (size_t)rhs_fused_blocks(m->g);
     if (nb < 2048) nb = 2048;
@@ -1977,6 +1977,12 @@ extern "C" int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double
       launch_relax_block2(m->st, m->da[0], m->da[1], m->sg[1], m->res[0], m->da_alt[0], m->sg[0], m->nl, m->rc[0], m->walls, 1);
     } else if (!strcmp(kernel, "rhs")) {
       rhs_terms(m, MSOM_Q, MSOM_DQ, 1, m->p.iRe, m->p.iRe4, m->p.Eks, m->p.Ekb);
+    } else if (!strcmp(kernel, "resid_correct")) {
+      residual2(m, 1, m->f[MSOM_Q], SC_RES1, 0);
+    } else if (!strcmp(kernel, "resid_restrict")) {
+      residual2(m, 2 | 4, m->f[MSOM_Q], SC_RES1, 1);
+    } else if (!strcmp(kernel, "red_prolong")) {
+      launch_relax_red_prolong(m->st, m->da[0], m->da[1], m->sg[1], m->res[0], m->S[0], m->sg[0], m->nl, m->rc[0], m->uniformS, m->walls);
     } else if (!strcmp(kernel, "advance")) {
       launch_advance(m->st, m->f[MSOM_QPRED], m->f[MSOM_Q], m->f[MSOM_DQ], nullptr, m->g, m->nl, 1e-9, 0.);
     }

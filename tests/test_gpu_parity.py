@@ -407,6 +407,28 @@ def test_wide_level_two_point_relax_kernel(nx, ny, nl, uniform):
             assert rel(p_g, p_o) <= 1e-9
 
 
+@pytest.mark.parametrize("nx,ny,nl,extra", [(256, 128, 6, ""), (128, 16, 3, "sbc = -1\n"), (512, 32, 1, ""), (256, 256, 4, "varRo = 1\n")])
+@pytest.mark.parametrize("strict", [True, False])
+def test_lds_correct_residual_equals_plain(nx, ny, nl, extra, strict):
+    """k_correct_residual (correction + residual + face velocities through an LDS tile) against
+    k_residual2<CORRECT> (rhs_dbg bit 128 selects the plain kernel): psi, q, dt and the multigrid statistics
+    of a few steps are identical bit for bit in both builds."""
+    txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else "") + extra)
+    out = {}
+    for dbg in (0, 128):
+        g = QG(txt, strict=strict)
+        g.option("quiet", 1); g.option("rhs_dbg", dbg); g.option("TOLERANCE", 1e-7)
+        g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx))
+        g.set_const()
+        dts = [g.step() for _ in range(3)]
+        st = g.mgstats()
+        out[dbg] = (g.get(F["PSI"]), g.get(F["Q"]), dts, (st.i, st.resb, st.resa))
+        g.option("rhs_dbg", 0)
+        g.close()
+    assert np.array_equal(out[0][0], out[128][0]) and np.array_equal(out[0][1], out[128][1])
+    assert out[0][2] == out[128][2] and out[0][3] == out[128][3]
+
+
 @pytest.mark.parametrize("nx,ny,nl", [(128, 64, 3), (64, 64, 6), (256, 128, 2), (192, 80, 4), (64, 32, 1)])
 @pytest.mark.parametrize("strict", [True, False])
 def test_blocked_smoother_equals_plain_sweeps(nx, ny, nl, strict):
