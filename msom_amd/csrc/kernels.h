@@ -66,11 +66,20 @@ void launch_running_mean(hipStream_t st, double *pm, const double *po, const Nat
 void launch_filter_de(hipStream_t st, double *ft, const double *tmp2, double *pm, const NatGeom &g, int nl, double dtflt, double ediag);
 
 // ---- kernels_fused.hip
+// optional by-product of the fused tendency + advance pass: the first residual of the next inversion
+struct RhsResid {
+  double *res, *res_c;       // level-0 residual (split layout) and its restriction to level 1 (or null)
+  double *res_max;           // device scalar: max|res| (zeroed by the launcher)
+  double *bsum_partial;      // one partial sum of q_out per workgroup (rhs_pipe_blocks entries)
+  SplitGeom sg, cg;
+};
 int rhs_fused_blocks(const NatGeom &g);
 void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq,
                       double *umax_partial, double *umax_out, const NatGeom &g, int nl, int walls, int uniformS, const double *Su,
                       int have_qforc, double D, double beta, double iRe, double iRe4, double cs, double cb, double slip_c,
-                      const LayerCoef &lc, int variant, const double *q_in = nullptr, double *q_out = nullptr, double dt = 0.);
+                      const LayerCoef &lc, int variant, const double *q_in = nullptr, double *q_out = nullptr, double dt = 0.,
+                      const RhsResid *rr = nullptr);
+int rhs_pipe_blocks(const NatGeom &g);
 
 // ---- kernels_mg.hip
 void launch_nat_to_split(hipStream_t st, const double *nat, const NatGeom &g, double *sp, const SplitGeom &sg, int nl);

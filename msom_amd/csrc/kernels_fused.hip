@@ -42,6 +42,12 @@ struct RhsArgs {
   double D, beta, iRe, iRe4, cs, cb, slip_c;
   LayerCoef lc;
   double Su[MSOM_MAXNL];
+  // optional by-product of the fused advance (k_rhs_fused_pipe): the multigrid residual of the NEXT
+  // inversion, res = q_out - (lap + Gamma) psi (residual_layer, msqg/poisson_layer.h:182-255, same
+  // expression sequence as k_residual2), in the split layout, its restriction to level 1, max|res| and the
+  // per-block sums of q_out.  psi is the first guess of that inversion and already sits in LDS here.
+  double *res, *res_c, *res_max, *bsum_partial;
+  SplitGeom sg, cg;
 };
 
 __device__ __forceinline__ double wave_max_f(double v) {
@@ -326,6 +332,11 @@ __global__ void __launch_bounds__(FNT, 2) k_rhs_fused_pipe(RhsArgs a) {
   __shared__ double sP[3][PW * PH];
   __shared__ double sZ[2][ZW * ZH];
   __shared__ double sT[2][TW * TH];
+  // q_in of the rows this wave finalises next, fetched one barrier interval ahead by LDS-DMA
+  // (global_load_lds_dwordx4: no VGPR destination, 1 KB = 2 rows x 64 doubles per wave and interval): a
+  // plain load of q_in at the end of the dependency chain stalled the wave for a full memory latency per
+  // row (the kernel runs 2 waves per SIMD), which made the fused advance slower than a separate pass
+  __shared__ __align__(16) double sQ[2][FNT / 64][2][FTX];
 
   const int tid = threadIdx.x, tx = tid & (FTX - 1), ly0 = (tid / FTX) * RPT;
   const int x0 = blockIdx.x * FTX, y0 = blockIdx.y * FTY;
@@ -333,10 +344,36 @@ __global__ void __launch_bounds__(FNT, 2) k_rhs_fused_pipe(RhsArgs a) {
   const double D = a.D, D2 = D * D, rD2 = 1. / D2, D12 = 12. * D * D, rD12 = 1. / D12, D2x = 2 * D, rD2x = 1. / D2x;
   const int gi = x0 + tx;
   const bool late = tid >= FNT / 2;  // second wave of each SIMD: centre first, pass second
+  const bool qdma = a.q_out != nullptr && x0 + FTX <= a.g.nx && y0 + FTY <= a.g.ny;  // whole tiles only (block-uniform)
 
+#ifdef MSOM_STRICT
   double t_prev[RPT], lapT_prev[RPT], zc0[RPT], zc1[RPT], tc0[RPT], tc1[RPT], jd_prev[RPT];
 #pragma unroll
   for (int k = 0; k < RPT; k++) t_prev[k] = lapT_prev[k] = zc0[k] = zc1[k] = tc0[k] = tc1[k] = jd_prev[k] = 0.;
+#else
+  // product build: everything of layer l that is known at iteration l is folded into ONE number per cell
+  // (tl: advection + beta + cross-layer Jacobians + iRe lap(zeta) + iRe4 lap(lap(zeta)) + drag + wind), and the
+  // two stretching terms share one field X = iRe zeta + iRe4 lap(zeta); 4 carried values instead of 7
+  double tl_prev[RPT], xa0[RPT], xa1[RPT], jd_prev[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; k++) tl_prev[k] = xa0[k] = xa1[k] = jd_prev[k] = 0.;
+#endif
+  // residual by-product: psi_{l-1}, psi_{l-2} at the cell and the two horizontal flux terms of layer l-1
+  const bool want_res = a.res != nullptr;
+#ifdef MSOM_STRICT
+  // reference order ((q + A) - B) + x) + y: the four pieces are carried separately
+  double pm1[RPT], pm2[RPT], xt_prev[RPT], yt_prev[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; k++) pm1[k] = pm2[k] = xt_prev[k] = yt_prev[k] = 0.;
+#else
+  // product build: -(lap + Gamma) psi of layer l is complete at iteration l (psi_{l+1} is in LDS), so one
+  // number per cell is carried to the iteration that finalises q_out of that layer
+  double pm1[RPT], g_prev[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; k++) pm1[k] = g_prev[k] = 0.;
+#endif
+  double res_m = 0., res_bs = 0.;
+  const double rD1 = 1. / D;
 
   constexpr int NW = FNT / 64, NR = (PH + NW - 1) / NW, NE = (6 * PH + FNT - 1) / FNT;
   const int lane = tid & 63, wv = tid >> 6;
@@ -367,7 +404,21 @@ __global__ void __launch_bounds__(FNT, 2) k_rhs_fused_pipe(RhsArgs a) {
       if (e < 6 * PH) dst[(e / 6) * PW + 64 + e % 6] = pf[NR + r];
     }
   };
-  auto finalize = [&](int l, int gj, double t, double lapT, double zm, double zc, double zp, double tm, double tc, double tp) {
+  // rows ly0 + 2 h, ly0 + 2 h + 1 of layer l: q_in -> sQ[h][wave]; lane L carries 16 bytes (2 columns)
+  auto q_prefetch = [&](int l, int h) {
+    const int ln = tid & 63, rr = ln >> 5, col = (ln & 31) * 2;
+    const double *gsrc = a.q_in + nat_idx(a.g, l, y0 + ly0 + 2 * h + rr, x0 + col);
+    const unsigned lds_dst =
+        __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)(&sQ[h][tid >> 6][0][0]));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+  };
+  // returns the residual of the cell (0 unless want_res)
+  auto finalize = [&](int l, int gj, double t, double lapT, double zm, double zc, double zp, double tm, double tc, double tp, double am, double ac,
+                      double ap, double xt, double yt, int qh, int qk) -> double {
     double dq = t;
     const size_t c = nat_idx(a.g, l, gj, gi);
     double s0 = 0., s1 = 0.;
@@ -392,12 +443,52 @@ __global__ void __launch_bounds__(FNT, 2) k_rhs_fused_pipe(RhsArgs a) {
     if (l == nl - 1) dq -= a.cb * zc;
     if (l == 0) dq -= a.wind[gj];
     if (a.have_qforc) dq += a.qforc[c];
-    if (a.q_out) a.q_out[c] = a.q_in[c] + dq * a.dt;
-    else a.dq[c] = dq;
+    if (!a.q_out) { a.dq[c] = dq; return 0.; }
+    const double qn = (qh >= 0 ? sQ[qh][tid >> 6][qk][tx] : a.q_in[c]) + dq * a.dt;
+    a.q_out[c] = qn;
+    if (!want_res) return 0.;
+#ifdef MSOM_STRICT
+    double re = qn;
+    if (nl > 1) {
+      if (l == 0) re = qn + s1 * (ac - ap) * a.lc.idh1[l];
+      else if (l < nl - 1) re = qn + s0 * (ac - am) * a.lc.idh0[l] - s1 * (ap - ac) * a.lc.idh1[l];
+      else re = qn + s0 * (ac - am) * a.lc.idh0[l];
+    }
+    re += xt;
+    re += yt;
+#else
+    const double re = qn + xt;  // xt carries the whole psi part
+#endif
+    a.res[split_idx(a.sg, l, gj, gi)] = re;
+    res_m = fmax(res_m, fabs(re));
+    res_bs += qn;
+    return re;
   };
+#ifndef MSOM_STRICT
+  // product build: dq_l = tl + Gamma(X)_l (+ q_forc); q_out; residual = q_out + g
+  auto finalize_fast = [&](int l, int gj, double tl, double xm, double xc, double xp, double g, int qh, int qk) -> double {
+    double dq = tl;
+    const size_t c = nat_idx(a.g, l, gj, gi);
+    if (nl > 1) {
+      if (l > 0) dq += (a.uniformS ? a.Su[l - 1] : a.S[c - a.g.ls]) * (xm - xc) * a.lc.idh0[l];
+      if (l < nl - 1) dq += (a.uniformS ? a.Su[l] : a.S[c]) * (xp - xc) * a.lc.idh1[l];
+    }
+    if (a.have_qforc) dq += a.qforc[c];
+    if (!a.q_out) { a.dq[c] = dq; return 0.; }
+    const double qn = (qh >= 0 ? sQ[qh][tid >> 6][qk][tx] : a.q_in[c]) + dq * a.dt;
+    a.q_out[c] = qn;
+    if (!want_res) return 0.;
+    const double re = qn + g;
+    a.res[split_idx(a.sg, l, gj, gi)] = re;
+    res_m = fmax(res_m, fabs(re));
+    res_bs += qn;
+    return re;
+  };
+#endif
   // centre rows [k0, k0 + HALF) of layer l
   auto centre = [&](int l, int k0, const double *P0, const double *P1, const double *Z, const double *T) {
     double p[3][3], z[3][3], p1[3][3], tcol[3];
+    double ra_even = 0., rb_even = 0.;
 #pragma unroll
     for (int b = 0; b < 2; b++) {
 #pragma unroll
@@ -433,10 +524,67 @@ __global__ void __launch_bounds__(FNT, 2) k_rhs_fused_pipe(RhsArgs a) {
       const double zc = z[1][1], tc = tcol[1];
       const int ct = (ly + 1) * TW + (tx + 1);
       const double lapT = DIVC(T[ct + 1] + T[ct - 1] + tcol[2] + tcol[0] - 4 * tc, D2, rD2);
-      if (in && l > 0) finalize(l - 1, gj, t_prev[k], lapT_prev[k], zc0[k], zc1[k], zc, tc0[k], tc1[k], tc);
-      if (in && l == nl - 1) finalize(l, gj, t, lapT, zc1[k], zc, 0., tc1[k], tc, 0.);
+      // horizontal part of the residual of layer l at this cell: ((c - W)/D - (E - c)/D)/D, then y
+      const double pc = p[1][1];
+      double xt = 0., yt = 0.;
+      if (want_res) {
+        xt = DIVC(DIVC(pc - p[1][0], D, rD1) - DIVC(p[1][2] - pc, D, rD1), D, rD1);
+        yt = DIVC(DIVC(pc - p[0][1], D, rD1) - DIVC(p[2][1] - pc, D, rD1), D, rD1);
+      }
+      double ra = 0., rb = 0.;
+#ifdef MSOM_STRICT
+      if (in && l > 0) ra = finalize(l - 1, gj, t_prev[k], lapT_prev[k], zc0[k], zc1[k], zc, tc0[k], tc1[k], tc, pm2[k], pm1[k], pc, xt_prev[k], yt_prev[k], qdma ? k0 / HALF : -1, kk);
+      if (in && l == nl - 1) rb = finalize(l, gj, t, lapT, zc1[k], zc, 0., tc1[k], tc, 0., pm1[k], pc, 0., xt, yt, -1, 0);
+#else
+      double gl = 0.;
+      if (want_res) {  // -(lap + Gamma) psi_l at this cell
+        gl = xt + yt;
+        if (in && nl > 1) {
+          const size_t c = nat_idx(a.g, l, gj, gi);
+          if (l > 0) gl += (a.uniformS ? a.Su[l - 1] : a.S[c - a.g.ls]) * (pc - pm1[k]) * a.lc.idh0[l];
+          if (l < nl - 1) gl -= (a.uniformS ? a.Su[l] : a.S[c]) * (p1[1][1] - pc) * a.lc.idh1[l];
+        }
+      }
+      const double xl = a.iRe * zc + a.iRe4 * tc;
+      double tl = t + a.iRe4 * lapT + tc * a.iRe;
+      if (l == 0) tl -= a.cs * zc + (in ? a.wind[gj] : 0.);
+      if (l == nl - 1) tl -= a.cb * zc;
+      if (in && l > 0) ra = finalize_fast(l - 1, gj, tl_prev[k], xa0[k], xa1[k], xl, g_prev[k], qdma ? k0 / HALF : -1, kk);
+      if (in && l == nl - 1) rb = finalize_fast(l, gj, tl, xa1[k], xl, 0., gl, -1, 0);
+      tl_prev[k] = tl; xa0[k] = xa1[k]; xa1[k] = xl; jd_prev[k] = jd;
+#endif
+#ifdef MSOM_STRICT
       t_prev[k] = t; lapT_prev[k] = lapT; jd_prev[k] = jd;
       zc0[k] = zc1[k]; zc1[k] = zc; tc0[k] = tc1[k]; tc1[k] = tc;
+#endif
+      if (want_res) {
+#ifdef MSOM_STRICT
+        pm2[k] = pm1[k]; pm1[k] = pc; xt_prev[k] = xt; yt_prev[k] = yt;
+#else
+        pm1[k] = pc; g_prev[k] = gl;
+#endif
+        // restriction to level 1: mean of the 4 children in foreach_child order (rows k, k+1 of this
+        // thread are the y pair, lanes tx, tx+1 the x pair); every lane takes part in the shuffles
+        if (a.res_c) {
+          if ((kk & 1) == 0) { ra_even = ra; rb_even = rb; }
+          else {
+            const double oa0 = __shfl_down(ra_even, 1, 64), oa1 = __shfl_down(ra, 1, 64);
+            const double ob0 = __shfl_down(rb_even, 1, 64), ob1 = __shfl_down(rb, 1, 64);
+            if (in && !(tx & 1)) {
+              if (l > 0) {
+                double sum = 0.;
+                sum += ra_even; sum += ra; sum += oa0; sum += oa1;
+                a.res_c[split_idx(a.cg, l - 1, gj >> 1, gi >> 1)] = sum / 4;
+              }
+              if (l == nl - 1) {
+                double sum = 0.;
+                sum += rb_even; sum += rb; sum += ob0; sum += ob1;
+                a.res_c[split_idx(a.cg, l, gj >> 1, gi >> 1)] = sum / 4;
+              }
+            }
+          }
+        }
+      }
     }
   };
 
@@ -446,7 +594,6 @@ __global__ void __launch_bounds__(FNT, 2) k_rhs_fused_pipe(RhsArgs a) {
   fetch(0);
   stash(sP[0]);
   if (nl > 1) { fetch(1); stash(sP[1]); }
-  if (nl > 2) fetch(2);
   __syncthreads();
   lds_lap<ZW, ZH, 2, PW, 3, FNT>(sZ[0], sP[0], bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);
   __syncthreads();
@@ -456,32 +603,68 @@ __global__ void __launch_bounds__(FNT, 2) k_rhs_fused_pipe(RhsArgs a) {
     const double *P0 = sP[l % 3], *P1 = sP[(l + 1) % 3];
     const double *Z = sZ[l & 1], *T = sT[l & 1];
     const bool more = l + 1 < nl;
-    // psi_{l+2}: registers -> LDS (buffer of psi_{l-1}, free since the last barrier); start psi_{l+3}
-    if (l + 2 < nl) stash(sP[(l + 2) % 3]);
-    if (l + 3 < nl) fetch(l + 3);
-    // interval 1: zeta_{l+1} pass || first half of the centre rows of layer l
-    if (!late && more) lds_lap<ZW, ZH, 2, PW, 3, FNT>(sZ[(l + 1) & 1], P1, bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);
+    // the q_in rows of layer l-1 fetched during the previous interval have landed (own wave's DMA)
+    if (qdma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (qdma && l > 0) q_prefetch(l - 1, 1);  // second-half rows of layer l-1: finalised in interval 2
+    // interval 1: zeta_{l+1} pass || first half of the centre rows of layer l.  psi_{l+2} travels global ->
+    // registers -> LDS (buffer of psi_{l-1}, free since the last barrier) around the LDS pass, whose duration
+    // hides the load latency; the staging registers are dead during the register-hungry centre loop
+    if (!late) {
+      if (l + 2 < nl) fetch(l + 2);
+      if (more) lds_lap<ZW, ZH, 2, PW, 3, FNT>(sZ[(l + 1) & 1], P1, bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);
+      if (l + 2 < nl) stash(sP[(l + 2) % 3]);
+    }
     centre(l, 0, P0, P1, Z, T);
-    if (late && more) lds_lap<ZW, ZH, 2, PW, 3, FNT>(sZ[(l + 1) & 1], P1, bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);
+    if (late) {
+      if (l + 2 < nl) fetch(l + 2);
+      if (more) lds_lap<ZW, ZH, 2, PW, 3, FNT>(sZ[(l + 1) & 1], P1, bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);
+      if (l + 2 < nl) stash(sP[(l + 2) % 3]);
+    }
     __syncthreads();
+    if (qdma) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (more) q_prefetch(l, 0);  // first-half rows of layer l: finalised in interval 1 of the next iteration
+    }
     // interval 2: tmp_{l+1} pass || second half of the centre rows
     if (!late && more) lds_lap<TW, TH, 1, ZW, 2, FNT>(sT[(l + 1) & 1], sZ[(l + 1) & 1], bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);
     centre(l, HALF, P0, P1, Z, T);
     if (late && more) lds_lap<TW, TH, 1, ZW, 2, FNT>(sT[(l + 1) & 1], sZ[(l + 1) & 1], bc, x0, y0, nx, ny, a.walls, a.slip_c, D2, rD2);
     __syncthreads();
   }
+  if (want_res) {  // max|res| -> atomic max, sum of q_out -> one partial per workgroup (fixed order)
+    double *red = sT[0];  // free after the last barrier
+    const double wm = wave_max_f(res_m);
+    double ws = res_bs;
+    for (int o = 32; o > 0; o >>= 1) ws += __shfl_down(ws, o, 64);
+    if (lane == 0) { red[wv] = wm; red[NW + wv] = ws; }
+    __syncthreads();
+    if (tid == 0) {
+      double mm = red[0], ss = red[NW];
+      for (int k = 1; k < NW; k++) { mm = fmax(mm, red[k]); ss += red[NW + k]; }
+      atomicMax((unsigned long long *)a.res_max, (unsigned long long)__double_as_longlong(mm));
+      a.bsum_partial[blockIdx.y * gridDim.x + blockIdx.x] = ss;
+    }
+  }
 }
 
 int g_rhs_dbg = 0;
+int rhs_pipe_blocks(const NatGeom &g) { return ((g.nx + FTX - 1) / FTX) * ((g.ny + 31) / 32); }
 int rhs_fused_blocks(const NatGeom &g) { return ((g.nx + FTX - 1) / FTX) * ((g.ny + 7) / 8); }  // upper bound (smallest FTY)
 
 void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq,
                       double *umax_partial, double *umax_out, const NatGeom &g, int nl, int walls, int uniformS, const double *Su,
                       int have_qforc, double D, double beta, double iRe, double iRe4, double cs, double cb, double slip_c,
-                      const LayerCoef &lc, int variant, const double *q_in, double *q_out, double dt) {
+                      const LayerCoef &lc, int variant, const double *q_in, double *q_out, double dt, const RhsResid *rr) {
   RhsArgs a;
   extern int g_rhs_dbg;
   a.dbg = g_rhs_dbg;
+  a.res = a.res_c = a.res_max = a.bsum_partial = nullptr;
+  if (rr && variant == 1 && q_out) {
+    a.res = rr->res; a.res_c = rr->res_c; a.res_max = rr->res_max; a.bsum_partial = rr->bsum_partial; a.sg = rr->sg; a.cg = rr->cg;
+    (void)hipMemsetAsync(rr->res_max, 0, sizeof(double), st);
+  } else {
+    a.sg = SplitGeom(); a.cg = SplitGeom();
+  }
   a.q_in = q_in; a.q_out = q_out; a.dt = dt;
   a.psi = psi; a.S = S; a.qforc = qforc; a.wind = wind; a.dq = dq; a.umax_partial = umax_partial;
   a.g = g; a.nl = nl; a.walls = walls; a.uniformS = uniformS; a.have_qforc = have_qforc;

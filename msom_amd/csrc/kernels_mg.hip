@@ -862,6 +862,118 @@ __device__ __forceinline__ void relax_red_prolong_body(const RelaxPArgs &p) {
     for (int l = 0; l < NL; l++) split_write_ghosts(p.da, p.g, l, j, i, x[l], p.walls);
   }
 }
+// Both row parities in one thread: the red cells (2 kx, 2 J) and (2 kx + 1, 2 J + 1) interpolate their
+// neighbours from the SAME 3 x 3 coarse window around (kx, J), so the window is loaded once for two
+// cells (9 instead of 18 coarse loads per pair and layer).  Per-cell arithmetic as in
+// relax_red_prolong_body, hence identical results.
+template <int NL, bool UNIFORM, int PJ>
+struct RedCell {
+  int i, j;
+  size_t own;
+  bool valid, wl, el, sl, nl_, ow, oe, os, on;
+  double rhs[NL], t0[NL], t1[NL], t2[NL];
+  __device__ __forceinline__ void init(const RelaxPArgs &p, int kx, int J) {
+    i = 2 * kx + PJ; j = 2 * J + PJ;
+    valid = kx < p.g.hk && j < p.g.ny;
+    const int nx = p.g.nx, ny = p.g.ny;
+    own = split_idx(p.g, 0, valid ? j : 0, valid ? i : 0);
+    wl = i - 1 == 0 && (p.walls & WALL_W); el = i + 1 == nx - 1 && (p.walls & WALL_E);
+    sl = j - 1 == 0 && (p.walls & WALL_S); nl_ = j + 1 == ny - 1 && (p.walls & WALL_N);
+    ow = i == 0 && (p.walls & WALL_W); oe = i == nx - 1 && (p.walls & WALL_E);
+    os = j == 0 && (p.walls & WALL_S); on = j == ny - 1 && (p.walls & WALL_N);
+  }
+  __device__ __forceinline__ void layer(const RelaxPArgs &p, int l, const double (&c)[3][3]) {
+    if (!valid) return;
+    constexpr int pj = PJ, pi = PJ;
+    constexpr int wxn = pi ? 1 : 0, wxf = pi ? 0 : 1, exn = pi ? 2 : 1, exf = pi ? 1 : 2, cxf = pi ? 2 : 0, cyf = pj ? 2 : 0;
+    constexpr int syn = pj ? 1 : 0, syf = pj ? 0 : 1, nyn = pj ? 2 : 1, nyf = pj ? 1 : 2;
+    const size_t ls = p.g.ls;
+    const double sqD = p.rc.sqD;
+#define BIL(yn, yf, xn, xf) BILINEAR(c[yn][xn], c[yn][xf], c[yf][xn], c[yf][xf])
+    const double vo = (ow | oe | os | on) ? BIL(1, cyf, 1, cxf) : 0.;
+    const double vw = ow ? -vo : BIL(1, cyf, wxn, wxf);
+    const double ve = oe ? -vo : BIL(1, cyf, exn, exf);
+    const double vs = os ? -vo : BIL(syn, syf, 1, cxf);
+    const double vn = on ? -vo : BIL(nyn, nyf, 1, cxf);
+#undef BIL
+    if (wl) p.da[split_idx(p.g, l, j, -1)] = -vw;
+    if (el) p.da[split_idx(p.g, l, j, p.g.nx)] = -ve;
+    if (sl) p.da[split_idx(p.g, l, -1, i)] = -vs;
+    if (nl_) p.da[split_idx(p.g, l, p.g.ny, i)] = -vn;
+    rhs[l] = -sqD * p.res[own + l * ls];
+    if (NL > 1 && !UNIFORM) {
+      t0[l] = l > 0 ? -sqD * p.S[own + (l - 1) * ls] * p.rc.idh0[l] : 0.;
+      t2[l] = l < NL - 1 ? -sqD * p.S[own + l * ls] * p.rc.idh1[l] : 0.;
+      t1[l] = l == 0 ? -t2[l] : (l < NL - 1 ? -t0[l] - t2[l] : -t0[l]);
+      rhs[l] += 1. * ve + 1. * vw;
+      t1[l] += 1. + 1.;
+      rhs[l] += 1. * vn + 1. * vs;
+      t1[l] += 1. + 1.;
+    } else {
+      rhs[l] += ve + vw;
+      rhs[l] += vn + vs;
+    }
+  }
+  __device__ __forceinline__ void finish(const RelaxPArgs &p) {
+    if (!valid) return;
+    const size_t ls = p.g.ls;
+    double x[NL];
+    if (NL == 1) {
+      double d = 0.;
+      d += 2.; d += 2.;
+      x[0] = rhs[0] / d;
+    } else if (UNIFORM) {
+#pragma unroll
+      for (int l = 1; l < NL; l++) rhs[l] -= p.rc.w[l] * rhs[l - 1];
+      x[NL - 1] = rhs[NL - 1] * p.rc.it1[NL - 1];
+#pragma unroll
+      for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - p.rc.t2[l] * x[l + 1]) * p.rc.it1[l];
+    } else {
+#pragma unroll
+      for (int l = 1; l < NL; l++) {
+        t1[l] -= t0[l] * t2[l - 1] / t1[l - 1];
+        rhs[l] -= t0[l] * rhs[l - 1] / t1[l - 1];
+      }
+      x[NL - 1] = rhs[NL - 1] / t1[NL - 1];
+#pragma unroll
+      for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - t2[l] * x[l + 1]) / t1[l];
+    }
+#pragma unroll
+    for (int l = 0; l < NL; l++) p.da[own + l * ls] = x[l];
+    if ((ow | oe | os | on) || ((p.walls & WALL_PER) && (i == 0 || i == p.g.nx - 1 || j == 0 || j == p.g.ny - 1))) {
+#pragma unroll
+      for (int l = 0; l < NL; l++) split_write_ghosts(p.da, p.g, l, j, i, x[l], p.walls);
+    }
+  }
+};
+template <int NL, bool UNIFORM>
+__global__ void __launch_bounds__(BX *BY) k_relax_red_prolong2(RelaxPArgs p) {
+  const int kx = blockIdx.x * BX + threadIdx.x, J = blockIdx.y * BY + threadIdx.y;
+  if (kx >= p.g.hk || 2 * J >= p.g.ny) return;
+  RedCell<NL, UNIFORM, 0> c0;
+  RedCell<NL, UNIFORM, 1> c1;
+  c0.init(p, kx, J);
+  c1.init(p, kx, J);
+  size_t cw[3][3];
+#pragma unroll
+  for (int dj = -1; dj <= 1; dj++)
+#pragma unroll
+    for (int di = -1; di <= 1; di++) cw[dj + 1][di + 1] = split_idx(p.cg, 0, J + dj, kx + di);
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    const double *cc = p.coarse + (size_t)l * p.cg.ls;
+    double c[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) c[a][b] = cc[cw[a][b]];
+    c0.layer(p, l, c);
+    c1.layer(p, l, c);
+  }
+  c0.finish(p);
+  c1.finish(p);
+}
+
 template <int NL, bool UNIFORM>
 __global__ void __launch_bounds__(BX *BY) k_relax_red_prolong(RelaxPArgs p) {
   if (blockIdx.z == 0) relax_red_prolong_body<NL, UNIFORM, 0>(p);
@@ -870,6 +982,12 @@ __global__ void __launch_bounds__(BX *BY) k_relax_red_prolong(RelaxPArgs p) {
 template <int NL>
 static void relax_red_prolong_dispatch(hipStream_t st, const RelaxPArgs &p, int uniformS) {
   dim3 gr = grid2d(p.g.hk, (p.g.ny + 1) / 2);
+  extern int g_rhs_dbg;
+  if (!(g_rhs_dbg & 256)) {  // both row parities per thread
+    if (uniformS) hipLaunchKernelGGL((k_relax_red_prolong2<NL, true>), gr, block2d(), 0, st, p);
+    else hipLaunchKernelGGL((k_relax_red_prolong2<NL, false>), gr, block2d(), 0, st, p);
+    return;
+  }
   gr.z = 2;
   if (uniformS) hipLaunchKernelGGL((k_relax_red_prolong<NL, true>), gr, block2d(), 0, st, p);
   else hipLaunchKernelGGL((k_relax_red_prolong<NL, false>), gr, block2d(), 0, st, p);

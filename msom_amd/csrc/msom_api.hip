@@ -33,7 +33,7 @@
 
 // device scalar slots
 // RES0, RES1 and UMAX[nl] are contiguous: one max all-reduce / one copy brings them to the host
-enum { SC_BSUM = 2, SC_KE = 3, SC_SCRATCH = 4, SC_RES0 = 6, SC_RES1 = 7, SC_UMAX = 8 /* MAXNL */, SC_LSUM = 32 /* MAXNL */, SC_COUNT = 64 };
+enum { SC_BSUM = 2, SC_KE = 3, SC_SCRATCH = 4, SC_RES0 = 6, SC_RES1 = 7, SC_UMAX = 8 /* MAXNL */, SC_RESF = 16 /* max|res| from the fused tendency pass */, SC_LSUM = 32 /* MAXNL */, SC_COUNT = 64 };
 
 struct ProfSlot {
   std::vector<hipEvent_t> ev;  // pairs (start, stop)
@@ -78,6 +78,7 @@ struct msom {
   // scratch
   double *staging = nullptr;   // contiguous nl*ny*nx
   double *partial = nullptr;   // per-block partial sums
+  double *partial_rr = nullptr;  // per-workgroup sums of q_out from the fused tendency pass (consumed by the next mg_solve)
   double *partial_umax = nullptr;  // per-block partial maxima of k_umax
   double *d_scal = nullptr, *h_scal = nullptr;
   double *d_wind = nullptr;    // per-row surface forcing profile
@@ -99,6 +100,9 @@ struct msom {
   // wavelet scale filter (msqg/qg.h:509-560): pyramids s (restricted psi), r (filtered), sig_lev
   int wv_nlev = 0, wv_ready = 0;
   int nme_ft = 0;  // msqg/qg_energy.h:17
+  int res_ready = -1;  // field id whose first multigrid residual (levels 0, 1; SC_RESF; partial sums) the last tendency pass already produced
+  int adv_fused = 1;   // fold q_out = q_in + dt dq into the tendency pass
+  int rhs_resid = 1;   // let the fused tendency + advance pass produce it
   int s_zero = 0;  // pystep_de(onlyKE = 1) zeroed the stretching field S (msqg/qg_energy.h:319-325); undone by msom_set_const
   std::vector<NatGeom> wv_g;
   std::vector<double *> wv_s, wv_r, wv_sig;
@@ -321,6 +325,7 @@ static int alloc_all(msom *m) {
   HIPCHK(hipMemsetAsync(m->psi_alt, 0, m->g.ls * m->nl * sizeof(double), m->st));
   HIPCHK(hipMalloc(&m->staging, (size_t)m->nl * (m->p.nptr > 1 ? m->p.nptr : 1) * m->nx * m->ny * sizeof(double)));
   HIPCHK(hipMalloc(&m->partial, ((size_t)partial_count(m->g) * m->nl + 64) * sizeof(double)));  // + chunk sums of launch_sum_final
+  HIPCHK(hipMalloc(&m->partial_rr, ((size_t)rhs_pipe_blocks(m->g) + 64) * sizeof(double)));
   {
     size_t nb = (size_t)rhs_fused_blocks(m->g);
     if (nb < 2048) nb = 2048;
@@ -474,6 +479,7 @@ extern "C" int msom_destroy(msom_t *m) {
   if (m->psi_alt) hipFree(m->psi_alt);
   if (m->staging) hipFree(m->staging);
   if (m->partial) hipFree(m->partial);
+  if (m->partial_rr) hipFree(m->partial_rr);
   if (m->partial_umax) hipFree(m->partial_umax);
   if (m->d_scal) hipFree(m->d_scal);
   if (m->h_scal) hipHostFree(m->h_scal);
@@ -512,6 +518,8 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "block_variant")) { extern int g_block_variant; g_block_variant = (int)v; }
   else if (!strcmp(key, "rhs_dbg")) { extern int g_rhs_dbg; g_rhs_dbg = (int)v; }
   else if (!strcmp(key, "rhs_variant")) m->rhs_variant = (int)v;
+  else if (!strcmp(key, "adv_fused")) m->adv_fused = (int)v;
+  else if (!strcmp(key, "rhs_resid")) { m->rhs_resid = (int)v; m->res_ready = -1; }
   else if (!strcmp(key, "seed")) { m->seed = (unsigned)v; srand(m->seed); }
   else if (!strcmp(key, "noise_mode")) m->noise_mode = (int)v;
   else if (!strcmp(key, "stochastic")) {
@@ -587,6 +595,7 @@ static int fill_bc(msom *m, int field) {
 
 // host or device pointer -> natural field (+ boundary())
 static int upload(msom *m, int field, const double *a) {
+  m->res_ready = -1;
   const size_t n = (size_t)m->flayers[field] * m->nx * m->ny;
   HIPCHK(hipMemcpyAsync(m->staging, a, n * sizeof(double), hipMemcpyDefault, m->st));
   launch_pack(m->st, m->staging, m->f[field], m->g, m->flayers[field]);
@@ -634,6 +643,7 @@ extern "C" int msom_remove_mean(msom_t *m, int field) {
     int r = reduce_scal(m, SC_LSUM, nl, RED_SUM);
     if (r) return r;
   }
+  m->res_ready = -1;
   launch_sub_layer_const(m->st, m->f[field], m->d_scal + SC_LSUM, m->g, nl, 1. / ((double)m->gnx * m->gny));
   fill_bc(m, field);
   return sync_stream(m);
@@ -960,7 +970,12 @@ static int mg_solve(msom *m, const double *b, msom_mgstats *s) {
   s->i = 0; s->nrelax = 4;
   HIPCHK(hipMemsetAsync(m->d_scal, 0, 8 * sizeof(double), m->st));
   m->umax_ready = 0;
-  if (fused) {
+  const bool have_res = fused && m->res_ready >= 0 && b == m->f[m->res_ready];
+  m->res_ready = -1;
+  if (have_res) {  // res[0], res[1], max|res| and the partial sums of b came out of the tendency pass
+    HIPCHK(hipMemcpyAsync(m->d_scal + SC_RES0, m->d_scal + SC_RESF, sizeof(double), hipMemcpyDeviceToDevice, m->st));
+    launch_sum_final(m->st, m->partial_rr, m->d_scal + SC_BSUM, rhs_pipe_blocks(m->g));
+  } else if (fused) {
     residual2(m, 2 | 4, b, SC_RES0, 1);
     launch_sum_final(m->st, m->partial, m->d_scal + SC_BSUM, residual2_blocks(m->g));
   } else {
@@ -1062,12 +1077,21 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
     // tiles: the fused kernel needs psi on a 3-cell halo (zeta on 2, lap(zeta) on 1)
     if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], nl, m->bc, 3));
     if (m->bc == BC_PERIODIC) launch_fill_periodic(m->st, m->f[MSOM_PSI], m->g, nl, 3);
+    if (!m->adv_fused) adv_out = -1;
+    // the advance rides along: the pass can also emit the first residual of the inversion of q[adv_out]
+    const bool use_rr = adv_out >= 0 && m->rhs_resid && m->rhs_variant == 1 && m->mg_fused && m->nlev > 1 && m->bc != BC_PERIODIC;
+    RhsResid rr;
+    if (use_rr) {
+      rr.res = m->res[0]; rr.res_c = m->res[1]; rr.res_max = m->d_scal + SC_RESF; rr.bsum_partial = m->partial_rr;
+      rr.sg = m->sg[0]; rr.cg = m->sg[1];
+    }
     // one pass over psi: zeta, Jacobians, beta, dissipation, drag, forcing, max|u| (kernels_fused.hip)
     launch_rhs_fused(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, m->f[dqfield], nullptr,
                      nullptr, m->g, nl, m->walls & WALL_ALL, m->uniformS, m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe,
                      iRe4, Eks / (p.Rom * 2 * m->dhf[0]), Ekb / (p.Rom * 2 * m->dhf[nl - 1]),
                      p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, m->rhs_variant, adv_out >= 0 ? m->f[adv_in] : nullptr,
-                     adv_out >= 0 ? m->f[adv_out] : nullptr, adv_dt);
+                     adv_out >= 0 ? m->f[adv_out] : nullptr, adv_dt, use_rr ? &rr : nullptr);
+    if (use_rr) m->res_ready = adv_out;
     if (advanced && adv_out >= 0) *advanced = 1;
     return MSOM_OK;
   }
@@ -1140,6 +1164,7 @@ static int generate_noise_host(msom *m) {
 
 // advance_qg, msqg/qg.h:594-606 / msqg/qg_stochastic.h:128-149
 static int advance_qg(msom *m, int out, int in, int dq, double dt) {
+  m->res_ready = -1;
   const double *noise = nullptr;
   double dts = 0;
   if (m->stochastic) {
@@ -1445,6 +1470,7 @@ static void wv_fill(msom *m, double *f, const NatGeom &g) {
 }
 // field <- inverse_wavelet(sig_lev * wavelet(field)), all layers (msqg/qg.h:524-539)
 static int wavelet_apply(msom *m, double *f) {
+  m->res_ready = -1;
   int r = wavelet_setup(m);
   if (r) return r;
   const int K = m->wv_nlev, nl = m->nl;
@@ -1877,6 +1903,7 @@ static int split_download(msom *m, const double *sp, const SplitGeom &sg, double
 }
 // nsweeps red-black relaxations on level `lev`: da in/out, res in (both [layer][y][x] of that level)
 extern "C" int msom_dbg_relax(msom_t *m, int lev, double *da, const double *res, int nsweeps) {
+  if (m) m->res_ready = -1;
   NEED_CONST(m);
   if (lev < 0 || lev >= m->nlev || !da || !res) return MSOM_ERR_ARG;
   int r;
@@ -1893,6 +1920,7 @@ extern "C" int msom_dbg_relax(msom_t *m, int lev, double *da, const double *res,
   return split_download(m, m->da[lev], m->sg[lev], da, m->nl);
 }
 extern "C" int msom_dbg_residual(msom_t *m, const double *a, const double *b, double *res, double *maxres) {
+  if (m) m->res_ready = -1;
   NEED_CONST(m);
   int r;
   if ((r = upload(m, MSOM_TMP, a))) return r;
@@ -1905,6 +1933,7 @@ extern "C" int msom_dbg_residual(msom_t *m, const double *a, const double *b, do
   return MSOM_OK;
 }
 extern "C" int msom_dbg_restrict(msom_t *m, int lev_fine, const double *fine, double *coarse) {
+  if (m) m->res_ready = -1;
   NEED_CONST(m);
   if (lev_fine < 0 || lev_fine + 1 >= m->nlev) return MSOM_ERR_ARG;
   int r;
@@ -1913,6 +1942,7 @@ extern "C" int msom_dbg_restrict(msom_t *m, int lev_fine, const double *fine, do
   return split_download(m, m->res[lev_fine + 1], m->sg[lev_fine + 1], coarse, m->nl);
 }
 extern "C" int msom_dbg_prolong(msom_t *m, int lev_coarse, const double *coarse, double *fine) {
+  if (m) m->res_ready = -1;
   NEED_CONST(m);
   if (lev_coarse < 1 || lev_coarse >= m->nlev) return MSOM_ERR_ARG;
   int r;
@@ -1923,6 +1953,7 @@ extern "C" int msom_dbg_prolong(msom_t *m, int lev_coarse, const double *coarse,
 }
 // single operators on the internal fields: "del2", "stretch", "advection", "dissip", "forcing"
 extern "C" int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, double add, double fac) {
+  if (m) m->res_ready = -1;
   NEED_CONST(m);
   if (check_field(m, f_in) || check_field(m, f_out) || !op) return MSOM_ERR_ARG;
   const Params &p = m->p;
@@ -1957,6 +1988,7 @@ extern "C" int msom_profile_read(msom_t *m, const char *kernel, double *avg_ms, 
 }
 // back-to-back launches of one kernel on the finest level, HIP-event timed
 extern "C" int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double *avg_ms) {
+  if (m) m->res_ready = -1;
   NEED_CONST(m);
   if (!kernel || reps < 1 || !avg_ms) return MSOM_ERR_ARG;
   hipEvent_t a, b;
@@ -1983,6 +2015,9 @@ extern "C" int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double
       residual2(m, 2 | 4, m->f[MSOM_Q], SC_RES1, 1);
     } else if (!strcmp(kernel, "red_prolong")) {
       launch_relax_red_prolong(m->st, m->da[0], m->da[1], m->sg[1], m->res[0], m->S[0], m->sg[0], m->nl, m->rc[0], m->uniformS, m->walls);
+    } else if (!strcmp(kernel, "rhs_adv")) {
+      int adv = 0;
+      rhs_terms(m, MSOM_Q, MSOM_DQ, 1, m->p.iRe, m->p.iRe4, m->p.Eks, m->p.Ekb, MSOM_QPRED, MSOM_Q, 1e-9, &adv);
     } else if (!strcmp(kernel, "advance")) {
       launch_advance(m->st, m->f[MSOM_QPRED], m->f[MSOM_Q], m->f[MSOM_DQ], nullptr, m->g, m->nl, 1e-9, 0.);
     }
