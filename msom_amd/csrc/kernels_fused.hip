@@ -50,6 +50,13 @@ struct RhsArgs {
   SplitGeom sg, cg;
 };
 
+// value of lane + 1 (valid in even lanes): DPP row_shl:1, two 32-bit moves, no LDS crossbar traffic
+__device__ __forceinline__ double lane_next(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x101, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x101, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_max_f(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
   return v;
@@ -325,7 +332,7 @@ __global__ void k_max_final2(const double *partial, double *out, int nb, int nl)
 // zeta / tmp tiles, three psi buffers), and the two waves that share a SIMD take the two jobs
 // in opposite order (waves 0-3: pass first, waves 4-7: centre first), so a SIMD always has one
 // wave waiting on LDS and one issuing fp64 work.  2 barriers per layer instead of 4.
-template <int FTY, int FNT>
+template <int FTY, int FNT, bool RES>
 __global__ void __launch_bounds__(FNT, 2) k_rhs_fused_pipe(RhsArgs a) {
   constexpr int RPT = FTX * FTY / FNT, HALF = RPT / 2;
   constexpr int PH = FTY + 6, ZH = FTY + 4, TH = FTY + 2;
@@ -359,7 +366,7 @@ __global__ void __launch_bounds__(FNT, 2) k_rhs_fused_pipe(RhsArgs a) {
   for (int k = 0; k < RPT; k++) tl_prev[k] = xa0[k] = xa1[k] = jd_prev[k] = 0.;
 #endif
   // residual by-product: psi_{l-1}, psi_{l-2} at the cell and the two horizontal flux terms of layer l-1
-  const bool want_res = a.res != nullptr;
+  constexpr bool want_res = RES;  // compile-time: the by-product's carried values cost registers only where it is produced
 #ifdef MSOM_STRICT
   // reference order ((q + A) - B) + x) + y: the four pieces are carried separately
   double pm1[RPT], pm2[RPT], xt_prev[RPT], yt_prev[RPT];
@@ -568,8 +575,8 @@ __global__ void __launch_bounds__(FNT, 2) k_rhs_fused_pipe(RhsArgs a) {
         if (a.res_c) {
           if ((kk & 1) == 0) { ra_even = ra; rb_even = rb; }
           else {
-            const double oa0 = __shfl_down(ra_even, 1, 64), oa1 = __shfl_down(ra, 1, 64);
-            const double ob0 = __shfl_down(rb_even, 1, 64), ob1 = __shfl_down(rb, 1, 64);
+            const double oa0 = lane_next(ra_even), oa1 = lane_next(ra);
+            const double ob0 = lane_next(rb_even), ob1 = lane_next(rb);
             if (in && !(tx & 1)) {
               if (l > 0) {
                 double sum = 0.;
@@ -673,7 +680,10 @@ void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const 
   int fty = (variant == 2 || variant == 4) ? 16 : (variant == 3 || variant == 5) ? 8 : 32;
   dim3 gr((g.nx + FTX - 1) / FTX, (g.ny + fty - 1) / fty);
   switch (variant) {
-    case 1: hipLaunchKernelGGL((k_rhs_fused_pipe<32, 512>), gr, dim3(512), 0, st, a); break;
+    case 1:
+      if (a.res) hipLaunchKernelGGL((k_rhs_fused_pipe<32, 512, true>), gr, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((k_rhs_fused_pipe<32, 512, false>), gr, dim3(512), 0, st, a);
+      break;
     case 2: hipLaunchKernelGGL((k_rhs_fused<16, 512, 2>), gr, dim3(512), 0, st, a); break;
     case 3: hipLaunchKernelGGL((k_rhs_fused<8, 256, 2>), gr, dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL((k_rhs_fused<16, 512, 4>), gr, dim3(512), 0, st, a); break;

@@ -102,7 +102,7 @@ struct msom {
   int nme_ft = 0;  // msqg/qg_energy.h:17
   int res_ready = -1;  // field id whose first multigrid residual (levels 0, 1; SC_RESF; partial sums) the last tendency pass already produced
   int adv_fused = 1;   // fold q_out = q_in + dt dq into the tendency pass
-  int rhs_resid = 1;   // let the fused tendency + advance pass produce it
+  int rhs_resid = 0;   // let the fused tendency + advance pass produce it: measured slower (23 spilled VGPRs in the 256-VGPR kernel: 2.21 ms vs 1.63 + 0.50 ms), kept as an option
   int s_zero = 0;  // pystep_de(onlyKE = 1) zeroed the stretching field S (msqg/qg_energy.h:319-325); undone by msom_set_const
   std::vector<NatGeom> wv_g;
   std::vector<double *> wv_s, wv_r, wv_sig;

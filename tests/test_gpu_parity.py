@@ -418,7 +418,7 @@ def test_lds_correct_residual_equals_plain(nx, ny, nl, extra, strict):
     for dbg in (0, 128 + 256):      # 256: one-parity-per-thread form of the fused red half-sweep + prolongation
         g = QG(txt, strict=strict)
         g.option("quiet", 1); g.option("rhs_dbg", dbg); g.option("TOLERANCE", 1e-7)
-        g.option("rhs_resid", 0 if dbg else 1)        # first residual of a solve: from the tendency pass / from k_residual2
+        g.option("rhs_resid", 0 if dbg else 1)        # first residual of a solve: from the tendency pass (option) / from k_residual2
         g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx))
         g.set_const()
         dts = [g.step() for _ in range(3)]
