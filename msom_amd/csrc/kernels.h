@@ -82,6 +82,13 @@ void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const 
 int rhs_pipe_blocks(const NatGeom &g);
 
 // ---- kernels_mg.hip
+// coarse part of the multigrid cycle in one launch (k_mg_coarse): lev[0] = finest of the group
+#define MGC_MAXLEV 8
+#define MGC_MAXDIM 64
+#define MGC_NT 512
+struct CoarseLev { double *da, *res; const double *S; SplitGeom g; RelaxCoef rc; };
+struct CoarseArgs { CoarseLev lev[MGC_MAXLEV]; int n, walls, prolong_fused; };
+void launch_mg_coarse(hipStream_t st, const CoarseArgs *d_args, int nrelax, int nl, int uniformS);
 void launch_nat_to_split(hipStream_t st, const double *nat, const NatGeom &g, double *sp, const SplitGeom &sg, int nl);
 void launch_split_to_nat(hipStream_t st, const double *sp, const SplitGeom &sg, double *nat, const NatGeom &g, int nl);
 void launch_split_pack(hipStream_t st, const double *src, double *sp, const SplitGeom &sg, int nl, int bc, int walls);

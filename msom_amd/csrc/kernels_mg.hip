@@ -559,9 +559,7 @@ void launch_residual2(hipStream_t st, int mode, const double *a, const double *d
 // ------------------------------------------------------------------ K10 restriction, K11 prolongation
 
 // coarse = mean of the 4 children, summed in Basilisk's foreach_child order
-__global__ void k_restrict(const double *__restrict__ fine, SplitGeom fg, double *coarse, SplitGeom cg, int nl) {
-  const int I = blockIdx.x * BX + threadIdx.x, J = blockIdx.y * BY + threadIdx.y;
-  if (I >= cg.nx || J >= cg.ny) return;
+__device__ __forceinline__ void restrict_pt(const double *__restrict__ fine, const SplitGeom &fg, double *coarse, const SplitGeom &cg, int nl, int I, int J) {
   for (int l = 0; l < nl; l++) {
     double sum = 0.;
     sum += fine[split_idx(fg, l, 2 * J, 2 * I)];
@@ -571,15 +569,18 @@ __global__ void k_restrict(const double *__restrict__ fine, SplitGeom fg, double
     coarse[split_idx(cg, l, J, I)] = sum / 4;
   }
 }
+__global__ void k_restrict(const double *__restrict__ fine, SplitGeom fg, double *coarse, SplitGeom cg, int nl) {
+  const int I = blockIdx.x * BX + threadIdx.x, J = blockIdx.y * BY + threadIdx.y;
+  if (I >= cg.nx || J >= cg.ny) return;
+  restrict_pt(fine, fg, coarse, cg, nl, I, J);
+}
 void launch_restrict(hipStream_t st, const double *fine, const SplitGeom &fg, double *coarse, const SplitGeom &cg, int nl) {
   hipLaunchKernelGGL(k_restrict, grid2d(cg.nx, cg.ny), block2d(), 0, st, fine, fg, coarse, cg, nl);
 }
 
 // bilinear: (9 c + 3 (c[child.x] + c[0,child.y]) + c[child.x,child.y]) / 16, then
 // boundary_level(da) on the fine level (ghosts written by the wall threads)
-__global__ void k_prolong(const double *__restrict__ coarse, SplitGeom cg, double *fine, SplitGeom fg, int nl, int walls) {
-  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
-  if (i >= fg.nx || j >= fg.ny) return;
+__device__ __forceinline__ void prolong_pt(const double *__restrict__ coarse, const SplitGeom &cg, double *fine, const SplitGeom &fg, int nl, int walls, int i, int j) {
   const int I = i >> 1, J = j >> 1, cx = (i & 1) ? 1 : -1, cy = (j & 1) ? 1 : -1;
   for (int l = 0; l < nl; l++) {
     const double v = BILINEAR(coarse[split_idx(cg, l, J, I)], coarse[split_idx(cg, l, J, I + cx)], coarse[split_idx(cg, l, J + cy, I)],
@@ -587,6 +588,11 @@ __global__ void k_prolong(const double *__restrict__ coarse, SplitGeom cg, doubl
     fine[split_idx(fg, l, j, i)] = v;
     split_write_ghosts(fine, fg, l, j, i, v, walls);
   }
+}
+__global__ void k_prolong(const double *__restrict__ coarse, SplitGeom cg, double *fine, SplitGeom fg, int nl, int walls) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= fg.nx || j >= fg.ny) return;
+  prolong_pt(coarse, cg, fine, fg, nl, walls, i, j);
 }
 void launch_prolong(hipStream_t st, const double *coarse, const SplitGeom &cg, double *fine, const SplitGeom &fg, int nl, int walls) {
   hipLaunchKernelGGL(k_prolong, grid2d(fg.nx, fg.ny), block2d(), 0, st, coarse, cg, fine, fg, nl, walls);
@@ -605,10 +611,16 @@ struct RelaxArgs {
 // FINE tags the instantiation launched on the finest level (level 0): a distinct kernel
 // symbol, so that profiler statistics of the HBM-bound fine sweep are not averaged with the
 // launch-latency-bound coarse levels.
+template <int NL, bool UNIFORM>
+__device__ __forceinline__ void relax_color_pt(const RelaxArgs &p, int kx, int j);
 template <int NL, bool UNIFORM, bool FINE>
 __global__ void __launch_bounds__(BX *BY) k_relax_color(RelaxArgs p) {
   const int kx = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
   if (kx >= p.g.hk || j >= p.g.ny) return;
+  relax_color_pt<NL, UNIFORM>(p, kx, j);
+}
+template <int NL, bool UNIFORM>
+__device__ __forceinline__ void relax_color_pt(const RelaxArgs &p, int kx, int j) {
   const int px = (j + p.color) & 1;  // x parity of this colour's points in row j
   const int i = 2 * kx + px;
   const int hp = p.g.hp, rp = p.g.rp;
@@ -947,9 +959,15 @@ struct RedCell {
   }
 };
 template <int NL, bool UNIFORM>
+__device__ __forceinline__ void red_prolong2_pt(const RelaxPArgs &p, int kx, int J);
+template <int NL, bool UNIFORM>
 __global__ void __launch_bounds__(BX *BY) k_relax_red_prolong2(RelaxPArgs p) {
   const int kx = blockIdx.x * BX + threadIdx.x, J = blockIdx.y * BY + threadIdx.y;
   if (kx >= p.g.hk || 2 * J >= p.g.ny) return;
+  red_prolong2_pt<NL, UNIFORM>(p, kx, J);
+}
+template <int NL, bool UNIFORM>
+__device__ __forceinline__ void red_prolong2_pt(const RelaxPArgs &p, int kx, int J) {
   RedCell<NL, UNIFORM, 0> c0;
   RedCell<NL, UNIFORM, 1> c1;
   c0.init(p, kx, J);
@@ -973,6 +991,69 @@ __global__ void __launch_bounds__(BX *BY) k_relax_red_prolong2(RelaxPArgs p) {
   c0.finish(p);
   c1.finish(p);
 }
+
+// ------------------------------------------------------------------ coarse levels in ONE launch
+// Levels of at most MGC_MAXDIM x MGC_MAXDIM cells are launch-latency bound (a colour half-sweep of a 32^2
+// level takes ~1 us of work and ~4.5 us of launch): one 512-thread workgroup (256 VGPRs per wave: the fused prolongation needs ~150) runs the whole coarse part
+// of the cycle -- restrictions down, zero first guess on the coarsest level, nrelax red-black sweeps per
+// level, prolongation folded into the first red half-sweep on the way up -- with __syncthreads() where
+// the separate launches had kernel boundaries.  The per-point device functions are the ones of the
+// stand-alone kernels, so the arithmetic is identical.
+template <int NL, bool UNIFORM>
+__global__ void __launch_bounds__(MGC_NT) k_mg_coarse(const CoarseArgs *pa, int nrelax) {
+  const CoarseArgs &a = *pa;
+  const int tid = threadIdx.x, n = a.n;
+  for (int k = 1; k < n; k++) {  // restriction of the residual, level by level
+    const CoarseLev &F = a.lev[k - 1], &C = a.lev[k];
+    for (int t = tid; t < C.g.nx * C.g.ny; t += MGC_NT) restrict_pt(F.res, F.g, C.res, C.g, NL, t % C.g.nx, t / C.g.nx);
+    __syncthreads();
+  }
+  for (int k = n - 1; k >= 0; k--) {
+    const CoarseLev &L = a.lev[k];
+    bool fused = false;
+    if (k == n - 1) {  // first guess 0 (ghosts included)
+      for (size_t t = tid; t < L.g.ls * NL; t += MGC_NT) L.da[t] = 0.;
+    } else if (a.prolong_fused && nrelax >= 1 && L.g.nx >= 4 && L.g.ny >= 4) fused = true;
+    else {
+      const CoarseLev &C = a.lev[k + 1];
+      for (int t = tid; t < L.g.nx * L.g.ny; t += MGC_NT) prolong_pt(C.da, C.g, L.da, L.g, NL, a.walls, t % L.g.nx, t / L.g.nx);
+    }
+    __syncthreads();
+    for (int it = 0; it < nrelax; it++)
+      for (int c = 0; c < 2; c++) {
+        if (fused && it == 0 && c == 0) {
+          RelaxPArgs p;
+          p.da = L.da; p.res = L.res; p.S = L.S; p.coarse = a.lev[k + 1].da; p.g = L.g; p.cg = a.lev[k + 1].g; p.walls = a.walls; p.rc = L.rc;
+          const int nj = (L.g.ny + 1) / 2;
+          for (int t = tid; t < L.g.hk * nj; t += MGC_NT) red_prolong2_pt<NL, UNIFORM>(p, t % L.g.hk, t / L.g.hk);
+        } else {
+          RelaxArgs p;
+          p.da = L.da; p.res = L.res; p.S = L.S; p.g = L.g; p.color = c; p.walls = a.walls; p.rc = L.rc;
+          for (int t = tid; t < L.g.hk * L.g.ny; t += MGC_NT) relax_color_pt<NL, UNIFORM>(p, t % L.g.hk, t / L.g.hk);
+        }
+        __syncthreads();
+      }
+  }
+}
+template <int NL>
+static void mg_coarse_dispatch(hipStream_t st, const CoarseArgs *d_args, int nrelax, int uniformS) {
+  if (uniformS) hipLaunchKernelGGL((k_mg_coarse<NL, true>), dim3(1), dim3(MGC_NT), 0, st, d_args, nrelax);
+  else hipLaunchKernelGGL((k_mg_coarse<NL, false>), dim3(1), dim3(MGC_NT), 0, st, d_args, nrelax);
+}
+void launch_mg_coarse(hipStream_t st, const CoarseArgs *d_args, int nrelax, int nl, int uniformS) {
+  switch (nl) {
+    case 1: mg_coarse_dispatch<1>(st, d_args, nrelax, uniformS); break;
+    case 2: mg_coarse_dispatch<2>(st, d_args, nrelax, uniformS); break;
+    case 3: mg_coarse_dispatch<3>(st, d_args, nrelax, uniformS); break;
+    case 4: mg_coarse_dispatch<4>(st, d_args, nrelax, uniformS); break;
+    case 5: mg_coarse_dispatch<5>(st, d_args, nrelax, uniformS); break;
+    case 6: mg_coarse_dispatch<6>(st, d_args, nrelax, uniformS); break;
+    case 7: mg_coarse_dispatch<7>(st, d_args, nrelax, uniformS); break;
+    case 8: mg_coarse_dispatch<8>(st, d_args, nrelax, uniformS); break;
+    default: break;
+  }
+}
+
 
 template <int NL, bool UNIFORM>
 __global__ void __launch_bounds__(BX *BY) k_relax_red_prolong(RelaxPArgs p) {

@@ -100,6 +100,9 @@ struct msom {
   // wavelet scale filter (msqg/qg.h:509-560): pyramids s (restricted psi), r (filtered), sig_lev
   int wv_nlev = 0, wv_ready = 0;
   int nme_ft = 0;  // msqg/qg_energy.h:17
+  // coarse levels (<= MGC_MAXDIM cells a side) solved by ONE launch (k_mg_coarse)
+  CoarseArgs *d_cargs = nullptr;
+  int mgc_first = -1, mgc_opt = 0;  // first (finest) level of the group, -1: none; option "mg_coarse" (measured: no faster than the ~45 tiny launches it replaces)
   int res_ready = -1;  // field id whose first multigrid residual (levels 0, 1; SC_RESF; partial sums) the last tendency pass already produced
   int adv_fused = 1;   // fold q_out = q_in + dt dq into the tendency pass
   int rhs_resid = 0;   // let the fused tendency + advance pass produce it: measured slower (23 spilled VGPRs in the 256-VGPR kernel: 2.21 ms vs 1.63 + 0.50 ms), kept as an option
@@ -480,6 +483,7 @@ extern "C" int msom_destroy(msom_t *m) {
   if (m->staging) hipFree(m->staging);
   if (m->partial) hipFree(m->partial);
   if (m->partial_rr) hipFree(m->partial_rr);
+  if (m->d_cargs) hipFree(m->d_cargs);
   if (m->partial_umax) hipFree(m->partial_umax);
   if (m->d_scal) hipFree(m->d_scal);
   if (m->h_scal) hipHostFree(m->h_scal);
@@ -510,11 +514,12 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "profile")) m->profile = (int)v;
   else if (!strcmp(key, "fused")) m->fused = (int)v;
   else if (!strcmp(key, "mg_fused")) m->mg_fused = (int)v;
-  else if (!strcmp(key, "block_sweeps")) m->block_sweeps = (int)v;
+  else if (!strcmp(key, "block_sweeps")) { m->block_sweeps = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "mg_global_sum")) m->mg_global_sum = (int)v;
   else if (!strcmp(key, "agglomerate")) { m->agglomerate = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "agg_size")) { m->agg_size = (int)v; if (m->const_set) return build_coefs(m); }
-  else if (!strcmp(key, "prolong_fused")) m->prolong_fused = (int)v;
+  else if (!strcmp(key, "prolong_fused")) { m->prolong_fused = (int)v; if (m->const_set) return build_coefs(m); }
+  else if (!strcmp(key, "mg_coarse")) { m->mgc_opt = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "block_variant")) { extern int g_block_variant; g_block_variant = (int)v; }
   else if (!strcmp(key, "rhs_dbg")) { extern int g_rhs_dbg; g_rhs_dbg = (int)v; }
   else if (!strcmp(key, "rhs_variant")) m->rhs_variant = (int)v;
@@ -717,6 +722,39 @@ static int setup_agglomeration(msom *m) {
   return MSOM_OK;
 }
 
+// group of coarsest levels handled by k_mg_coarse: the gathered global levels (tiles + agglomeration) or
+// this tile's own levels (single tile); levels that need halo exchanges stay on the per-kernel path
+static int setup_mg_coarse(msom *m) {
+  m->mgc_first = -1;
+  if (!m->mgc_opt || m->block_sweeps || m->nlev < 1) return MSOM_OK;
+  const bool glob = m->agg_level >= 0;
+  if (!glob && m->nranks > 1) return MSOM_OK;
+  const int klo = glob ? m->agg_level : 0;
+  int k0 = -1;
+  for (int k = m->nlev - 1; k >= klo; k--) {
+    const SplitGeom &g = glob ? m->gsg[k - m->agg_level] : m->sg[k];
+    if (g.nx > MGC_MAXDIM || g.ny > MGC_MAXDIM) break;
+    k0 = k;
+  }
+  if (k0 < 0 || m->nlev - k0 > MGC_MAXLEV) return MSOM_OK;
+  CoarseArgs h;
+  memset(&h, 0, sizeof h);
+  h.n = m->nlev - k0;
+  h.walls = glob ? WALL_ALL : m->walls;
+  h.prolong_fused = m->prolong_fused;
+  for (int k = k0; k < m->nlev; k++) {
+    CoarseLev &L = h.lev[k - k0];
+    if (glob) { const int q = k - m->agg_level; L.da = m->gda[q]; L.res = m->gres[q]; L.S = nullptr; L.g = m->gsg[q]; }
+    else { L.da = m->da[k]; L.res = m->res[k]; L.S = m->S[k]; L.g = m->sg[k]; }
+    L.rc = m->rc[k];
+  }
+  if (!m->d_cargs) HIPCHK(hipMalloc(&m->d_cargs, sizeof(CoarseArgs)));
+  HIPCHK(hipMemcpyAsync(m->d_cargs, &h, sizeof h, hipMemcpyHostToDevice, m->st));
+  HIPCHK(hipStreamSynchronize(m->st));
+  m->mgc_first = k0;
+  return MSOM_OK;
+}
+
 // layer metrics, Ro, S on all levels, column-solver constants, forcing profile
 static int build_coefs(msom *m) {
   const Params &p = m->p;
@@ -775,6 +813,7 @@ static int build_coefs(msom *m) {
   {
     int r = setup_agglomeration(m);
     if (r) return r;
+    if ((r = setup_mg_coarse(m))) return r;
   }
   // surface forcing profile :451 (host libm so that it matches the CPU formulation bit for bit)
   {
@@ -905,24 +944,30 @@ static void level_solve(msom *m, Lev &L, const Lev *coarse, int nrelax, int corn
 // on the gathered global coarse grid by every rank (identical arithmetic, no halo traffic).
 static void mg_cycle_levels(msom *m, int nrelax, int first_restrict) {
   const int nl = m->nl, kc = m->agg_level >= 0 ? m->agg_level : m->nlev;
-  for (int k = first_restrict; k < m->nlev && k <= kc; k++) launch_restrict(m->st, m->res[k - 1], m->sg[k - 1], m->res[k], m->sg[k], nl);
-  if (kc < m->nlev) {
+  const int kg = m->mgc_first;  // levels >= kg (of the gathered grid if kc < nlev, else of this tile): one launch
+  const bool glob = kc < m->nlev;
+  // tile levels: restrict down to the gather level / to the finest level of the one-launch group
+  const int rmax = glob ? kc : (kg >= 0 ? kg : m->nlev - 1);
+  for (int k = first_restrict; k < m->nlev && k <= rmax; k++) launch_restrict(m->st, m->res[k - 1], m->sg[k - 1], m->res[k], m->sg[k], nl);
+  if (glob) {
     // gather the level-kc residual of all tiles, restrict it further on the global grid
     const SplitGeom &tg = m->sg[kc];
     const size_t cnt = (size_t)nl * tg.nx * tg.ny;
     launch_split_unpack(m->st, m->res[kc], tg, m->agg_send, nl);
     STICKY(m, comm_allgather(m->comm, m->agg_send, m->agg_recv, cnt));
     launch_assemble_global(m->st, m->agg_recv, m->gres[0], m->gsg[0], nl, tg.nx, tg.ny, m->px);
-    for (int k = kc + 1; k < m->nlev; k++) launch_restrict(m->st, m->gres[k - 1 - kc], m->gsg[k - 1 - kc], m->gres[k - kc], m->gsg[k - kc], nl);
-    for (int k = m->nlev - 1; k >= kc; k--) {
+    const int gtop = kg >= 0 ? kg : m->nlev - 1;  // coarsest level restricted by its own launch
+    for (int k = kc + 1; k <= gtop; k++) launch_restrict(m->st, m->gres[k - 1 - kc], m->gsg[k - 1 - kc], m->gres[k - kc], m->gsg[k - kc], nl);
+    if (kg >= 0) launch_mg_coarse(m->st, m->d_cargs, nrelax, nl, m->uniformS);
+    for (int k = (kg >= 0 ? kg : m->nlev) - 1; k >= kc; k--) {
       Lev L = glob_lev(m, k);
       if (k == m->nlev - 1) level_solve(m, L, nullptr, nrelax, 0);
       else { Lev C = glob_lev(m, k + 1); level_solve(m, L, &C, nrelax, 0); }
     }
     // this rank's tile of the level-kc correction, with its ghost ring
     launch_extract_tile(m->st, m->gda[0], m->gsg[0], m->da[kc], tg, nl, m->ix * tg.nx, m->iy * tg.ny);
-  }
-  for (int k = (kc < m->nlev ? kc : m->nlev) - 1; k >= 0; k--) {
+  } else if (kg >= 0) launch_mg_coarse(m->st, m->d_cargs, nrelax, nl, m->uniformS);
+  for (int k = (glob ? kc : (kg >= 0 ? kg : m->nlev)) - 1; k >= 0; k--) {
     Lev L = tile_lev(m, k);
     if (k == m->nlev - 1) level_solve(m, L, nullptr, nrelax, k > 0);
     else { Lev C = tile_lev(m, k + 1); level_solve(m, L, &C, nrelax, k > 0); }

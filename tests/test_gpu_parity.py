@@ -434,6 +434,30 @@ def test_lds_correct_residual_equals_plain(nx, ny, nl, extra, strict):
         assert out[0][2] == pytest.approx(out[384][2], rel=1e-9) and out[0][3][0] == out[384][3][0]
 
 
+@pytest.mark.parametrize("nx,ny,nl", [(256, 128, 6), (64, 64, 3), (32, 32, 1), (512, 64, 2)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_one_launch_coarse_levels_equal_per_kernel_path(nx, ny, nl, strict):
+    """option mg_coarse: the levels of at most 64 cells a side solved by ONE workgroup (k_mg_coarse) give the
+    same psi as the kernel-per-half-sweep path (bit for bit in the strict build)"""
+    txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else ""))
+    out = {}
+    for opt in (0, 1):
+        g = QG(txt, strict=strict)
+        g.option("quiet", 1); g.option("TOLERANCE", 1e-8)
+        g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx))
+        g.set_const()
+        g.option("mg_coarse", opt)
+        for _ in range(2):
+            g.step()
+        st = g.mgstats()
+        out[opt] = (g.get(F["PSI"]), (st.i, st.resa))
+        g.close()
+    if strict:
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    else:
+        assert rel(out[1][0], out[0][0]) <= 1e-10 and out[0][1][0] == out[1][1][0]
+
+
 @pytest.mark.parametrize("nx,ny,nl", [(128, 64, 3), (64, 64, 6), (256, 128, 2), (192, 80, 4), (64, 32, 1)])
 @pytest.mark.parametrize("strict", [True, False])
 def test_blocked_smoother_equals_plain_sweeps(nx, ny, nl, strict):
