@@ -992,6 +992,42 @@ __device__ __forceinline__ void red_prolong2_pt(const RelaxPArgs &p, int kx, int
   c1.finish(p);
 }
 
+// Same cells per thread as k_relax_red_prolong2, with the coarse correction staged through LDS: a 64 x 4
+// thread block needs the (64 + 2) x (4 + 2) coarse cells around it on every layer; loaded once (~9 loads
+// per thread for all layers) instead of 9 per thread and layer, the 3 x 3 windows are then LDS reads.
+// Used on wide levels, where the per-layer window loads made the pass instruction-bound.
+template <int NL, bool UNIFORM>
+__global__ void __launch_bounds__(BX *BY) k_relax_red_prolong3(RelaxPArgs p) {
+  constexpr int CW = BX + 2, CH = BY + 2, CP = CW + 2;
+  __shared__ double C[NL][CH][CP];
+  const int tid = threadIdx.y * BX + threadIdx.x;
+  const int kx0 = blockIdx.x * BX, J0 = blockIdx.y * BY;
+  for (int t = tid; t < NL * CH * CW; t += BX * BY) {
+    const int l = t / (CH * CW), r = (t / CW) % CH, c = t % CW;
+    const int I = kx0 - 1 + c, J = J0 - 1 + r;
+    C[l][r][c] = (I <= p.cg.nx && J <= p.cg.ny) ? p.coarse[split_idx(p.cg, l, J, I)] : 0.;
+  }
+  __syncthreads();
+  const int kx = kx0 + threadIdx.x, J = J0 + threadIdx.y;
+  if (kx >= p.g.hk || 2 * J >= p.g.ny) return;
+  RedCell<NL, UNIFORM, 0> c0;
+  RedCell<NL, UNIFORM, 1> c1;
+  c0.init(p, kx, J);
+  c1.init(p, kx, J);
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    double c[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) c[a][b] = C[l][threadIdx.y + a][threadIdx.x + b];
+    c0.layer(p, l, c);
+    c1.layer(p, l, c);
+  }
+  c0.finish(p);
+  c1.finish(p);
+}
+
 // ------------------------------------------------------------------ coarse levels in ONE launch
 // Levels of at most MGC_MAXDIM x MGC_MAXDIM cells are launch-latency bound (a colour half-sweep of a 32^2
 // level takes ~1 us of work and ~4.5 us of launch): one 512-thread workgroup (256 VGPRs per wave: the fused prolongation needs ~150) runs the whole coarse part
@@ -1064,6 +1100,11 @@ template <int NL>
 static void relax_red_prolong_dispatch(hipStream_t st, const RelaxPArgs &p, int uniformS) {
   dim3 gr = grid2d(p.g.hk, (p.g.ny + 1) / 2);
   extern int g_rhs_dbg;
+  if (!(g_rhs_dbg & 256) && p.g.hk >= 128 && !(g_rhs_dbg & 512)) {  // wide levels: coarse windows through LDS
+    if (uniformS) hipLaunchKernelGGL((k_relax_red_prolong3<NL, true>), gr, block2d(), 0, st, p);
+    else hipLaunchKernelGGL((k_relax_red_prolong3<NL, false>), gr, block2d(), 0, st, p);
+    return;
+  }
   if (!(g_rhs_dbg & 256)) {  // both row parities per thread
     if (uniformS) hipLaunchKernelGGL((k_relax_red_prolong2<NL, true>), gr, block2d(), 0, st, p);
     else hipLaunchKernelGGL((k_relax_red_prolong2<NL, false>), gr, block2d(), 0, st, p);
