@@ -102,7 +102,7 @@ struct msom {
   int nme_ft = 0;  // msqg/qg_energy.h:17
   // coarse levels (<= MGC_MAXDIM cells a side) solved by ONE launch (k_mg_coarse)
   CoarseArgs *d_cargs = nullptr;
-  int mgc_first = -1, mgc_opt = 0;  // first (finest) level of the group, -1: none; option "mg_coarse" (measured: no faster than the ~45 tiny launches it replaces)
+  int mgc_first = -1, mgc_opt = 1;  // first (finest) level of the group, -1: none; option "mg_coarse"
   int res_ready = -1;  // field id whose first multigrid residual (levels 0, 1; SC_RESF; partial sums) the last tendency pass already produced
   int adv_fused = 1;   // fold q_out = q_in + dt dq into the tendency pass
   int rhs_resid = 0;   // let the fused tendency + advance pass produce it: measured slower (23 spilled VGPRs in the 256-VGPR kernel: 2.21 ms vs 1.63 + 0.50 ms), kept as an option
