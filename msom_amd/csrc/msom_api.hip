@@ -70,7 +70,7 @@ struct msom {
   std::vector<RelaxCoef> rc;
   size_t max_split = 0;
   // agglomerated coarse levels (tiled mode): levels >= agg_level live on the gathered global grid
-  int agg_level = -1, agglomerate = 1, agg_size = 64;
+  int agg_level = -1, agglomerate = 1, agg_size = 256;
   int mg_global_sum = 0;
   std::vector<SplitGeom> gsg;
   std::vector<double *> gda, gda_alt, gres;

@@ -88,6 +88,30 @@ def test_tiled_equals_single_tile_bit_for_bit(px, py, tile, nl, strict):
     assert np.array_equal(assemble(out, "psi", px, py), g.get(F["PSI"]))
 
 
+@pytest.mark.parametrize("strict", [True, False])
+def test_large_tiles_default_agglomeration(strict):
+    """2 x 2 tiles of 512^2 with the default options: level 0 exchanges halos after every colour, the levels
+    from 256^2 per tile down are gathered (global 512^2 ... 4^2, the last five in one launch), the wide-level
+    kernels (two cells per thread, LDS-tiled correction, fused tendency) run on tiles; equal to the single
+    tile bit for bit."""
+    px = py = 2
+    tile, nl = 512, 2
+    gn = tile * px
+    params = orc.double_gyre_params(gn, nl, extra="MGLEVELS = 9\n")
+    psi = orc.synthetic_psi(nl, gn, gn)
+    out = run_tiled(params, px, py, psi, nsteps=3, strict=strict)
+    g = QG(params, strict=strict)
+    g.option("quiet", 1)
+    g.set(F["PSI"], psi)
+    g.set_const()
+    g.set_tnext(float("inf"))
+    dts = [g.step() for _ in range(3)]
+    for r in range(px * py):
+        assert out[r]["dts"] == dts, r
+    assert np.array_equal(assemble(out, "q", px, py), g.get(F["Q"]))
+    assert np.array_equal(assemble(out, "psi", px, py), g.get(F["PSI"]))
+
+
 def test_tiled_strict_matches_oracle():
     """The tiled strict build is bit-exact against the (untiled) CPU oracle as well."""
     px, py, tile, nl = 2, 2, 32, 3
