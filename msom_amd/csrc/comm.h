@@ -36,6 +36,8 @@ void launch_nat_pack_strip(hipStream_t st, const double *f, const NatGeom &g, in
 void launch_nat_unpack_strip(hipStream_t st, double *f, const NatGeom &g, int nl, int i0, int j0, int w, int h, const double *buf);
 void launch_split_pack_strip(hipStream_t st, const double *f, const SplitGeom &g, int nl, int i0, int j0, int w, int h, double *buf);
 void launch_split_unpack_strip(hipStream_t st, double *f, const SplitGeom &g, int nl, int i0, int j0, int w, int h, const double *buf);
+void launch_split_pack_faces(hipStream_t st, const double *f, const SplitGeom &g, int nl, double *const bufs[4]);
+void launch_split_unpack_faces(hipStream_t st, double *f, const SplitGeom &g, int nl, double *const bufs[4]);
 void launch_split_wall_corners(hipStream_t st, double *f, const SplitGeom &g, int nl, int walls);
 
 #endif

@@ -65,6 +65,38 @@ __global__ void k_split_wall_corners(double *f, SplitGeom g, int nl, int walls) 
   if ((walls & WALL_E) && !(walls & WALL_N)) f[split_idx(g, l, g.ny, g.nx)] = -f[split_idx(g, l, g.ny, g.nx - 1)];
 }
 
+// all four face strips (1 cell deep) of a split field in ONE launch: W, E columns [l][j], S, N rows [l][i]
+// (the layouts of k_split_pack_strip); faces without a neighbour are skipped.  unpack writes the ghosts.
+struct FaceBufs { double *b[4]; };  // DIR_W, DIR_E, DIR_S, DIR_N; null = no neighbour
+template <bool PACK>
+__global__ void k_split_faces(double *f, SplitGeom g, int nl, FaceBufs fb) {
+  const int nW = nl * g.ny, nS = nl * g.nx;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int dir, l, i, j;
+  if (t < 2 * nW) { dir = t < nW ? DIR_W : DIR_E; t -= dir == DIR_E ? nW : 0; l = t / g.ny; j = t % g.ny; i = dir == DIR_W ? 0 : g.nx - 1; }
+  else if (t < 2 * nW + 2 * nS) { t -= 2 * nW; dir = t < nS ? DIR_S : DIR_N; t -= dir == DIR_N ? nS : 0; l = t / g.nx; i = t % g.nx; j = dir == DIR_S ? 0 : g.ny - 1; }
+  else return;
+  double *b = fb.b[dir];
+  if (!b) return;
+  if (PACK) b[t] = f[split_idx(g, l, j, i)];
+  else {  // ghost cell beyond the face
+    const int gi = dir == DIR_W ? -1 : dir == DIR_E ? g.nx : i, gj = dir == DIR_S ? -1 : dir == DIR_N ? g.ny : j;
+    f[split_idx(g, l, gj, gi)] = b[t];
+  }
+}
+void launch_split_pack_faces(hipStream_t st, const double *f, const SplitGeom &g, int nl, double *const bufs[4]) {
+  FaceBufs fb;
+  for (int d = 0; d < 4; d++) fb.b[d] = bufs[d];
+  const int n = 2 * nl * (g.nx + g.ny);
+  hipLaunchKernelGGL(k_split_faces<true>, dim3((n + 255) / 256), dim3(256), 0, st, const_cast<double *>(f), g, nl, fb);
+}
+void launch_split_unpack_faces(hipStream_t st, double *f, const SplitGeom &g, int nl, double *const bufs[4]) {
+  FaceBufs fb;
+  for (int d = 0; d < 4; d++) fb.b[d] = bufs[d];
+  const int n = 2 * nl * (g.nx + g.ny);
+  hipLaunchKernelGGL(k_split_faces<false>, dim3((n + 255) / 256), dim3(256), 0, st, f, g, nl, fb);
+}
+
 static inline dim3 g1(int n) { return dim3((n + 255) / 256); }
 
 // ------------------------------------------------------------------ RCCL (dlopen)

@@ -247,26 +247,31 @@ static int exch_split(msom *m, double *f, const SplitGeom &sg, int nl, int corne
   if (m->nranks == 1) return MSOM_OK;
   Xfer x[4];
   int n = 0;
+  if (!corners) {  // one pack launch, one message per neighbour, one unpack launch
+    double *sb[4], *rb[4];
+    for (int dir : {DIR_W, DIR_E, DIR_S, DIR_N}) {
+      const bool on = m->nb[dir] >= 0;
+      sb[dir] = on ? comm_sendbuf(m->comm, dir) : nullptr;
+      rb[dir] = on ? comm_recvbuf(m->comm, dir) : nullptr;
+      if (on) x[n++] = {m->nb[dir], AXIS(dir), sb[dir], rb[dir], (size_t)nl * (dir == DIR_W || dir == DIR_E ? sg.ny : sg.nx)};
+    }
+    launch_split_pack_faces(m->st, f, sg, nl, sb);
+    int r = comm_exchange(m->comm, x, n);
+    if (r) return r;
+    launch_split_unpack_faces(m->st, f, sg, nl, rb);
+    return MSOM_OK;
+  }
   auto pack = [&](int dir, int i0, int j0, int w, int h) {
     launch_split_pack_strip(m->st, f, sg, nl, i0, j0, w, h, comm_sendbuf(m->comm, dir));
     x[n++] = {m->nb[dir], AXIS(dir), comm_sendbuf(m->comm, dir), comm_recvbuf(m->comm, dir), (size_t)w * h * nl};
   };
-  const int x0 = corners ? -1 : 0, xw = corners ? sg.nx + 2 : sg.nx;
+  const int x0 = -1, xw = sg.nx + 2;
   if (m->nb[DIR_W] >= 0) pack(DIR_W, 0, 0, 1, sg.ny);
   if (m->nb[DIR_E] >= 0) pack(DIR_E, sg.nx - 1, 0, 1, sg.ny);
-  if (!corners) {
-    if (m->nb[DIR_S] >= 0) pack(DIR_S, 0, 0, sg.nx, 1);
-    if (m->nb[DIR_N] >= 0) pack(DIR_N, 0, sg.ny - 1, sg.nx, 1);
-  }
   int r = comm_exchange(m->comm, x, n);
   if (r) return r;
   if (m->nb[DIR_W] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, -1, 0, 1, sg.ny, comm_recvbuf(m->comm, DIR_W));
   if (m->nb[DIR_E] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, sg.nx, 0, 1, sg.ny, comm_recvbuf(m->comm, DIR_E));
-  if (!corners) {
-    if (m->nb[DIR_S] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, 0, -1, sg.nx, 1, comm_recvbuf(m->comm, DIR_S));
-    if (m->nb[DIR_N] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, 0, sg.ny, sg.nx, 1, comm_recvbuf(m->comm, DIR_N));
-    return MSOM_OK;
-  }
   launch_split_wall_corners(m->st, f, sg, nl, m->walls);
   n = 0;
   if (m->nb[DIR_S] >= 0) pack(DIR_S, x0, 0, xw, 1);
