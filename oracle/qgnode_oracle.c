@@ -103,10 +103,17 @@ int orn_set_option(orn_t *o, const char *k, double v) {
   return 0;
 }
 double orn_get_param(orn_t *o, const char *k) {
-  if (!strcmp(k, "N")) return o->N; if (!strcmp(k, "nl")) return o->nl; if (!strcmp(k, "L0")) return o->L0; if (!strcmp(k, "DT")) return o->DT;
-  if (!strcmp(k, "nlevels")) return o->nlev; if (!strcmp(k, "iRd2_low")) return o->iRd2_low; if (!strcmp(k, "bc_fac")) return o->bc_fac;
-  if (!strcmp(k, "tend")) return o->tend; if (!strcmp(k, "dtout")) return o->dtout;
-  if (!strncmp(k, "idh0_", 5)) return o->idh0[atoi(k + 5)]; if (!strncmp(k, "idh1_", 5)) return o->idh1[atoi(k + 5)];
+  if (!strcmp(k, "N")) return o->N;
+  if (!strcmp(k, "nl")) return o->nl;
+  if (!strcmp(k, "L0")) return o->L0;
+  if (!strcmp(k, "DT")) return o->DT;
+  if (!strcmp(k, "nlevels")) return o->nlev;
+  if (!strcmp(k, "iRd2_low")) return o->iRd2_low;
+  if (!strcmp(k, "bc_fac")) return o->bc_fac;
+  if (!strcmp(k, "tend")) return o->tend;
+  if (!strcmp(k, "dtout")) return o->dtout;
+  if (!strncmp(k, "idh0_", 5)) return o->idh0[atoi(k + 5)];
+  if (!strncmp(k, "idh1_", 5)) return o->idh1[atoi(k + 5)];
   return NAN;
 }
 int orn_nlayers_of(orn_t *o, int f) { return o->f[f].nl; }
