@@ -66,6 +66,37 @@ def cpu_baseline(nl, n_cpu=1024, steps=2):
     }
 
 
+_VARIANT_SNIPPET = """
+import sys, time
+sys.path.insert(0, {tests!r})
+import orc
+n, nl, steps, sm = {n}, {nl}, {steps}, {sm}
+o = orc.Oracle(orc.double_gyre_params(n, nl), smoother=sm, quiet=1)
+o.set(orc.PSI, orc.synthetic_psi(nl, n, n)); o.set_const(); o.step()
+t0 = time.perf_counter()
+for _ in range(steps): o.step()
+print(n * n * nl * steps / (time.perf_counter() - t0))
+"""
+
+
+def cpu_variants(nl, n=512, steps=2):
+    """SURVEY 8d asks for the lexicographic (reference order) and single-thread CPU timings next to the
+    OpenMP red-black one: each in its own process (OMP_NUM_THREADS is read once), on a smaller sample."""
+    import subprocess
+
+    out = {}
+    for name, sm, threads in (("red_black_1_thread", 1, 1), ("lexicographic_reference_order_1_thread", 0, 1)):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+        code = _VARIANT_SNIPPET.format(tests=os.path.join(ROOT, "tests"), n=n, nl=nl, steps=steps, sm=sm)
+        try:
+            r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+            out[name] = {"value": float(r.stdout.strip().splitlines()[-1]), "unit": "grid-point-updates/s", "cores": threads,
+                         "sample": f"{steps} RK2 steps at {n}x{n}x{nl}"}
+        except Exception as e:  # the headline baseline above does not depend on these
+            out[name] = {"error": str(e)[:200]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,6 +246,7 @@ def main():
             g.close()
             out["cpu_baseline"] = cpu_baseline(nl, n_cpu=args.cpu_n)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["cpu_baseline"]["variants"] = cpu_variants(nl)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
