@@ -330,7 +330,10 @@ LAYERS = {
     2: ("[0.0023669]", "[0.2,0.8]"),
     3: ("[0.0023669,0.0076173]", "[0.06,0.14,0.8]"),
     4: ("[0.0023669,0.0076173,0.0076173]", "[0.06,0.14,0.4,0.4]"),
+    5: ("[0.0023669,0.0023669,0.0076173,0.0076173]", "[0.03,0.03,0.14,0.4,0.4]"),
     6: ("[0.0023669,0.0023669,0.0076173,0.0076173,0.0076173]", "[0.03,0.03,0.07,0.07,0.4,0.4]"),
+    7: ("[0.0023669,0.0023669,0.0076173,0.0076173,0.0076173,0.0076173]", "[0.03,0.03,0.07,0.07,0.2,0.2,0.4]"),
+    8: ("[0.0023669,0.0023669,0.0076173,0.0076173,0.0076173,0.0076173,0.0076173]", "[0.03,0.03,0.07,0.07,0.2,0.2,0.2,0.2]"),
 }
 
 

@@ -631,3 +631,27 @@ def test_passive_tracers_bit_exact(nx, ny, nl, nptr, extra):
     assert np.array_equal(g.get(F["PTR"]), o.get(orc.PTR))
     assert np.array_equal(g.get(F["Q"]), o.get(orc.Q))
     assert np.abs(g.get(F["PTR"]) - c0).max() > 0
+
+
+@pytest.mark.parametrize("nl", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_every_supported_layer_count(nl):
+    """nl = 1 ... MSOM_MAXNL: three RK2 steps at 256 x 128 (wide-level kernels, LDS-tiled correction, fused
+    tendency + advance, one-launch coarse levels), strict build bit-exact against the oracle, product build
+    within 1e-9."""
+    nx, ny = 256, 128
+    for strict in (True, False):
+        o, g = make_pair(nx, ny, nl, strict=strict, TOLERANCE=1e-9)
+        for _ in range(3):
+            o.step(); g.step()
+        if strict:
+            assert np.array_equal(g.get(F["PSI"]), o.get(orc.PSI)) and np.array_equal(g.get(F["Q"]), o.get(orc.Q))
+            assert g.t == o.t
+        else:
+            assert rel(g.get(F["PSI"]), o.get(orc.PSI)) <= 1e-9 and rel(g.get(F["Q"]), o.get(orc.Q)) <= 1e-9
+
+
+def test_more_layers_than_supported_is_rejected():
+    from msom_amd import MsomError
+    txt = orc.double_gyre_params(32, 8).replace("nl = 8", "nl = 9")
+    with pytest.raises(MsomError, match="supported range"):
+        QG(txt)
