@@ -227,6 +227,52 @@ struct NRelaxArgs {
 };
 // one colour of relax_baroclinic (qg_baroclinic_ms.h:228-291) / relax_barotropic (qg_barotropic.h:57-76)
 // on the interior vertices; boundary vertices of the correction stay 0 (homogeneous psi BC).
+// column solve of one vertex: ew[l] = a_E + a_W, ns[l] = a_N + a_S of layer l; c = index of the vertex in layer 0
+template <int NL>
+__device__ __forceinline__ void n_col_solve(const NRelaxArgs &p, size_t c, const double (&ew)[NL], const double (&ns)[NL], double (&x)[NL]) {
+  const size_t ls = p.g.ls;
+  const double sq = p.sqD, m = p.mk[c];
+  if (NL == 1) {
+    double d = -(-p.iRd2) * sq, v = -p.b[c] * sq;
+    v += ew[0] * m; d += 2.;
+    v += ns[0] * m; d += 2.;
+    x[0] = v / d;
+    return;
+  }
+  double t0[NL], t1[NL], t2[NL], rhs[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    const size_t k = c + l * ls;
+    rhs[l] = -sq * p.b[k] * m;
+    t0[l] = l == 0 ? 0. : (l < NL - 1 ? -sq * p.S2[k - ls] * p.lc.idh0[l] * m : -sq * p.S2[k - ls] * p.lc.idh0[l]);  // bottom t0 not masked, :267
+    t2[l] = l < NL - 1 ? -sq * p.S2[k] * p.lc.idh1[l] * m : 0.;
+    t1[l] = l == 0 ? -t2[l] : (l < NL - 1 ? -t0[l] - t2[l] : -t0[l]);
+    rhs[l] += ew[l] * m; t1[l] += 2;
+    rhs[l] += ns[l] * m; t1[l] += 2;
+  }
+#ifdef MSOM_STRICT
+#pragma unroll
+  for (int l = 1; l < NL; l++) { t1[l] -= t0[l] * t2[l - 1] / t1[l - 1]; rhs[l] -= t0[l] * rhs[l - 1] / t1[l - 1]; }
+  x[NL - 1] = rhs[NL - 1] / t1[NL - 1];
+#pragma unroll
+  for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - t2[l] * x[l + 1]) / t1[l];
+#else
+  // product build: one reciprocal per layer instead of three divisions (the smoother is bound by the fp64
+  // division sequences, not by HBM)
+  double r[NL];
+  r[0] = 1. / t1[0];
+#pragma unroll
+  for (int l = 1; l < NL; l++) {
+    const double w = t0[l] * r[l - 1];
+    t1[l] -= w * t2[l - 1];
+    rhs[l] -= w * rhs[l - 1];
+    r[l] = 1. / t1[l];
+  }
+  x[NL - 1] = rhs[NL - 1] * r[NL - 1];
+#pragma unroll
+  for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - t2[l] * x[l + 1]) * r[l];
+#endif
+}
 template <int NL>
 __global__ void __launch_bounds__(BX *BY) k_n_relax(NRelaxArgs p) {
   const int n = p.g.nx - 1;
@@ -235,32 +281,92 @@ __global__ void __launch_bounds__(BX *BY) k_n_relax(NRelaxArgs p) {
   if (i >= n || j >= n) return;
   const int pitch = p.g.pitch;
   const size_t ls = p.g.ls, c = nat_idx(p.g, 0, j, i);
-  const double sq = p.sqD, m = p.mk[c];
-  if (NL == 1) {
-    double d = -(-p.iRd2) * sq, v = -p.b[c] * sq;
-    v += (p.a[c + 1] + p.a[c - 1]) * m; d += 2.;
-    v += (p.a[c + pitch] + p.a[c - pitch]) * m; d += 2.;
-    p.a[c] = v / d;
-    return;
-  }
-  double t0[NL], t1[NL], t2[NL], rhs[NL], x[NL];
+  double ew[NL], ns[NL], x[NL];
 #pragma unroll
   for (int l = 0; l < NL; l++) {
     const size_t k = c + l * ls;
-    rhs[l] = -sq * p.b[k] * m;
-    t0[l] = l == 0 ? 0. : (l < NL - 1 ? -sq * p.S2[k - ls] * p.lc.idh0[l] * m : -sq * p.S2[k - ls] * p.lc.idh0[l]);  // bottom t0 not masked, :267
-    t2[l] = l < NL - 1 ? -sq * p.S2[k] * p.lc.idh1[l] * m : 0.;
-    t1[l] = l == 0 ? -t2[l] : (l < NL - 1 ? -t0[l] - t2[l] : -t0[l]);
-    rhs[l] += (p.a[k + 1] + p.a[k - 1]) * m; t1[l] += 2;
-    rhs[l] += (p.a[k + pitch] + p.a[k - pitch]) * m; t1[l] += 2;
+    ew[l] = p.a[k + 1] + p.a[k - 1];
+    ns[l] = p.a[k + pitch] + p.a[k - pitch];
   }
-#pragma unroll
-  for (int l = 1; l < NL; l++) { t1[l] -= t0[l] * t2[l - 1] / t1[l - 1]; rhs[l] -= t0[l] * rhs[l - 1] / t1[l - 1]; }
-  x[NL - 1] = rhs[NL - 1] / t1[NL - 1];
-#pragma unroll
-  for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - t2[l] * x[l + 1]) / t1[l];
+  n_col_solve<NL>(p, c, ew, ns, x);
 #pragma unroll
   for (int l = 0; l < NL; l++) p.a[c + l * ls] = x[l];
+}
+// NS full red-black sweeps in ONE pass over HBM, out of place (a_in -> a_out; neighbouring workgroups read each
+// other's tiles): a 64 x TH tile of the correction with a 2 NS halo goes to LDS, half-sweep h updates the
+// cells of colour h & 1 inside the region tile +- (2 NS - 1 - h) -- a cell is updated only when its four
+// neighbours carry the values of the previous half-sweep, so every update equals the one of the
+// kernel-per-colour sweep bit for bit -- and the tile is stored.  In the natural (colour-interleaved)
+// layout a colour pass moves whole cache lines of which it uses half; this pass reads and writes every
+// line once per NS sweeps.
+template <int NL, int NS, int TH>
+__global__ void __launch_bounds__(BX *BY) k_n_relax_tile(NRelaxArgs p, const double *a_in) {
+  constexpr int TW = 64, H = 2 * NS, LW = TW + 2 * H, LH = TH + 2 * H;
+  __shared__ double A[NL][LH][LW];
+  const int tid = threadIdx.y * BX + threadIdx.x;
+  const int n = p.g.nx - 1, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  for (int t = tid; t < NL * LH * LW; t += BX * BY) {
+    const int l = t / (LH * LW), r = (t / LW) % LH, c = t % LW;
+    const int gi = x0 - H + c, gj = y0 - H + r;
+    A[l][r][c] = (gi >= 0 && gi <= n && gj >= 0 && gj <= n) ? a_in[nat_idx(p.g, l, gj, gi)] : 0.;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2 * NS; h++) {
+    const int e = H - 1 - h, RW = TW + 2 * e, RH = TH + 2 * e, half = RW / 2, col = h & 1;
+    for (int t = tid; t < RH * half; t += BX * BY) {
+      const int r = t / half, k = t % half;
+      const int gj = y0 - e + r, xs = x0 - e;
+      const int gi = xs + ((col + xs + gj) & 1) + 2 * k;
+      if (gi < 1 || gi >= n || gj < 1 || gj >= n) continue;  // boundary vertices and beyond: never relaxed
+      const int lr = gj - (y0 - H), lc = gi - (x0 - H);
+      double ew[NL], ns[NL], x[NL];
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        ew[l] = A[l][lr][lc + 1] + A[l][lr][lc - 1];
+        ns[l] = A[l][lr + 1][lc] + A[l][lr - 1][lc];
+      }
+      n_col_solve<NL>(p, nat_idx(p.g, 0, gj, gi), ew, ns, x);
+#pragma unroll
+      for (int l = 0; l < NL; l++) A[l][lr][lc] = x[l];
+    }
+    __syncthreads();
+  }
+  for (int t = tid; t < NL * TH * TW; t += BX * BY) {
+    const int l = t / (TH * TW), r = (t / TW) % TH, c = t % TW;
+    const int gi = x0 + c, gj = y0 + r;
+    if (gi <= n && gj <= n) p.a[nat_idx(p.g, l, gj, gi)] = A[l][r + H][c + H];
+  }
+}
+template <int NL>
+static void n_relax_tile_dispatch(hipStream_t st, const NRelaxArgs &p, const double *a_in, int ns) {
+  const int n1 = p.g.nx;
+  if constexpr (NL <= 6) {
+    if (ns == 2) {
+      hipLaunchKernelGGL((k_n_relax_tile<NL, 2, 32>), dim3((n1 + 63) / 64, (n1 + 31) / 32), block2d(), 0, st, p, a_in);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_n_relax_tile<NL, 1, 16>), dim3((n1 + 63) / 64, (n1 + 15) / 16), block2d(), 0, st, p, a_in);
+}
+// returns the number of sweeps done by this pass (ns asked; 1 when the 2-sweep tile does not fit in LDS)
+int launch_n_relax_tile(hipStream_t st, const double *a_in, double *a_out, const double *b, const double *mk, const double *S2, const NatGeom &g,
+                        int nl, int ns, double D, double iRd2, const LayerCoef &lc) {
+  NRelaxArgs p;
+  p.a = a_out; p.b = b; p.mk = mk; p.S2 = S2; p.g = g; p.color = 0; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc;
+  if (ns == 2 && nl > 6) ns = 1;
+  switch (nl) {
+    case 1: n_relax_tile_dispatch<1>(st, p, a_in, ns); break;
+    case 2: n_relax_tile_dispatch<2>(st, p, a_in, ns); break;
+    case 3: n_relax_tile_dispatch<3>(st, p, a_in, ns); break;
+    case 4: n_relax_tile_dispatch<4>(st, p, a_in, ns); break;
+    case 5: n_relax_tile_dispatch<5>(st, p, a_in, ns); break;
+    case 6: n_relax_tile_dispatch<6>(st, p, a_in, ns); break;
+    case 7: n_relax_tile_dispatch<7>(st, p, a_in, ns); break;
+    case 8: n_relax_tile_dispatch<8>(st, p, a_in, ns); break;
+    default: break;
+  }
+  return ns;
 }
 void launch_n_relax(hipStream_t st, double *a, const double *b, const double *mk, const double *S2, const NatGeom &g, int nl, int color, double D,
                     double iRd2, const LayerCoef &lc) {

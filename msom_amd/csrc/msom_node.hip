@@ -11,6 +11,7 @@
 #include <string.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,7 @@ struct NLevel {
   double D;     // L0 / n
   NatGeom g;
   double *da, *res, *mask, *S2;  // level 0: mask and S2 alias the model fields
+  double *da2;                   // second correction buffer (the tiled smoother works out of place)
 };
 enum { NSC_RES = 0, NSC_UMAX = 1, NSC_KE = 2, NSC_COUNT = 8 };
 
@@ -40,6 +42,7 @@ struct msomn {
   double D = 0, psi_bc = 0., iRd2_low = 0.;
   double tolerance = 1e-3;
   int nitermax = 100, nitermin = 1, nrelax = 5, quiet = 0;  // nodal-poisson.h:19-23
+  int tiled_relax = 0;  // option: LDS-tiled smoother passes (1-2 sweeps per pass) on the wide levels; measured 3 % faster at 4097^2 x 3, 7 % slower at 2049^2 x 3
   NatGeom g;
   double *f[MSOMN_NFIELDS] = {nullptr};
   int fl[MSOMN_NFIELDS] = {0};
@@ -94,6 +97,7 @@ extern "C" void msomn_destroy(msomn_t *m) {
   for (int k = 0; k < MSOMN_NFIELDS; k++) if (m->f[k]) (void)hipFree(m->f[k]);
   for (size_t k = 0; k < m->lev.size(); k++) {
     if (m->lev[k].da) (void)hipFree(m->lev[k].da);
+    if (m->lev[k].da2) (void)hipFree(m->lev[k].da2);
     if (m->lev[k].res) (void)hipFree(m->lev[k].res);
     if (k > 0 && m->lev[k].mask) (void)hipFree(m->lev[k].mask);
     if (k > 0 && m->lev[k].S2) (void)hipFree(m->lev[k].S2);
@@ -120,9 +124,9 @@ static int node_alloc(msomn *m) {
     L.n = m->N >> k;
     L.D = m->p.L0 / L.n;
     L.g = node_geom(L.n);
-    L.da = L.res = L.mask = L.S2 = nullptr;
+    L.da = L.da2 = L.res = L.mask = L.S2 = nullptr;
     int r;
-    if ((r = dalloc(&L.da, L.g.ls * m->nl)) || (r = dalloc(&L.res, L.g.ls * m->nl))) return r;
+    if ((r = dalloc(&L.da, L.g.ls * m->nl)) || (r = dalloc(&L.da2, L.g.ls * m->nl)) || (r = dalloc(&L.res, L.g.ls * m->nl))) return r;
     if (k == 0) { L.mask = m->f[MSOMN_MASK]; L.S2 = m->f[MSOMN_S2]; }
     else if ((r = dalloc(&L.mask, L.g.ls)) || (r = dalloc(&L.S2, L.g.ls * m->nlm))) return r;
   }
@@ -197,6 +201,7 @@ extern "C" int msomn_set_option(msomn_t *m, const char *key, double v) {
   else if (!strcmp(key, "NITERMIN")) m->nitermin = (int)v;
   else if (!strcmp(key, "DT")) m->p.DT = v;
   else if (!strcmp(key, "quiet")) m->quiet = (int)v;
+  else if (!strcmp(key, "tiled_relax")) m->tiled_relax = (int)v;
   else { msom_set_error("unknown option %s", key); return MSOM_ERR_ARG; }
   return MSOM_OK;
 }
@@ -288,6 +293,20 @@ static void relax_level(msomn *m, int k, double *da, const double *res) {
   NLevel &L = m->lev[k];
   for (int c = 0; c < 2; c++) launch_n_relax(m->st, da, res, L.mask, L.S2, L.g, m->nl, c, L.D, m->iRd2_low, m->lc);
 }
+// nsweeps red-black sweeps of level k on L.da.  Wide levels: LDS-tiled passes of 2 (or 1) sweeps, out of place
+// (L.da <-> L.da2 swap, L.da always the current one); narrow levels: one launch per colour.
+static void relax_sweeps(msomn *m, int k, int nsweeps) {
+  NLevel &L = m->lev[k];
+  if (!m->tiled_relax || L.n + 1 < 64) {
+    for (int s = 0; s < nsweeps; s++) relax_level(m, k, L.da, L.res);
+    return;
+  }
+  for (int s = 0; s < nsweeps;) {
+    const int want = nsweeps - s >= 2 ? 2 : 1;
+    s += launch_n_relax_tile(m->st, L.da, L.da2, L.res, L.mask, L.S2, L.g, m->nl, want, L.D, m->iRd2_low, m->lc);
+    std::swap(L.da, L.da2);
+  }
+}
 static int build_levels(msomn *m) {
   launch_n_bnd_const(m->st, m->f[MSOMN_MASK], m->g, 1, 0.);
   for (int k = 1; k < m->nlev; k++) {
@@ -319,7 +338,7 @@ static int vpoisson(msomn *m, double *a, const double *b) {
     }
     HIPCHK(hipMemsetAsync(m->lev[nlev - 1].da, 0, m->lev[nlev - 1].g.ls * nl * sizeof(double), m->st));
     for (int k = nlev - 1; k >= 0; k--) {
-      for (int s = 0; s < mg.nrelax; s++) relax_level(m, k, m->lev[k].da, m->lev[k].res);
+      relax_sweeps(m, k, mg.nrelax);
       if (k > 0) launch_n_prolong(m->st, m->lev[k].da, m->lev[k].g, m->lev[k - 1].da, m->lev[k - 1].g, nl);
     }
     launch_n_correct(m->st, a, m->lev[0].da, m->g, nl, m->psi_bc);
@@ -491,7 +510,7 @@ extern "C" int msomn_dbg_relax(msomn_t *m, int k, double *da, const double *res,
   int r;
   if ((r = upload_g(m, L.da, L.g, m->nl, da)) || (r = upload_g(m, L.res, L.g, m->nl, res))) return r;
   launch_n_bnd_const(m->st, L.da, L.g, m->nl, 0.);
-  for (int s = 0; s < nsweeps; s++) relax_level(m, k, L.da, L.res);
+  relax_sweeps(m, k, nsweeps);
   HIPCHK(hipGetLastError());
   return download_g(m, L.da, L.g, m->nl, da);
 }

@@ -99,6 +99,28 @@ def test_multigrid_pieces(nl, strict):
 
 
 @pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nl,N", [(1, 128), (3, 256), (6, 128), (8, 64)])
+def test_tiled_smoother_passes(nl, N, strict):
+    """k_n_relax_tile (1 or 2 red-black sweeps per pass through an LDS tile, out of place) on the wide levels:
+    1, 2, 3 and 5 sweeps against the oracle's colour-by-colour sweeps, and against the per-colour kernels"""
+    if nl not in orn.NODE_LAYERS:
+        orn.NODE_LAYERS[nl] = ("[" + ",".join(["%.3f" % (1.0 / nl)] * nl) + "]", "[" + ",".join(["%d." % (9000 - 900 * l) for l in range(nl - 1)]) + "]")
+    o, g = make_pair(N, nl, strict, mask=True, extra="gp_low = 0.02\n")
+    g.set_option("tiled_relax", 1)
+    rng = np.random.default_rng(11)
+    for k in (0, 1):
+        n1 = (N >> k) + 1
+        da, res = rng.standard_normal((nl, n1, n1)), rng.standard_normal((nl, n1, n1))
+        for ns in (1, 2, 3, 5):
+            got, ref = g.dbg_relax(k, da, res, ns), o.relax(k, da, res, ns)
+            same(got, ref, strict, 1e-10)
+            g.set_option("tiled_relax", 0)
+            plain = g.dbg_relax(k, da, res, ns)
+            g.set_option("tiled_relax", 1)
+            assert np.array_equal(got, plain) or not strict
+
+
+@pytest.mark.parametrize("strict", [True, False])
 @pytest.mark.parametrize("nl,bc_fac,mask", [(1, 0.0, False), (1, 1.0, True), (2, 0.0, True), (3, 1.0, False), (4, 0.5, True)])
 def test_invert_and_rhs(nl, bc_fac, mask, strict):
     o, g = make_pair(32, nl, strict, bc_fac=bc_fac, nu4=2.0, mask=mask, topo=True, pg=True, extra="gp_low = 0.02\n", TOLERANCE=1e-9)

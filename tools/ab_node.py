@@ -1,0 +1,19 @@
+"""vertex variant: step time with option toggles (same process, same GPU)"""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np, orn
+from msom_amd import NodeQG
+N, nl = int(sys.argv[1]) if len(sys.argv) > 1 else 2048, 3
+g = NodeQG(orn.node_params(N, nl, bc_fac=1.0)); g.set_option("quiet", 1)
+mk = np.ones((1, N + 1, N + 1)); mk[0, N // 4: N // 4 + N // 8, N // 2: N // 2 + N // 8] = 0
+mk[0, 0, :] = mk[0, -1, :] = mk[0, :, 0] = mk[0, :, -1] = 0
+g.set("MASK", mk); g.set("PSI", orn.node_psi(nl, N) * mk); g.set_const()
+for _ in range(3): g.step(True)
+def run(n=6):
+    t0 = time.perf_counter()
+    for _ in range(n): g.step(True)
+    return (time.perf_counter() - t0) / n * 1e3
+for rep in range(2):
+    for opt in (1, 0):
+        g.set_option("tiled_relax", opt); run(1)
+        print(f"tiled_relax={opt}  {run():8.3f} ms/step  cycles {g.mgstats().i}", flush=True)
