@@ -22,6 +22,12 @@
 #define BY 4
 static inline dim3 grid2d(int nx, int ny) { return dim3((nx + BX - 1) / BX, (ny + BY - 1) / BY); }
 static inline dim3 block2d() { return dim3(BX, BY); }
+static inline dim3 grid_capped(int nx, int ny) {
+  dim3 g = grid2d(nx, ny);
+  const unsigned cap = 2048 / g.x > 0 ? 2048 / g.x : 1;
+  if (g.y > cap) g.y = cap;
+  return g;
+}
 #define VTX(g, i, j) const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y; if (i >= (g).nx || j >= (g).ny) return
 
 __device__ __forceinline__ double wave_max_n(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64)); return v; }
@@ -395,10 +401,12 @@ struct NResArgs {
   double sqD, iRd2;
   LayerCoef lc;
 };
+// at most ~2048 workgroups (rows strided over gridDim.y): one atomicMax per workgroup on a single word
+// saturates at ~88 per microsecond, which would dominate a pass launched with one workgroup per 64 x 4 cells
 __global__ void k_n_residual(NResArgs p) {
-  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  const int i = blockIdx.x * BX + threadIdx.x;
   double mx = 0.;
-  if (i < p.g.nx && j < p.g.ny) {
+  for (int j = blockIdx.y * BY + threadIdx.y; i < p.g.nx && j < p.g.ny; j += gridDim.y * BY) {
     const int nl = p.nl, pitch = p.g.pitch;
     const size_t ls = p.g.ls, c0 = nat_idx(p.g, 0, j, i);
     const double m = p.mk[c0], sq = p.sqD, rsq = 1. / sq;
@@ -430,7 +438,7 @@ void launch_n_residual(hipStream_t st, const double *a, const double *b, const d
                        const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc) {
   NResArgs p;
   p.a = a; p.b = b; p.mk = mk; p.S2 = S2; p.res = res; p.maxres = maxres; p.g = g; p.nl = nl; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc;
-  hipLaunchKernelGGL(k_n_residual, grid2d(g.nx, g.ny), block2d(), 0, st, p);
+  hipLaunchKernelGGL(k_n_residual, grid_capped(g.nx, g.ny), block2d(), 0, st, p);
 }
 // restriction_coarsen_vert (residual), restriction_coarsen_vert2 (mask), restriction_vert (injection), my_vertex.h:49-75
 __global__ void k_n_restrict(const double *__restrict__ f, NatGeom fg, double *c, NatGeom cg, int nl, int kind) {
@@ -481,9 +489,9 @@ void launch_n_correct(hipStream_t st, double *a, const double *da, const NatGeom
 }
 // adjust_dt qg-node/qg.h:258-284: max |psi[0,1] - psi[]| / D and |psi[1,0] - psi[]| / D over faces and layers
 __global__ void k_n_umax(const double *__restrict__ psi, double *out, NatGeom g, int nl, double D) {
-  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  const int i = blockIdx.x * BX + threadIdx.x;
   double m = 0.;
-  if (i < g.nx && j < g.ny) {
+  for (int j = blockIdx.y * BY + threadIdx.y; i < g.nx && j < g.ny; j += gridDim.y * BY) {
     const double rD = 1. / D;
     for (int l = 0; l < nl; l++) {
       const size_t c = nat_idx(g, l, j, i);
@@ -502,7 +510,7 @@ __global__ void k_n_umax(const double *__restrict__ psi, double *out, NatGeom g,
   }
 }
 void launch_n_umax(hipStream_t st, const double *psi, double *out, const NatGeom &g, int nl, double D) {
-  hipLaunchKernelGGL(k_n_umax, grid2d(g.nx, g.ny), block2d(), 0, st, psi, out, g, nl, D);
+  hipLaunchKernelGGL(k_n_umax, grid_capped(g.nx, g.ny), block2d(), 0, st, psi, out, g, nl, D);
 }
 // KE diagnostic qg-node/qg.c:172-178 (per-block partials, summed by launch_sum_final)
 __global__ void k_n_ke(const double *__restrict__ psi, double *partial, NatGeom g, double D2, double rD2) {
