@@ -86,10 +86,17 @@ msom_t *msom_create_str(const char *params_text);
 int msom_destroy(msom_t *m);
 
 /* run-time counterparts of the reference's compile-time flags and Basilisk globals:
- * "TOLERANCE" "NITERMAX" "NITERMIN" (mspg/elliptic.h:111-112, qg.h:159), "DT",
- * "stochastic" (-D_STOCHASTIC), "seed", "flag_topo", "fixed_cycles" (bench: data-independent
- * work), "uniform_S" (0 forces the general S-field kernels), "profile" (HIP-event timing of
- * the smoother launches). */
+ * "TOLERANCE" "NITERMAX" "NITERMIN" (mspg/elliptic.h:111-112, qg.h:159), "DT", "quiet",
+ * "stochastic" (-D_STOCHASTIC), "seed", "noise_mode" (0: the reference's serial rand() stream generated on
+ * the host, 1: counter-based Philox on the device), "flag_topo", "uniform_S" (0 forces the general
+ * S-field kernels), "profile" (HIP-event timing of the finest-level smoother and residual launches).
+ * Implementation switches, all result-preserving in the strict build (defaults in brackets):
+ * "fused" [1] one-pass tendency kernel, "adv_fused" [1] advance folded into it, "rhs_variant" [1],
+ * "rhs_resid" [0] first residual of the next inversion as its by-product, "mg_fused" [1] fused
+ * residual/restriction and correction/residual passes, "prolong_fused" [1], "mg_coarse" [1] coarse levels
+ * in one launch, "block_sweeps" [0] temporally blocked smoother, "agglomerate" [1] / "agg_size" [256]
+ * gathered coarse levels of tiled runs, "mg_global_sum" [0]; "rhs_dbg", "block_variant": timing
+ * experiments of tools/. */
 int msom_set_option(msom_t *m, const char *key, double value);
 /* parsed / derived parameters: N nx ny nl L0 DT iRe iRe4 CFL Rom tend dtout beta tau0 Ekb Eks
  * sbc idh0_<l> idh1_<l> Fr_<l> dh_<l> nlevels */
