@@ -398,32 +398,58 @@ extern "C" int msom_dbg_rccl_selftest(void) {
   if (r) return r;
   ncclUniqueId id;
   NCCLCHK(g_rccl.GetUniqueId(&id));
-  hipStream_t st;
+  // same stream set-up as a tiled model: compute stream + high-priority non-blocking communication stream,
+  // ordered by event pairs; all transport calls on the communication stream
+  hipStream_t st, st2;
+  hipEvent_t e1, e2;
+  int lo = 0, hi = 0;
   HIPCHKC(hipStreamCreate(&st));
+  HIPCHKC(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  HIPCHKC(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, hi));
+  HIPCHKC(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+  HIPCHKC(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
   Comm c;
-  c.kind = COMM_RCCL; c.rank = 0; c.n = 1; c.st = st;
+  c.kind = COMM_RCCL; c.rank = 0; c.n = 1; c.st = st2;
   NCCLCHK(g_rccl.CommInitRank(&c.nccl, 1, id, 0));
   const int n = 1000;
-  double *d = nullptr;
+  double *d = nullptr, *busy = nullptr;
+  const size_t nbusy = (size_t)32 << 20;
   HIPCHKC(hipMalloc(&d, 6 * n * sizeof(double)));
+  HIPCHKC(hipMalloc(&busy, nbusy * sizeof(double)));
   std::vector<double> h(6 * n, 0.);
   for (int k = 0; k < 2 * n; k++) h[k] = 1.5 * k - 7.;
-  HIPCHKC(hipMemcpyAsync(d, h.data(), 6 * n * sizeof(double), hipMemcpyHostToDevice, st));
-  Xfer x[2] = {{0, DIR_W, d, d + 2 * n, (size_t)n}, {0, DIR_E, d + n, d + 3 * n, (size_t)n}};
-  if ((r = comm_exchange(&c, x, 2))) return r;
-  if ((r = comm_allgather(&c, d, d + 4 * n, n))) return r;
-  double hs[2];
-  if ((r = comm_allreduce(&c, d + 1, hs, 2, RED_MAX))) return r;
-  if ((r = comm_allreduce(&c, d + 1, hs, 2, RED_SUM))) return r;
-  HIPCHKC(hipMemcpyAsync(h.data(), d, 6 * n * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHKC(hipStreamSynchronize(st));
   int bad = 0;
-  for (int k = 0; k < 2 * n; k++) bad += h[2 * n + k] != 1.5 * k - 7.;
-  for (int k = 0; k < n; k++) bad += h[4 * n + k] != 1.5 * k - 7.;
-  bad += hs[0] != 1.5 * 1 - 7. || hs[1] != 1.5 * 2 - 7.;
+  for (int rep = 0; rep < 3 && !bad; rep++) {
+    HIPCHKC(hipMemcpyAsync(d, h.data(), 6 * n * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHKC(hipEventRecord(e1, st));              // comm_begin
+    HIPCHKC(hipStreamWaitEvent(st2, e1, 0));
+    Xfer x[2] = {{0, DIR_W, d, d + 2 * n, (size_t)n}, {0, DIR_E, d + n, d + 3 * n, (size_t)n}};
+    if ((r = comm_exchange(&c, x, 2))) return r;
+    HIPCHKC(hipMemsetAsync(busy, rep, nbusy * sizeof(double), st));  // "interior" work beside the exchange
+    if ((r = comm_allgather(&c, d, d + 4 * n, n))) return r;
+    HIPCHKC(hipEventRecord(e2, st2));             // comm_end
+    HIPCHKC(hipStreamWaitEvent(st, e2, 0));
+    double hs[2];
+    HIPCHKC(hipEventRecord(e1, st));
+    HIPCHKC(hipStreamWaitEvent(st2, e1, 0));
+    if ((r = comm_allreduce(&c, d + 1, hs, 2, RED_MAX))) return r;
+    if ((r = comm_allreduce(&c, d + 1, hs, 2, RED_SUM))) return r;
+    HIPCHKC(hipEventRecord(e2, st2));
+    HIPCHKC(hipStreamWaitEvent(st, e2, 0));
+    std::vector<double> out(6 * n, 0.);
+    HIPCHKC(hipMemcpyAsync(out.data(), d, 6 * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHKC(hipStreamSynchronize(st));
+    for (int k = 0; k < 2 * n; k++) bad += out[2 * n + k] != 1.5 * k - 7.;
+    for (int k = 0; k < n; k++) bad += out[4 * n + k] != 1.5 * k - 7.;
+    bad += hs[0] != 1.5 * 1 - 7. || hs[1] != 1.5 * 2 - 7.;
+  }
   g_rccl.CommDestroy(c.nccl);
   c.nccl = nullptr;
   (void)hipFree(d);
+  (void)hipFree(busy);
+  (void)hipEventDestroy(e1);
+  (void)hipEventDestroy(e2);
+  (void)hipStreamDestroy(st2);
   (void)hipStreamDestroy(st);
   if (bad) { msom_set_error("RCCL self-test: %d wrong values", bad); return MSOM_ERR_COMM; }
   return MSOM_OK;

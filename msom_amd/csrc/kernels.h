@@ -102,7 +102,9 @@ void launch_residual2(hipStream_t st, int mode, const double *a, const double *d
 void launch_restrict(hipStream_t st, const double *fine, const SplitGeom &fg, double *coarse, const SplitGeom &cg, int nl);
 void launch_prolong(hipStream_t st, const double *coarse, const SplitGeom &cg, double *fine, const SplitGeom &fg, int nl, int walls);
 void launch_relax_color(hipStream_t st, double *da, const double *res, const double *S, const SplitGeom &sg, int nl, const RelaxCoef &rc,
-                        int uniformS, int color, int walls, int fine);
+                        int uniformS, int color, int walls, int fine, int region = 0);
+void launch_relax_ring(hipStream_t st, double *da, const double *res, const double *S, const SplitGeom &sg, int nl, const RelaxCoef &rc,
+                       int uniformS, int color, int walls);
 void launch_relax_block2(hipStream_t st, const double *da_in, const double *coarse, const SplitGeom &cg, const double *res, double *da_out,
                          const SplitGeom &sg, int nl, const RelaxCoef &rc, int walls, int fine);
 void launch_relax_red_prolong(hipStream_t st, double *da, const double *coarse, const SplitGeom &cg, const double *res, const double *S,

@@ -605,6 +605,8 @@ struct RelaxArgs {
   const double *res, *S;
   SplitGeom g;
   int color, walls;
+  int region;  // 0: all cells of the colour, 1: all but the outermost ring of the tile (the ring goes first, k_relax_ring,
+               // so that its halo exchange overlaps this launch)
   RelaxCoef rc;
 };
 
@@ -617,6 +619,23 @@ template <int NL, bool UNIFORM, bool FINE>
 __global__ void __launch_bounds__(BX *BY) k_relax_color(RelaxArgs p) {
   const int kx = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
   if (kx >= p.g.hk || j >= p.g.ny) return;
+  if (p.region == 1) {
+    const int i = 2 * kx + ((j + p.color) & 1);
+    if (i == 0 || i == p.g.nx - 1 || j == 0 || j == p.g.ny - 1) return;
+  }
+  relax_color_pt<NL, UNIFORM>(p, kx, j);
+}
+// the outermost ring of the tile, colour p.color: rows 0 and ny-1 (hk cells each) and, on every other row,
+// the one end cell that has this colour (i = 0 has x parity 0, i = nx-1 parity 1)
+template <int NL, bool UNIFORM>
+__global__ void __launch_bounds__(256) k_relax_ring(RelaxArgs p) {
+  const int t = blockIdx.x * 256 + threadIdx.x, hk = p.g.hk, ny = p.g.ny;
+  int kx, j;
+  if (t < hk) { kx = t; j = 0; }
+  else if (t < 2 * hk) { kx = t - hk; j = ny - 1; }
+  else if (t < 2 * hk + ny - 2) { j = 1 + t - 2 * hk; kx = ((j + p.color) & 1) ? hk - 1 : 0; }
+  else return;
+  if (ny == 1 && t >= hk) return;
   relax_color_pt<NL, UNIFORM>(p, kx, j);
 }
 template <int NL, bool UNIFORM>
@@ -689,6 +708,7 @@ template <int NL, bool UNIFORM, bool FINE>
 __global__ void __launch_bounds__(BX *BY) k_relax_color_x2(RelaxArgs p) {
   const int kx = 2 * (blockIdx.x * BX + threadIdx.x), j = blockIdx.y * BY + threadIdx.y;
   if (kx >= p.g.hk || j >= p.g.ny) return;
+  if (p.region == 1 && (j == 0 || j == p.g.ny - 1)) return;
   const int px = (j + p.color) & 1;
   const int i = 2 * kx + px;  // x of the first point; the second is i + 2
   const int hp = p.g.hp, rp = p.g.rp;
@@ -755,10 +775,18 @@ __global__ void __launch_bounds__(BX *BY) k_relax_color_x2(RelaxArgs p) {
       }
     }
   }
+  if (p.region == 1 && (i == 0 || i + 2 == p.g.nx - 1)) {  // one cell of the pair is on the ring: store the other one only
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      if (i == 0) p.da[own + 1 + l * ls] = xb[l];
+      else p.da[own + l * ls] = xa[l];
+    }
+    return;
+  }
 #pragma unroll
   for (int l = 0; l < NL; l++) *reinterpret_cast<double2 *>(p.da + own + l * ls) = make_double2(xa[l], xb[l]);
   const bool edge = (i == 0) | (i + 2 >= p.g.nx - 1) | (j == 0) | (j == p.g.ny - 1);
-  if (edge && p.walls) {
+  if (edge && p.walls && p.region == 0) {
 #pragma unroll
     for (int l = 0; l < NL; l++) {
       split_write_ghosts(p.da, p.g, l, j, i, xa[l], p.walls);
@@ -1064,7 +1092,7 @@ __global__ void __launch_bounds__(MGC_NT) k_mg_coarse(const CoarseArgs *pa, int 
           for (int t = tid; t < L.g.hk * nj; t += MGC_NT) red_prolong2_pt<NL, UNIFORM>(p, t % L.g.hk, t / L.g.hk);
         } else {
           RelaxArgs p;
-          p.da = L.da; p.res = L.res; p.S = L.S; p.g = L.g; p.color = c; p.walls = a.walls; p.rc = L.rc;
+          p.da = L.da; p.res = L.res; p.S = L.S; p.g = L.g; p.color = c; p.walls = a.walls; p.rc = L.rc; p.region = 0;
           for (int t = tid; t < L.g.hk * L.g.ny; t += MGC_NT) relax_color_pt<NL, UNIFORM>(p, t % L.g.hk, t / L.g.hk);
         }
         __syncthreads();
@@ -1153,10 +1181,32 @@ static void relax_dispatch(hipStream_t st, const RelaxArgs &p, int uniformS, int
     else hipLaunchKernelGGL((k_relax_color<NL, false, false>), gr, block2d(), 0, st, p);
   }
 }
-void launch_relax_color(hipStream_t st, double *da, const double *res, const double *S, const SplitGeom &sg, int nl, const RelaxCoef &rc,
-                        int uniformS, int color, int walls, int fine) {
+template <int NL>
+static void relax_ring_dispatch(hipStream_t st, const RelaxArgs &p, int uniformS) {
+  const int n = 2 * p.g.hk + p.g.ny - 2;
+  if (uniformS) hipLaunchKernelGGL((k_relax_ring<NL, true>), dim3((n + 255) / 256), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_relax_ring<NL, false>), dim3((n + 255) / 256), dim3(256), 0, st, p);
+}
+void launch_relax_ring(hipStream_t st, double *da, const double *res, const double *S, const SplitGeom &sg, int nl, const RelaxCoef &rc,
+                       int uniformS, int color, int walls) {
   RelaxArgs p;
-  p.da = da; p.res = res; p.S = S; p.g = sg; p.color = color; p.walls = walls; p.rc = rc;
+  p.da = da; p.res = res; p.S = S; p.g = sg; p.color = color; p.walls = walls; p.rc = rc; p.region = 0;
+  switch (nl) {
+    case 1: relax_ring_dispatch<1>(st, p, uniformS); break;
+    case 2: relax_ring_dispatch<2>(st, p, uniformS); break;
+    case 3: relax_ring_dispatch<3>(st, p, uniformS); break;
+    case 4: relax_ring_dispatch<4>(st, p, uniformS); break;
+    case 5: relax_ring_dispatch<5>(st, p, uniformS); break;
+    case 6: relax_ring_dispatch<6>(st, p, uniformS); break;
+    case 7: relax_ring_dispatch<7>(st, p, uniformS); break;
+    case 8: relax_ring_dispatch<8>(st, p, uniformS); break;
+    default: break;
+  }
+}
+void launch_relax_color(hipStream_t st, double *da, const double *res, const double *S, const SplitGeom &sg, int nl, const RelaxCoef &rc,
+                        int uniformS, int color, int walls, int fine, int region) {
+  RelaxArgs p;
+  p.da = da; p.res = res; p.S = S; p.g = sg; p.color = color; p.walls = walls; p.rc = rc; p.region = region;
   switch (nl) {
     case 1: relax_dispatch<1>(st, p, uniformS, fine); break;
     case 2: relax_dispatch<2>(st, p, uniformS, fine); break;

@@ -85,6 +85,12 @@ struct msom {
   double umax_pg[MSOM_MAXNL];
   int umax_ready = 0;  // h_scal[SC_UMAX..] holds max|u| of the current psi (from the last solve)
   hipStream_t st = nullptr;
+  // tiled runs: every transport call (RCCL / LOCAL), with its pack and unpack kernels, is issued on the
+  // communication stream st2 (higher priority); event pairs order it against the compute stream st, so a
+  // halo exchange can run beside an interior kernel launched in between (option "overlap")
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_c2x = nullptr, ev_x2c = nullptr;
+  int overlap = 1;
   // flags
   int const_set = 0, flag_topo = 0, have_pg = 0, have_zpg = 0, have_qforc = 0;
   int fr_uniform = 1, uniformS = 0, uniform_opt = -1 /* auto */;
@@ -191,9 +197,24 @@ static const int OPP[8] = {DIR_E, DIR_W, DIR_N, DIR_S, DIR_NE, DIR_NW, DIR_SE, D
 // both ends of a neighbour pair label their message with the same axis id
 #define AXIS(dir) ((dir) < OPP[dir] ? (dir) : OPP[dir])
 
+// communication stream <-> compute stream ordering (tiled runs)
+static void comm_begin(msom *m) {  // st2 continues after everything queued on st so far
+  hipEventRecord(m->ev_c2x, m->st);
+  hipStreamWaitEvent(m->st2, m->ev_c2x, 0);
+}
+static void comm_end(msom *m) {    // st continues after everything queued on st2 so far
+  hipEventRecord(m->ev_x2c, m->st2);
+  hipStreamWaitEvent(m->st, m->ev_x2c, 0);
+}
+
 // all-reduce n device scalars starting at `slot` over the tiles; result in h_scal (and d_scal)
 static int reduce_scal(msom *m, int slot, int n, int op) {
-  if (m->nranks > 1) return comm_allreduce(m->comm, m->d_scal + slot, m->h_scal + slot, n, op);
+  if (m->nranks > 1) {
+    comm_begin(m);
+    const int r = comm_allreduce(m->comm, m->d_scal + slot, m->h_scal + slot, n, op);
+    comm_end(m);
+    return r;
+  }
   HIPCHK(hipMemcpyAsync(m->h_scal + slot, m->d_scal + slot, n * sizeof(double), hipMemcpyDeviceToHost, m->st));
   HIPCHK(hipStreamSynchronize(m->st));
   return MSOM_OK;
@@ -205,46 +226,50 @@ static int reduce_scal(msom *m, int slot, int n, int op) {
 static int exch_nat(msom *m, double *f, int nl, int bc, int depth) {
   const NatGeom &g = m->g;
   const int d = depth;
+  hipStream_t cs = m->nranks > 1 ? m->st2 : m->st;  // packs, wall BCs and unpacks ride on the communication stream
+  if (m->nranks > 1) comm_begin(m);
   if (m->nranks > 1) {
     Xfer x[2];
     int n = 0;
     for (int dir : {DIR_W, DIR_E}) {
       if (m->nb[dir] < 0) continue;
-      launch_nat_pack_strip(m->st, f, g, nl, dir == DIR_W ? 0 : g.nx - d, 0, d, g.ny, comm_sendbuf(m->comm, dir));
+      launch_nat_pack_strip(cs, f, g, nl, dir == DIR_W ? 0 : g.nx - d, 0, d, g.ny, comm_sendbuf(m->comm, dir));
       x[n++] = {m->nb[dir], AXIS(dir), comm_sendbuf(m->comm, dir), comm_recvbuf(m->comm, dir), (size_t)d * g.ny * nl};
     }
     int r = comm_exchange(m->comm, x, n);
-    if (r) return r;
+    if (r) { comm_end(m); return r; }
     for (int dir : {DIR_W, DIR_E}) {
       if (m->nb[dir] < 0) continue;
-      launch_nat_unpack_strip(m->st, f, g, nl, dir == DIR_W ? -d : g.nx, 0, d, g.ny, comm_recvbuf(m->comm, dir));
+      launch_nat_unpack_strip(cs, f, g, nl, dir == DIR_W ? -d : g.nx, 0, d, g.ny, comm_recvbuf(m->comm, dir));
     }
   }
-  launch_fill_ghost(m->st, f, g, nl, bc, m->walls, d);
+  launch_fill_ghost(cs, f, g, nl, bc, m->walls, d);
   if (m->nranks > 1) {
     Xfer x[2];
     int n = 0;
     const int w = g.nx + 2 * d;
     for (int dir : {DIR_S, DIR_N}) {
       if (m->nb[dir] < 0) continue;
-      launch_nat_pack_strip(m->st, f, g, nl, -d, dir == DIR_S ? 0 : g.ny - d, w, d, comm_sendbuf(m->comm, dir));
+      launch_nat_pack_strip(cs, f, g, nl, -d, dir == DIR_S ? 0 : g.ny - d, w, d, comm_sendbuf(m->comm, dir));
       x[n++] = {m->nb[dir], AXIS(dir), comm_sendbuf(m->comm, dir), comm_recvbuf(m->comm, dir), (size_t)d * w * nl};
     }
     int r = comm_exchange(m->comm, x, n);
-    if (r) return r;
+    if (r) { comm_end(m); return r; }
     for (int dir : {DIR_S, DIR_N}) {
       if (m->nb[dir] < 0) continue;
-      launch_nat_unpack_strip(m->st, f, g, nl, -d, dir == DIR_S ? -d : g.ny, w, d, comm_recvbuf(m->comm, dir));
+      launch_nat_unpack_strip(cs, f, g, nl, -d, dir == DIR_S ? -d : g.ny, w, d, comm_recvbuf(m->comm, dir));
     }
   }
+  if (m->nranks > 1) comm_end(m);
   return MSOM_OK;
 }
 
 // halo exchange (depth 1) of a multigrid field in split layout.  corners = 0: the 4 face
 // neighbours in one phase (enough for the 5-point smoother); corners = 1: two phases so that
 // the corner ghosts needed by the bilinear prolongation are valid.
-static int exch_split(msom *m, double *f, const SplitGeom &sg, int nl, int corners) {
-  if (m->nranks == 1) return MSOM_OK;
+// everything on the communication stream; the caller orders it against the compute stream
+static int exch_split_raw(msom *m, double *f, const SplitGeom &sg, int nl, int corners) {
+  hipStream_t cs = m->st2;
   Xfer x[4];
   int n = 0;
   if (!corners) {  // one pack launch, one message per neighbour, one unpack launch
@@ -255,14 +280,14 @@ static int exch_split(msom *m, double *f, const SplitGeom &sg, int nl, int corne
       rb[dir] = on ? comm_recvbuf(m->comm, dir) : nullptr;
       if (on) x[n++] = {m->nb[dir], AXIS(dir), sb[dir], rb[dir], (size_t)nl * (dir == DIR_W || dir == DIR_E ? sg.ny : sg.nx)};
     }
-    launch_split_pack_faces(m->st, f, sg, nl, sb);
+    launch_split_pack_faces(cs, f, sg, nl, sb);
     int r = comm_exchange(m->comm, x, n);
     if (r) return r;
-    launch_split_unpack_faces(m->st, f, sg, nl, rb);
+    launch_split_unpack_faces(cs, f, sg, nl, rb);
     return MSOM_OK;
   }
   auto pack = [&](int dir, int i0, int j0, int w, int h) {
-    launch_split_pack_strip(m->st, f, sg, nl, i0, j0, w, h, comm_sendbuf(m->comm, dir));
+    launch_split_pack_strip(cs, f, sg, nl, i0, j0, w, h, comm_sendbuf(m->comm, dir));
     x[n++] = {m->nb[dir], AXIS(dir), comm_sendbuf(m->comm, dir), comm_recvbuf(m->comm, dir), (size_t)w * h * nl};
   };
   const int x0 = -1, xw = sg.nx + 2;
@@ -270,23 +295,37 @@ static int exch_split(msom *m, double *f, const SplitGeom &sg, int nl, int corne
   if (m->nb[DIR_E] >= 0) pack(DIR_E, sg.nx - 1, 0, 1, sg.ny);
   int r = comm_exchange(m->comm, x, n);
   if (r) return r;
-  if (m->nb[DIR_W] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, -1, 0, 1, sg.ny, comm_recvbuf(m->comm, DIR_W));
-  if (m->nb[DIR_E] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, sg.nx, 0, 1, sg.ny, comm_recvbuf(m->comm, DIR_E));
-  launch_split_wall_corners(m->st, f, sg, nl, m->walls);
+  if (m->nb[DIR_W] >= 0) launch_split_unpack_strip(cs, f, sg, nl, -1, 0, 1, sg.ny, comm_recvbuf(m->comm, DIR_W));
+  if (m->nb[DIR_E] >= 0) launch_split_unpack_strip(cs, f, sg, nl, sg.nx, 0, 1, sg.ny, comm_recvbuf(m->comm, DIR_E));
+  launch_split_wall_corners(cs, f, sg, nl, m->walls);
   n = 0;
   if (m->nb[DIR_S] >= 0) pack(DIR_S, x0, 0, xw, 1);
   if (m->nb[DIR_N] >= 0) pack(DIR_N, x0, sg.ny - 1, xw, 1);
   if ((r = comm_exchange(m->comm, x, n))) return r;
-  if (m->nb[DIR_S] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, x0, -1, xw, 1, comm_recvbuf(m->comm, DIR_S));
-  if (m->nb[DIR_N] >= 0) launch_split_unpack_strip(m->st, f, sg, nl, x0, sg.ny, xw, 1, comm_recvbuf(m->comm, DIR_N));
-  launch_split_wall_corners(m->st, f, sg, nl, m->walls);
+  if (m->nb[DIR_S] >= 0) launch_split_unpack_strip(cs, f, sg, nl, x0, -1, xw, 1, comm_recvbuf(m->comm, DIR_S));
+  if (m->nb[DIR_N] >= 0) launch_split_unpack_strip(cs, f, sg, nl, x0, sg.ny, xw, 1, comm_recvbuf(m->comm, DIR_N));
+  launch_split_wall_corners(cs, f, sg, nl, m->walls);
   return MSOM_OK;
+}
+static int exch_split(msom *m, double *f, const SplitGeom &sg, int nl, int corners) {
+  if (m->nranks == 1) return MSOM_OK;
+  comm_begin(m);
+  const int r = exch_split_raw(m, f, sg, nl, corners);
+  comm_end(m);
+  return r;
 }
 
 // ------------------------------------------------------------------ lifecycle
 
 static int alloc_all(msom *m) {
   HIPCHK(hipStreamCreate(&m->st));
+  if (m->nranks > 1) {
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(hipStreamCreateWithPriority(&m->st2, hipStreamNonBlocking, hi));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_c2x, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_x2c, hipEventDisableTiming));
+  }
   m->g = make_nat(m->nx, m->ny);
   for (int k = 0; k < MSOM_NFIELDS; k++) {
     m->f[k] = nullptr;
@@ -434,7 +473,7 @@ static msom *create_common(const Params &p0, int px, int py, int rank, const voi
     }
   }
   if (alloc_all(m) != MSOM_OK ||
-      (m->nranks > 1 && comm_create(&m->comm, rank, m->nranks, id128, m->st,
+      (m->nranks > 1 && comm_create(&m->comm, rank, m->nranks, id128, m->st2,
                                     (size_t)3 * ((m->nx > m->ny ? m->nx : m->ny) + 6) * m->nl) != MSOM_OK) ||
       set_vars(m) != MSOM_OK) {
     msom_destroy(m);
@@ -496,6 +535,9 @@ extern "C" int msom_destroy(msom_t *m) {
   for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block})
     for (auto e : ps->ev) hipEventDestroy(e);
   if (m->comm) comm_destroy(m->comm);
+  if (m->ev_c2x) hipEventDestroy(m->ev_c2x);
+  if (m->ev_x2c) hipEventDestroy(m->ev_x2c);
+  if (m->st2) hipStreamDestroy(m->st2);
   if (m->st) hipStreamDestroy(m->st);
   delete m;
   return MSOM_OK;
@@ -529,6 +571,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "rhs_dbg")) { extern int g_rhs_dbg; g_rhs_dbg = (int)v; }
   else if (!strcmp(key, "rhs_variant")) m->rhs_variant = (int)v;
   else if (!strcmp(key, "adv_fused")) m->adv_fused = (int)v;
+  else if (!strcmp(key, "overlap")) m->overlap = (int)v;
   else if (!strcmp(key, "rhs_resid")) { m->rhs_resid = (int)v; m->res_ready = -1; }
   else if (!strcmp(key, "seed")) { m->seed = (unsigned)v; srand(m->seed); }
   else if (!strcmp(key, "noise_mode")) m->noise_mode = (int)v;
@@ -917,13 +960,24 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
     const bool pl = coarse && it == 0;  // prolongation rides in the first red half-sweep
     if (prof && !pl) prof_begin(m, m->prof_sweep);
     for (int c = 0; c < 2; c++) {
+      const int corners = corners_last && it == nrelax - 1 && c == 1;
+      if (L.tiled && m->overlap && !(pl && c == 0) && !corners && L.sg->nx >= 32 && L.sg->ny >= 8) {
+        // the outermost ring of the tile first; its halo exchange (communication stream) then runs beside the
+        // interior cells (compute stream); same per-cell arithmetic, so the result does not change
+        launch_relax_ring(m->st, *L.da, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, c, L.walls);
+        comm_begin(m);
+        STICKY(m, exch_split_raw(m, *L.da, *L.sg, nl, 0));
+        launch_relax_color(m->st, *L.da, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, c, L.walls, L.fine, 1);
+        comm_end(m);
+        continue;
+      }
       if (pl && c == 0)
         launch_relax_red_prolong(m->st, *L.da, *coarse->da, *coarse->sg, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, L.walls);
       else
         launch_relax_color(m->st, *L.da, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, c, L.walls, L.fine);
       // boundary_level(da, l): the last exchange of the level also carries the corner ghosts
       // that the bilinear prolongation to the next finer level reads
-      if (L.tiled) STICKY(m, exch_split(m, *L.da, *L.sg, nl, corners_last && it == nrelax - 1 && c == 1));
+      if (L.tiled) STICKY(m, exch_split(m, *L.da, *L.sg, nl, corners));
     }
     if (prof && !pl) prof_end(m, m->prof_sweep);
   }
@@ -959,7 +1013,9 @@ static void mg_cycle_levels(msom *m, int nrelax, int first_restrict) {
     const SplitGeom &tg = m->sg[kc];
     const size_t cnt = (size_t)nl * tg.nx * tg.ny;
     launch_split_unpack(m->st, m->res[kc], tg, m->agg_send, nl);
+    comm_begin(m);
     STICKY(m, comm_allgather(m->comm, m->agg_send, m->agg_recv, cnt));
+    comm_end(m);
     launch_assemble_global(m->st, m->agg_recv, m->gres[0], m->gsg[0], nl, tg.nx, tg.ny, m->px);
     const int gtop = kg >= 0 ? kg : m->nlev - 1;  // coarsest level restricted by its own launch
     for (int k = kc + 1; k <= gtop; k++) launch_restrict(m->st, m->gres[k - 1 - kc], m->gsg[k - 1 - kc], m->gres[k - kc], m->gsg[k - kc], nl);
