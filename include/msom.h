@@ -244,7 +244,7 @@ typedef struct msomn msomn_t;
 msomn_t *msomn_create(const char *params_path);
 msomn_t *msomn_create_str(const char *params_text);
 void msomn_destroy(msomn_t *m);                                 /* trash_vars qg.h:537-544 */
-/* keys: TOLERANCE NITERMAX NITERMIN (nodal-poisson.h:19-23) DT quiet */
+/* keys: TOLERANCE NITERMAX NITERMIN (nodal-poisson.h:19-23) DT quiet stochastic seed tiled_relax */
 int msomn_set_option(msomn_t *m, const char *key, double value);
 /* keys: N nl L0 DT tend dtout nlevels iRd2_low bc_fac idh0_<l> idh1_<l>; NaN if unknown */
 double msomn_get_param(msomn_t *m, const char *key);
@@ -287,6 +287,12 @@ int msomn_dbg_restrict(msomn_t *m, int level_fine, const double *fine, double *c
 int msomn_dbg_prolong(msomn_t *m, int level_coarse, const double *coarse, double *fine);
 int msomn_dbg_level_mask(msomn_t *m, int level, double *out);
 int msomn_dbg_del2_zeta(msomn_t *m);
+/* stochastic forcing of the vertex model (-D_STOCHASTIC: qg-node/qg_stochastic.h, qg-node/qg.h:306-320; params keys
+ * amp_stoch, L_filt; option "stochastic" before msomn_set_const, option "seed" = srand).  The noise is a CELL
+ * scalar (N x N), wavelet-filtered with the coefficients of the uniform length L_filt.  msomn_dbg_noise: optionally
+ * set n_stoch, optionally filter it, optionally read it back; msomn_dbg_csig: sig_lev of one level. */
+int msomn_dbg_noise(msomn_t *m, const double *set, int filter, double *get);
+int msomn_dbg_csig(msomn_t *m, int level, double *out);
 
 #ifdef __cplusplus
 }

@@ -128,6 +128,8 @@ def load_library(strict=False):
         "msomn_dbg_prolong": (ci, [vp, ci, vp, vp]),
         "msomn_dbg_level_mask": (ci, [vp, ci, vp]),
         "msomn_dbg_del2_zeta": (ci, [vp]),
+        "msomn_dbg_noise": (ci, [vp, vp, ci, vp]),
+        "msomn_dbg_csig": (ci, [vp, ci, vp]),
     }
     for fn, (res, args) in sig.items():
         f = getattr(L, fn)  # AttributeError if the library does not export a declared symbol
@@ -609,3 +611,16 @@ class NodeQG:
 
     def dbg_del2_zeta(self):
         self._chk(self.L.msomn_dbg_del2_zeta(self.h))
+
+    # stochastic forcing (cell scalars)
+    def noise(self, set=None, filter=False):
+        out = np.empty((self.N, self.N))
+        a = None if set is None else _f64(set, (self.N, self.N))
+        self._chk(self.L.msomn_dbg_noise(self.h, _ptr(a), int(filter), _ptr(out)))
+        return out
+
+    def csig(self, k):
+        n = self.N >> k
+        out = np.empty((n, n))
+        self._chk(self.L.msomn_dbg_csig(self.h, k, _ptr(out)))
+        return out

@@ -535,3 +535,13 @@ void launch_n_ke(hipStream_t st, const double *psi, double *partial, double *out
   hipLaunchKernelGGL(k_n_ke, gr, block2d(), 0, st, psi, partial, g, D * D, 1. / (D * D));
   launch_sum_final(st, partial, out, (int)(gr.x * gr.y));
 }
+
+// stochastic forcing, qg-node/qg.h:316-317: q_0[vertex (i, j)] += n_stoch[cell (i, j)] * dts; the cell field has N x N
+// cells, vertices i, j = N read its ghost cells
+__global__ void k_n_add_noise(double *q, const double *__restrict__ n, NatGeom g, NatGeom cg, double dts) {
+  VTX(g, i, j);
+  q[nat_idx(g, 0, j, i)] += n[nat_idx(cg, 0, j, i)] * dts;
+}
+void launch_n_add_noise(hipStream_t st, double *q, const double *n, const NatGeom &g, const NatGeom &cg, double dts) {
+  hipLaunchKernelGGL(k_n_add_noise, grid2d(g.nx, g.ny), block2d(), 0, st, q, n, g, cg, dts);
+}

@@ -42,6 +42,10 @@ struct msomn {
   double D = 0, psi_bc = 0., iRd2_low = 0.;
   double tolerance = 1e-3;
   int nitermax = 100, nitermin = 1, nrelax = 5, quiet = 0;  // nodal-poisson.h:19-23
+  // stochastic forcing (-D_STOCHASTIC of the reference): cell-scalar noise n_stoch, wavelet-filtered (qg-node/qg_stochastic.h)
+  int stochastic = 0, corrector_step = 0, cnlev = 0;
+  std::vector<NatGeom> cg;
+  std::vector<double *> cs, cr, csig;  // cs[0] = n_stoch
   int tiled_relax = 0;  // option: LDS-tiled smoother passes (1-2 sweeps per pass) on the wide levels; measured 3 % faster at 4097^2 x 3, 7 % slower at 2049^2 x 3
   NatGeom g;
   double *f[MSOMN_NFIELDS] = {nullptr};
@@ -101,6 +105,11 @@ extern "C" void msomn_destroy(msomn_t *m) {
     if (m->lev[k].res) (void)hipFree(m->lev[k].res);
     if (k > 0 && m->lev[k].mask) (void)hipFree(m->lev[k].mask);
     if (k > 0 && m->lev[k].S2) (void)hipFree(m->lev[k].S2);
+  }
+  for (size_t k = 0; k < m->cs.size(); k++) {
+    if (m->cs[k]) (void)hipFree(m->cs[k]);
+    if (m->cr[k]) (void)hipFree(m->cr[k]);
+    if (m->csig[k]) (void)hipFree(m->csig[k]);
   }
   if (m->d_scal) (void)hipFree(m->d_scal);
   if (m->partial) (void)hipFree(m->partial);
@@ -202,6 +211,8 @@ extern "C" int msomn_set_option(msomn_t *m, const char *key, double v) {
   else if (!strcmp(key, "DT")) m->p.DT = v;
   else if (!strcmp(key, "quiet")) m->quiet = (int)v;
   else if (!strcmp(key, "tiled_relax")) m->tiled_relax = (int)v;
+  else if (!strcmp(key, "stochastic")) m->stochastic = (int)v;
+  else if (!strcmp(key, "seed")) srand((unsigned)v);
   else { msom_set_error("unknown option %s", key); return MSOM_ERR_ARG; }
   return MSOM_OK;
 }
@@ -372,6 +383,121 @@ static int adjust_dt(msomn *m, double dtmax, double *out) {
   return MSOM_OK;
 }
 
+// ---- stochastic forcing: qg-node/qg_stochastic.h (init_stoch :15-47, generate_noise :49-65), advance qg-node/qg.h:306-320
+static NatGeom cell_geom(int n) {
+  NatGeom g;
+  g.nx = g.ny = n;
+  g.pitch = ((n + 15) / 16) * 16 + 2 * MSOM_XP;
+  g.rows = n + 2 * MSOM_YP;
+  g.ls = (size_t)g.pitch * g.rows;
+  return g;
+}
+static int stoch_setup(msomn *m) {  // pyramids of the cell scalar + wavelet coefficients of the uniform filter length L_filt
+  const NodeParams &p = m->p;
+  int r;
+  if (m->cnlev == 0) {
+    int c = 1;
+    while ((m->N >> c) >= 1) c++;
+    m->cnlev = c;
+    m->cg.resize(c); m->cs.assign(c, nullptr); m->cr.assign(c, nullptr); m->csig.assign(c, nullptr);
+    for (int k = 0; k < c; k++) {
+      m->cg[k] = cell_geom(m->N >> k);
+      if ((r = dalloc(&m->cs[k], m->cg[k].ls)) || (r = dalloc(&m->cr[k], m->cg[k].ls)) || (r = dalloc(&m->csig[k], m->cg[k].ls))) return r;
+    }
+  }
+  const int K = m->cnlev;
+  std::vector<std::vector<double>> sl(K);
+  for (int k = 0; k < K; k++) {  // low pass from the finest level down
+    const int n = m->N >> k, fx = 2 * n;
+    const double Delta = p.L0 / n;
+    sl[k].resize((size_t)n * n);
+    for (int j = 0; j < n; j++)
+      for (int i = 0; i < n; i++) {
+        double ref_flag = 0;
+        if (k > 0) {
+          ref_flag += sl[k - 1][(size_t)(2 * j) * fx + 2 * i]; ref_flag += sl[k - 1][(size_t)(2 * j + 1) * fx + 2 * i];
+          ref_flag += sl[k - 1][(size_t)(2 * j) * fx + 2 * i + 1]; ref_flag += sl[k - 1][(size_t)(2 * j + 1) * fx + 2 * i + 1];
+        }
+        double v;
+        if (ref_flag > 0) v = 1;
+        else if (p.L_filt > 2 * Delta) v = 0;
+        else if (p.L_filt <= 2 * Delta && p.L_filt > Delta) v = 1 - (p.L_filt - Delta) / Delta;
+        else v = 1;
+        sl[k][(size_t)j * n + i] = v;
+      }
+  }
+  for (int k = 0; k < K; k++) {  // high pass, then to the device
+    for (double &v : sl[k]) v = 1 - v;
+    const NatGeom &g = m->cg[k];
+    HIPCHK(hipMemcpy2DAsync(m->csig[k] + nat_idx(g, 0, 0, 0), g.pitch * sizeof(double), sl[k].data(), g.nx * sizeof(double), g.nx * sizeof(double), g.ny,
+                            hipMemcpyHostToDevice, m->st));
+  }
+  HIPCHK(hipStreamSynchronize(m->st));
+  return MSOM_OK;
+}
+static void cell_bc(msomn *m, double *f, const NatGeom &g) { launch_fill_ghost(m->st, f, g, 1, BC_NEUMANN, WALL_ALL); }
+// wavelet -> scale by sig_lev -> inverse wavelet of the cell field cs[0] (kernels_wavelet.hip, one layer, default BC)
+static int cell_wavelet_filter(msomn *m) {
+  const int K = m->cnlev;
+  cell_bc(m, m->cs[0], m->cg[0]);
+  for (int k = 1; k < K; k++) {
+    launch_wv_restrict(m->st, m->cs[k - 1], m->cg[k - 1], m->cs[k], m->cg[k], 1);
+    cell_bc(m, m->cs[k], m->cg[k]);
+  }
+  if (K == 1) launch_wv_root(m->st, m->cs[0], m->csig[0], m->cs[0], m->cg[0], 1);
+  else {
+    launch_wv_root(m->st, m->cs[K - 1], m->csig[K - 1], m->cr[K - 1], m->cg[K - 1], 1);
+    cell_bc(m, m->cr[K - 1], m->cg[K - 1]);
+  }
+  for (int k = K - 2; k >= 0; k--) {
+    double *out = k == 0 ? m->cs[0] : m->cr[k];
+    launch_wv_recon(m->st, m->cs[k], m->cs[k + 1], m->cr[k + 1], m->csig[k], out, m->cg[k], m->cg[k + 1], 1);
+    cell_bc(m, out, m->cg[k]);
+  }
+  HIPCHK(hipGetLastError());
+  return MSOM_OK;
+}
+static int upload_cells(msomn *m, const double *a) {
+  const NatGeom &g = m->cg[0];
+  HIPCHK(hipMemcpy2DAsync(m->cs[0] + nat_idx(g, 0, 0, 0), g.pitch * sizeof(double), a, g.nx * sizeof(double), g.nx * sizeof(double), g.ny, hipMemcpyDefault, m->st));
+  HIPCHK(hipStreamSynchronize(m->st));
+  cell_bc(m, m->cs[0], g);
+  return MSOM_OK;
+}
+// reference-exact noise: Box-Muller on the serial rand() stream in foreach order (x outer, y inner), qg_stochastic.h:13,51-53
+static int generate_noise(msomn *m) {
+  const int N = m->N;
+  std::vector<double> h((size_t)N * N);
+  for (int i = 0; i < N; i++)
+    for (int j = 0; j < N; j++) {
+      const double a = sqrt(-2. * log(((double)(rand()) + 1.) / ((double)(RAND_MAX) + 2.)));
+      h[(size_t)j * N + i] = m->p.amp_stoch * (a * cos(2 * M_PI * rand() / (double)RAND_MAX));
+    }
+  int r = upload_cells(m, h.data());
+  return r ? r : cell_wavelet_filter(m);
+}
+extern "C" int msomn_dbg_noise(msomn_t *m, const double *set, int filter, double *get) {
+  NEED_NCONST(m);
+  if (m->cnlev == 0) { msom_set_error("stochastic forcing is off"); return MSOM_ERR_STATE; }
+  int r;
+  if (set && (r = upload_cells(m, set))) return r;
+  if (filter && (r = cell_wavelet_filter(m))) return r;
+  if (get) {
+    const NatGeom &g = m->cg[0];
+    HIPCHK(hipMemcpy2DAsync(get, g.nx * sizeof(double), m->cs[0] + nat_idx(g, 0, 0, 0), g.pitch * sizeof(double), g.nx * sizeof(double), g.ny, hipMemcpyDefault, m->st));
+  }
+  HIPCHK(hipStreamSynchronize(m->st));
+  return MSOM_OK;
+}
+extern "C" int msomn_dbg_csig(msomn_t *m, int level, double *out) {
+  NEED_NCONST(m);
+  if (level < 0 || level >= m->cnlev || !out) { msom_set_error("bad level %d", level); return MSOM_ERR_ARG; }
+  const NatGeom &g = m->cg[level];
+  HIPCHK(hipMemcpy2DAsync(out, g.nx * sizeof(double), m->csig[level] + nat_idx(g, 0, 0, 0), g.pitch * sizeof(double), g.nx * sizeof(double), g.ny, hipMemcpyDefault, m->st));
+  HIPCHK(hipStreamSynchronize(m->st));
+  return MSOM_OK;
+}
+
 extern "C" int msomn_set_const(msomn_t *m) {
   if (!m) return MSOM_ERR_ARG;
   NodeParams &p = m->p;
@@ -401,6 +527,7 @@ extern "C" int msomn_set_const(msomn_t *m) {
     }
   } else if (p.gp_low != 0.) m->iRd2_low = p.f0 * p.f0 / (p.gp_low * p.dh[nl - 1]);
   if ((r = build_levels(m))) return r;
+  if (m->stochastic && (r = stoch_setup(m))) return r;  // event init_stoch
   bnd_psi(m);
   if (p.nu != 0) p.DT = 0.5 * fmin(p.DT, m->D * m->D / p.nu / 4.);  // qg-node/qg.h:511-512
   if (p.beta != 0) p.DT = fmin(p.DT, 1 / (2. * p.beta * p.L0));
@@ -422,6 +549,18 @@ extern "C" int msomn_update(msomn_t *m, int qf, int dqf, double dtmax, double *d
 extern "C" int msomn_advance(msomn_t *m, int out, int in, int dq, double dt) {
   NEED_FIELD(m, out); NEED_FIELD(m, in); NEED_FIELD(m, dq);
   launch_advance(m->st, m->f[out], m->f[in], m->f[dq], nullptr, m->g, m->nl, dt, 0.);
+  if (m->stochastic) {  // qg-node/qg.h:306-320
+    if (m->cnlev == 0) { msom_set_error("stochastic: call msomn_set_const after switching it on"); return MSOM_ERR_STATE; }
+    m->corrector_step = (m->corrector_step + 1) % 2;
+    double dts = sqrt(dt);
+    if (m->corrector_step) {
+      int r = generate_noise(m);
+      if (r) return r;
+      dts = dts / sqrt(2);  // to get sqrt(dt)/2 (in the predictor step, dt = dt/2)
+    }
+    if (m->nl > 1 && !m->quiet) fprintf(stdout, "Stochastic not ready for multilayer yet \n");
+    launch_n_add_noise(m->st, m->f[out], m->cs[0], m->g, m->cg[0], dts);
+  }
   HIPCHK(hipGetLastError());
   return MSOM_OK;
 }

@@ -45,6 +45,7 @@ struct NodeParams {
   int N, nl, flag_ms;
   double L0, f0, beta, nu, nu4, hEkb, gp_low, scale_topo, tau0, tau1, tf1, tf2, dy_ws, forc_mode, noise_init;
   double Lfmax, Lfmin, fac_filt_Rd, dtflt, bc_fac, DT, tend, dtout, CFL, TOLERANCE, dtdiag;
+  double amp_stoch, L_filt; /* -D_STOCHASTIC keys, qg-node/qg.c:104-107 */
   double dh[MSOM_MAXARR], N2[MSOM_MAXARR];
 };
 /* params.c: restates read_params of qg-node/extra.h:83-116 */

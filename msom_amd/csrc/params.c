@@ -139,7 +139,7 @@ static const keydef NODE_KEYS[] = {
   KN("dy_ws", T_DBL, dy_ws), KN("forc_mode", T_DBL, forc_mode), KN("noise_init", T_DBL, noise_init), KN("Lfmax", T_DBL, Lfmax),
   KN("Lfmin", T_DBL, Lfmin), KN("fac_filt_Rd", T_DBL, fac_filt_Rd), KN("dtflt", T_DBL, dtflt), KN("dh", T_ARR, dh), KN("N2", T_ARR, N2),
   KN("bc_fac", T_DBL, bc_fac), KN("DT", T_DBL, DT), KN("tend", T_DBL, tend), KN("dtout", T_DBL, dtout), KN("CFL", T_DBL, CFL),
-  KN("TOLERANCE", T_DBL, TOLERANCE), KN("dtdiag", T_DBL, dtdiag),
+  KN("TOLERANCE", T_DBL, TOLERANCE), KN("dtdiag", T_DBL, dtdiag), KN("amp_stoch", T_DBL, amp_stoch), KN("L_filt", T_DBL, L_filt),
 };
 /* defaults: qg-node/qg.h:104-127,164; qg.c:61-66; Basilisk globals N = 64, L0 = 1, DT = 1e10, CFL = 0.5, TOLERANCE = 1e-3 */
 void msom_node_params_defaults(struct NodeParams *p) {

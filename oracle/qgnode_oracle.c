@@ -45,6 +45,11 @@ typedef struct {
   double t, dt, tnext_event, previous;
   int iter;
   orn_mgstats mg;
+  /* stochastic forcing (-D_STOCHASTIC): qg-node/qg_stochastic.h, qg-node/qg.h:306-320.  n_stoch and sig_lev are
+   * CELL scalars ("random noise define on scalar instead of vertex in order to use the wavelet transform") */
+  int stochastic, corrector_step, cnlev;
+  double amp_stoch, L_filt;
+  double **cs, **cw, **csig; /* cell pyramids, level k: (N >> k)^2 cells with one ghost ring */
 } orn_t;
 
 static void vf_alloc(vf *f, int n, int nl) { f->n = n; f->nl = nl; f->d = (double *)calloc((size_t)nl * (n + 3) * (n + 3), sizeof(double)); }
@@ -71,7 +76,7 @@ orn_t *orn_create_str(const char *text) {
     KI("N", N); KI("nl", nl); KI("flag_ms", flag_ms); KD("L0", L0); KD("f0", f0); KD("beta", beta); KD("nu", nu); KD("nu4", nu4);
     KD("hEkb", hEkb); KD("gp_low", gp_low); KD("scale_topo", scale_topo); KD("tau0", tau0); KD("tau1", tau1); KD("tf1", tf1);
     KD("tf2", tf2); KD("dy_ws", dy_ws); KD("forc_mode", forc_mode); KD("noise_init", noise_init); KD("bc_fac", bc_fac); KD("DT", DT);
-    KD("tend", tend); KD("dtout", dtout); KD("CFL", CFL); KD("TOLERANCE", TOLERANCE);
+    KD("tend", tend); KD("dtout", dtout); KD("CFL", CFL); KD("TOLERANCE", TOLERANCE); KD("amp_stoch", amp_stoch); KD("L_filt", L_filt);
     else if (!strcmp(k, "dh")) arr(v, o->dh);
     else if (!strcmp(k, "N2")) arr(v, o->N2);
   }
@@ -88,18 +93,25 @@ orn_t *orn_create_str(const char *text) {
   for (int j = 0; j <= N; j++) for (int i = 0; i <= N; i++) W(mk, 0, i, j) = (i == 0 || i == N || j == 0 || j == N) ? 0. : 1.;
   /* S2[] = N2[l] (qg_baroclinic_ms.h:471-476) */
   for (int l = 0; l < nl - 1; l++) for (int j = 0; j <= N; j++) for (int i = 0; i <= N; i++) W(&o->f[ORN_S2], l, i, j) = o->N2[l];
+  { int c = 1; while ((N >> c) >= 1) c++; o->cnlev = c; /* Basilisk levels depth() ... 0 */
+    o->cs = (double **)calloc(c, sizeof(double *)); o->cw = (double **)calloc(c, sizeof(double *)); o->csig = (double **)calloc(c, sizeof(double *));
+    for (int k = 0; k < c; k++) { size_t sz = (size_t)((N >> k) + 2) * ((N >> k) + 2);
+      o->cs[k] = (double *)calloc(sz, sizeof(double)); o->cw[k] = (double *)calloc(sz, sizeof(double)); o->csig[k] = (double *)calloc(sz, sizeof(double)); } }
   o->dt = 1.; o->tnext_event = HUGE_VAL;
   return o;
 }
 void orn_destroy(orn_t *o) {
   for (int k = 0; k < ORN_NFIELDS; k++) free(o->f[k].d);
   for (int k = 0; k < o->nlev; k++) { free(o->da[k].d); free(o->res[k].d); free(o->mask[k].d); free(o->S2[k].d); }
+  for (int k = 0; k < o->cnlev; k++) { free(o->cs[k]); free(o->cw[k]); free(o->csig[k]); }
+  free(o->cs); free(o->cw); free(o->csig);
   free(o->da); free(o->res); free(o->mask); free(o->S2); free(o);
 }
 int orn_set_option(orn_t *o, const char *k, double v) {
   if (!strcmp(k, "smoother")) o->smoother = (int)v; else if (!strcmp(k, "TOLERANCE")) o->TOLERANCE = v;
   else if (!strcmp(k, "NITERMAX")) o->nitermax = (int)v; else if (!strcmp(k, "NITERMIN")) o->nitermin = (int)v;
-  else if (!strcmp(k, "quiet")) o->quiet = (int)v; else if (!strcmp(k, "DT")) o->DT = v; else return -1;
+  else if (!strcmp(k, "quiet")) o->quiet = (int)v; else if (!strcmp(k, "DT")) o->DT = v;
+  else if (!strcmp(k, "stochastic")) o->stochastic = (int)v; else if (!strcmp(k, "seed")) srand((unsigned)v); else return -1;
   return 0;
 }
 double orn_get_param(orn_t *o, const char *k) {
@@ -352,6 +364,76 @@ static void invert_q(orn_t *o, vf *q) {
   bnd_q(o, q);
 }
 
+/* ---------------------------------------------------------------- stochastic forcing (cell scalars) */
+#define CI(n, i, j) ((size_t)((j) + 1) * ((n) + 2) + (size_t)((i) + 1))
+/* [BASILISK RULE] default BC of a cell scalar: ghost = interior (x direction first, then y over the x-ghosts) */
+static void cell_bc(double *f, int n) {
+  for (int j = 0; j < n; j++) { f[CI(n, n, j)] = f[CI(n, n - 1, j)]; f[CI(n, -1, j)] = f[CI(n, 0, j)]; }
+  for (int i = -1; i <= n; i++) { f[CI(n, i, n)] = f[CI(n, i, n - 1)]; f[CI(n, i, -1)] = f[CI(n, i, 0)]; }
+}
+/* event init_stoch qg-node/qg_stochastic.h:15-47: wavelet coefficients of the uniform filter length L_filt */
+static void init_stoch(orn_t *o) {
+  const int K = o->cnlev;
+  for (int k = 0; k < K; k++) {
+    const int n = o->N >> k; const double Delta = o->L0 / n;
+    for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) {
+      double ref_flag = 0;
+      if (k > 0) { const int m = n * 2; const double *c = o->csig[k - 1];
+        ref_flag += c[CI(m, 2 * i, 2 * j)]; ref_flag += c[CI(m, 2 * i, 2 * j + 1)]; ref_flag += c[CI(m, 2 * i + 1, 2 * j)]; ref_flag += c[CI(m, 2 * i + 1, 2 * j + 1)]; }
+      double v;
+      if (ref_flag > 0) v = 1;
+      else if (o->L_filt > 2 * Delta) v = 0;
+      else if (o->L_filt <= 2 * Delta && o->L_filt > Delta) v = 1 - (o->L_filt - Delta) / Delta;
+      else v = 1;
+      o->csig[k][CI(n, i, j)] = v;
+    }
+    cell_bc(o->csig[k], n);
+  }
+  for (int k = 0; k < K; k++) { const int n = o->N >> k;
+    for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) o->csig[k][CI(n, i, j)] = 1 - o->csig[k][CI(n, i, j)];
+    cell_bc(o->csig[k], n); }
+}
+static double normal_noise(void) { /* qg_stochastic.h:13 */
+  double a = sqrt(-2. * log(((double)(rand()) + 1.) / ((double)(RAND_MAX) + 2.)));
+  return a * cos(2 * M_PI * rand() / (double)RAND_MAX);
+}
+static double cell_bilinear(const double *c, int n, int i, int j) { /* fine cell (i, j) from the level with n cells */
+  const int I = i >> 1, J = j >> 1, cx = (i & 1) ? 1 : -1, cy = (j & 1) ? 1 : -1;
+  return (9. * c[CI(n, I, J)] + 3. * (c[CI(n, I + cx, J)] + c[CI(n, I, J + cy)]) + c[CI(n, I + cx, J + cy)]) / 16.;
+}
+/* wavelet -> scale by sig_lev -> inverse_wavelet of the cell field cs[0] ([BASILISK RULE], as in qg_oracle.c) */
+static void cell_wavelet_filter(orn_t *o) {
+  const int K = o->cnlev, N = o->N;
+  cell_bc(o->cs[0], N);
+  for (int k = 1; k < K; k++) { const int n = N >> k, m = n * 2; const double *f = o->cs[k - 1];
+    for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) {
+      double sum = 0.; sum += f[CI(m, 2 * i, 2 * j)]; sum += f[CI(m, 2 * i, 2 * j + 1)]; sum += f[CI(m, 2 * i + 1, 2 * j)]; sum += f[CI(m, 2 * i + 1, 2 * j + 1)];
+      o->cs[k][CI(n, i, j)] = sum / 4; }
+    cell_bc(o->cs[k], n); }
+  for (int k = 0; k < K - 1; k++) { const int n = N >> k;
+    for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) {
+      double d = o->cs[k][CI(n, i, j)]; d -= cell_bilinear(o->cs[k + 1], n >> 1, i, j);
+      o->cw[k][CI(n, i, j)] = d * o->csig[k][CI(n, i, j)]; } }
+  { const int n = N >> (K - 1);
+    for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) o->cs[K - 1][CI(n, i, j)] = o->cs[K - 1][CI(n, i, j)] * o->csig[K - 1][CI(n, i, j)];
+    cell_bc(o->cs[K - 1], n); }
+  for (int k = K - 2; k >= 0; k--) { const int n = N >> k;
+    for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) { double r = cell_bilinear(o->cs[k + 1], n >> 1, i, j); r += o->cw[k][CI(n, i, j)]; o->cw[k][CI(n, i, j)] = r; }
+    for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) o->cs[k][CI(n, i, j)] = o->cw[k][CI(n, i, j)];
+    cell_bc(o->cs[k], n); }
+}
+/* generate_noise qg_stochastic.h:49-65: serial rand() stream in foreach order (x outer, y inner) */
+static void generate_noise(orn_t *o) {
+  const int N = o->N;
+  for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) o->cs[0][CI(N, i, j)] = o->amp_stoch * normal_noise();
+  cell_wavelet_filter(o);
+}
+void orn_get_noise(orn_t *o, double *a) { const int N = o->N; for (int j = 0; j < N; j++) for (int i = 0; i < N; i++) a[(size_t)j * N + i] = o->cs[0][CI(N, i, j)]; }
+void orn_set_noise(orn_t *o, const double *a) { const int N = o->N; for (int j = 0; j < N; j++) for (int i = 0; i < N; i++) o->cs[0][CI(N, i, j)] = a[(size_t)j * N + i]; cell_bc(o->cs[0], N); }
+void orn_filter_noise(orn_t *o) { cell_wavelet_filter(o); }
+void orn_get_csig(orn_t *o, int k, double *a) { const int n = o->N >> k; for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) a[(size_t)j * n + i] = o->csig[k][CI(n, i, j)]; }
+int orn_cell_levels(orn_t *o) { return o->cnlev; }
+
 /* ---------------------------------------------------------------- set_const, time stepping */
 void orn_set_const(orn_t *o) { /* qg-node/qg.h:465-524 + qg_baroclinic_ms.h:449-510 + qg_barotropic.h:115-118 */
   const int nl = o->nl, N = o->N; const double D = o->L0 / N;
@@ -369,6 +451,7 @@ void orn_set_const(orn_t *o) { /* qg-node/qg.h:465-524 + qg_baroclinic_ms.h:449-
     for (int j = 0; j <= N; j++) for (int i = 0; i <= N; i++) W(&o->f[ORN_TOPO], 0, i, j) *= o->scale_topo;
   } else if (o->gp_low != 0.) o->iRd2_low = o->f0 * o->f0 / (o->gp_low * o->dh[nl - 1]);
   build_levels(o);
+  init_stoch(o);
   bnd_psi(o);
   if (o->nu != 0) o->DT = 0.5 * fmin(o->DT, D * D / o->nu / 4.);          /* qg-node/qg.h:511-512 */
   if (o->beta != 0) o->DT = fmin(o->DT, 1 / (2. * o->beta * o->L0));
@@ -395,6 +478,13 @@ double orn_update(orn_t *o, int qf, int dqf, double dtmax) { /* update_qg qg-nod
 void orn_advance(orn_t *o, int out, int in, int dq, double dt) { /* advance_qg qg-node/qg.h:291-302 */
   vf *a = &o->f[out], *b = &o->f[in], *d = &o->f[dq];
   for (int l = 0; l < a->nl; l++) for (int j = 0; j <= a->n; j++) for (int i = 0; i <= a->n; i++) W(a, l, i, j) = W(b, l, i, j) + W(d, l, i, j) * dt;
+  if (o->stochastic) { /* qg-node/qg.h:306-320; the vertex (i, j) takes the value of the cell (i, j) (ghost cells at i, j = N) */
+    const int N = o->N;
+    o->corrector_step = (o->corrector_step + 1) % 2;
+    double dts = sqrt(dt);
+    if (o->corrector_step) { generate_noise(o); dts = dts / sqrt(2); }
+    for (int j = 0; j <= N; j++) for (int i = 0; i <= N; i++) W(a, 0, i, j) += o->cs[0][CI(N, i, j)] * dts;
+  }
 }
 /* event forcing (i++), qg-node/qg.c:136-145 */
 void orn_forcing(orn_t *o) {

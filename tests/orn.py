@@ -32,6 +32,8 @@ def lib():
             ("orn_rhs_pv", None, [vp, ci, ci]), ("orn_comp_del2_zeta", None, [vp]), ("orn_relax_raw", None, [vp, ci, dp, dp, ci]),
             ("orn_residual_raw", cd, [vp, dp, dp, dp]), ("orn_restrict_raw", None, [vp, ci, dp, dp]),
             ("orn_prolong_raw", None, [vp, ci, dp, dp]), ("orn_get_level_mask", None, [vp, ci, dp]),
+            ("orn_get_noise", None, [vp, dp]), ("orn_set_noise", None, [vp, dp]), ("orn_filter_noise", None, [vp]),
+            ("orn_get_csig", None, [vp, ci, dp]), ("orn_cell_levels", ci, [vp]),
         ]:
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
@@ -152,6 +154,28 @@ class NodeOracle:
         f = np.empty((nl, 2 * (n1 - 1) + 1, 2 * (n1 - 1) + 1))
         self.L.orn_prolong_raw(self.h, lev, _p(coarse), _p(f))
         return f
+
+    # stochastic forcing (cell scalars n_stoch, sig_lev)
+    def noise(self):
+        a = np.empty((self.N, self.N))
+        self.L.orn_get_noise(self.h, _p(a))
+        return a
+
+    def set_noise(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self.L.orn_set_noise(self.h, _p(a))
+
+    def filter_noise(self):
+        self.L.orn_filter_noise(self.h)
+
+    def csig(self, k):
+        n = self.N >> k
+        a = np.empty((n, n))
+        self.L.orn_get_csig(self.h, k, _p(a))
+        return a
+
+    def cell_levels(self):
+        return self.L.orn_cell_levels(self.h)
 
     def level_mask(self, lev):
         n1 = (self.N >> lev) + 1

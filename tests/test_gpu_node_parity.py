@@ -157,6 +157,36 @@ def test_time_steps(nl, N, strict):
     assert g.iter == 6
 
 
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("N,L_filt", [(64, 8.0), (128, 1e6), (32, 20.0)])
+def test_stochastic_forcing(N, L_filt, strict):
+    """-D_STOCHASTIC of the vertex model (qg-node/qg_stochastic.h, qg.h:306-320): wavelet coefficients, the filtered
+    cell noise, and four RK2 steps driven by the reference-exact serial rand() stream (same seed on both sides)"""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    par = orn.node_params(N, 1, bc_fac=1.0, extra=f"gp_low = 0.02\namp_stoch = 0.3\nL_filt = {L_filt}\n")
+    o = orn.NodeOracle(par, smoother=orn.GS_RB, quiet=1, stochastic=1, TOLERANCE=1e-9)
+    g = NodeQG(par, strict=strict)
+    for k, v in (("quiet", 1), ("stochastic", 1), ("TOLERANCE", 1e-9)):
+        g.set_option(k, v)
+    psi = orn.node_psi(1, N)
+    o.set(orn.PSI, psi); g.set("PSI", psi)
+    o.set_const(); g.set_const()
+    for k in range(o.cell_levels()):
+        assert np.array_equal(g.csig(k), o.csig(k))
+    n0 = np.random.default_rng(3).standard_normal((N, N))
+    o.set_noise(n0); o.filter_noise()
+    same(g.noise(set=n0, filter=True), o.noise(), strict, 1e-13)
+    for m in (o, g):
+        libc.srand(11)
+        for _ in range(4):
+            m.step(True)
+    same(g.noise(), o.noise(), strict, 1e-13)
+    same(g.get("Q"), o.get(orn.Q), strict, 1e-7)
+    same(g.get("PSI"), o.get(orn.PSI), strict, 1e-7)
+    assert np.abs(g.noise()).max() > 0
+
+
 def test_full_size_properties():
     """2048^2 x 3 vertex grid with an island: the elliptic solve converges, q -> psi -> q closes, KE finite"""
     N, nl = 2048, 3

@@ -149,3 +149,38 @@ def test_time_steps_and_limiter():
     q = o.get(orn.Q)
     assert np.isfinite(q).all() and np.all(q[:, 1:-1, 1:-1] != 0)
     assert o.ke() > 0
+
+
+def test_stochastic_forcing_pieces():
+    """qg-node/qg_stochastic.h + qg.h:306-320: wavelet coefficients of the uniform filter length, all-pass /
+    all-stop limits of the filtered noise, sqrt(dt) weights of the predictor / corrector advance"""
+    N = 32                                   # L0 = 100: Delta_k = 3.125 * 2^k
+    o = orn.NodeOracle(orn.node_params(N, 1, extra="amp_stoch = 0.5\nL_filt = 1e6\n"), stochastic=1, seed=7)
+    o.set_const()
+    K = o.cell_levels()
+    assert K == 6 and all(np.all(o.csig(k) == 1) for k in range(K))        # low pass 0 everywhere -> high pass 1
+    rng = np.random.default_rng(0)
+    n0 = rng.standard_normal((N, N))
+    o.set_noise(n0); o.filter_noise()
+    assert np.abs(o.noise() - n0).max() <= 4e-16 * np.abs(n0).max() * 4
+    o2 = orn.NodeOracle(orn.node_params(N, 1, extra="amp_stoch = 0.5\nL_filt = 0.1\n"), stochastic=1)
+    o2.set_const()
+    assert all(np.all(o2.csig(k) == 0) for k in range(K))
+    o2.set_noise(n0); o2.filter_noise()
+    assert np.all(o2.noise() == 0)
+    o3 = orn.NodeOracle(orn.node_params(N, 1, extra="amp_stoch = 0.5\nL_filt = 8\n"), stochastic=1)
+    o3.set_const()                           # Delta_1 = 6.25 < 8 <= 12.5: low pass 1 - (8 - 6.25)/6.25 = 0.72 on level 1
+    assert np.all(o3.csig(0) == 1) and np.allclose(o3.csig(1), 0.28, rtol=1e-14) and np.all(o3.csig(2) == 0)
+    # advance: predictor draws the noise and adds n sqrt(dt/2) / ... , corrector re-uses it with sqrt(dt)
+    z = np.zeros((1, N + 1, N + 1))
+    o.set(orn.Q, z); o.set(orn.DQ, z)
+    dt = 0.04
+    o.advance(orn.QPRED, orn.Q, orn.DQ, dt / 2)
+    n = o.noise()
+    assert 0.3 < n.std() / 0.5 < 1.7 and abs(n.mean()) < 0.2             # amp_stoch * N(0,1), all-pass filter
+    qp = o.get(orn.QPRED)[0]
+    assert np.allclose(qp[:N, :N], n * np.sqrt(dt / 2) / np.sqrt(2), rtol=1e-14)
+    assert np.array_equal(qp[N, :N], qp[N - 1, :N]) and np.array_equal(qp[:N, N], qp[:N, N - 1])   # ghost cells of the cell field
+    o.advance(orn.Q, orn.Q, orn.DQ, dt)
+    assert np.array_equal(o.noise(), n)
+    assert np.allclose(o.get(orn.Q)[0][:N, :N], n * np.sqrt(dt), rtol=1e-14)
