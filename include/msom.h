@@ -234,7 +234,8 @@ enum {
   MSOMN_MASK = 8,  /* mask      1 inside / 0 land and boundary, 1 layer   qg.h:134         */
   MSOMN_DQ = 9,    /* updates                                                              */
   MSOMN_QPRED = 10,/* predictor                                                            */
-  MSOMN_NFIELDS = 11
+  MSOMN_QFORC3D = 11, /* q_forcing_3d (-DFORCING_3D, qg_baroclinic_ms.h:25,179-185): added to every layer once set */
+  MSOMN_NFIELDS = 12
 };
 typedef struct msomn msomn_t;
 

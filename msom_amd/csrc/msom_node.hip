@@ -44,6 +44,7 @@ struct msomn {
   int nitermax = 100, nitermin = 1, nrelax = 5, quiet = 0;  // nodal-poisson.h:19-23
   // stochastic forcing (-D_STOCHASTIC of the reference): cell-scalar noise n_stoch, wavelet-filtered (qg-node/qg_stochastic.h)
   int stochastic = 0, corrector_step = 0, cnlev = 0;
+  int forcing_3d = 0;  // -DFORCING_3D: switched on by setting MSOMN_QFORC3D
   std::vector<NatGeom> cg;
   std::vector<double *> cs, cr, csig;  // cs[0] = n_stoch
   int tiled_relax = 0;  // option: LDS-tiled smoother passes (1-2 sweeps per pass) on the wide levels; measured 3 % faster at 4097^2 x 3, 7 % slower at 2049^2 x 3
@@ -238,6 +239,7 @@ extern "C" int msomn_field_layers(msomn_t *m, int f) { NEED_FIELD(m, f); return 
 extern "C" int msomn_set_field(msomn_t *m, int f, const double *a) {
   NEED_FIELD(m, f);
   if (!a) return MSOM_ERR_ARG;
+  if (f == MSOMN_QFORC3D) m->forcing_3d = 1;
   return upload_g(m, m->f[f], m->g, m->fl[f], a);
 }
 extern "C" int msomn_get_field(msomn_t *m, int f, double *a) {
@@ -294,6 +296,7 @@ static int rhs_pv(msomn *m, double *q, double *dq) {
   launch_n_stretch(m->st, tmp, dq, S2, m->g, nl, 1., minus_nu4, m->lc);        // :172
   launch_n_del2(m->st, tmp, dq, m->g, nl, 1., minus_nu4, m->D);                 // :173
   launch_n_add2d(m->st, dq, m->f[MSOMN_QFORC], m->g);                           // :176-180 surface forcing
+  if (m->forcing_3d) launch_n_axpy(m->st, dq, m->f[MSOMN_QFORC3D], m->g, nl, 1.);   // :179-185 (FORCING_3D)
   launch_n_mul_mask(m->st, dq, nullptr, m->f[MSOMN_MASK], m->g, nl);            // :186-190
   HIPCHK(hipGetLastError());
   return MSOM_OK;
@@ -732,6 +735,10 @@ extern "C" int msomn_run(msomn_t *m, const char *workdir, long nsteps_max) {
         fprintf(stdout, "Read input files:\n");
         const struct { int f; const char *v; } in[] = {{MSOMN_S2, "N2"}, {MSOMN_PSIPG, "psi_pg"}, {MSOMN_MASK, "mask"}, {MSOMN_TOPO, "topo"}, {MSOMN_QFORC, "q_forcing"}};
         for (auto &e : in) (void)msomn_read_nc(m, e.f, name, e.v, 0);  // absent variables keep their defaults
+        {  // q_forcing_3d: only when the file has it (msomn_read_nc would switch FORCING_3D on)
+          std::vector<double> h3((size_t)(m->N + 1) * (m->N + 1) * m->nl);
+          if (!msom_nc_read(name, "q_forcing_3d", 0, m->nl, m->N + 1, m->N + 1, h3.data(), nullptr)) (void)msomn_set_field(m, MSOMN_QFORC3D, h3.data());
+        }
         fprintf(stdout, "%s .. ok\n", name);
       }
     }

@@ -25,7 +25,7 @@
 #define ORN_MAXNL 16
 
 enum { ORN_PSI = 0, ORN_Q, ORN_ZETA, ORN_TMP, ORN_PSIPG, ORN_S2 /* nl-1 */, ORN_TOPO /* 1 */, ORN_QFORC /* 1 */, ORN_MASK /* 1 */, ORN_DQ,
-       ORN_QPRED, ORN_NFIELDS };
+       ORN_QPRED, ORN_QFORC3D /* q_forcing_3d, -DFORCING_3D, qg_baroclinic_ms.h:25,179-185 */, ORN_NFIELDS };
 
 typedef struct { int n, nl; double *d; } vf; /* (n+3)^2 per layer: vertices -1..n+1 */
 #define VI(f, l, i, j) ((((size_t)(l) * ((f)->n + 3)) + (size_t)((j) + 1)) * ((f)->n + 3) + (size_t)((i) + 1))
@@ -47,7 +47,7 @@ typedef struct {
   orn_mgstats mg;
   /* stochastic forcing (-D_STOCHASTIC): qg-node/qg_stochastic.h, qg-node/qg.h:306-320.  n_stoch and sig_lev are
    * CELL scalars ("random noise define on scalar instead of vertex in order to use the wavelet transform") */
-  int stochastic, corrector_step, cnlev;
+  int stochastic, corrector_step, cnlev, forcing_3d;
   double amp_stoch, L_filt;
   double **cs, **cw, **csig; /* cell pyramids, level k: (N >> k)^2 cells with one ghost ring */
 } orn_t;
@@ -111,6 +111,7 @@ int orn_set_option(orn_t *o, const char *k, double v) {
   if (!strcmp(k, "smoother")) o->smoother = (int)v; else if (!strcmp(k, "TOLERANCE")) o->TOLERANCE = v;
   else if (!strcmp(k, "NITERMAX")) o->nitermax = (int)v; else if (!strcmp(k, "NITERMIN")) o->nitermin = (int)v;
   else if (!strcmp(k, "quiet")) o->quiet = (int)v; else if (!strcmp(k, "DT")) o->DT = v;
+  else if (!strcmp(k, "forcing_3d")) o->forcing_3d = (int)v;
   else if (!strcmp(k, "stochastic")) o->stochastic = (int)v; else if (!strcmp(k, "seed")) srand((unsigned)v); else return -1;
   return 0;
 }
@@ -234,6 +235,7 @@ static void rhs_pv(orn_t *o, vf *q, vf *dq) {
   comp_stretch(o, tmp, dq, 1., minus_nu4);
   comp_del2(o, tmp, dq, 1., minus_nu4, OUT_NONE);
   for (int j = 0; j <= n; j++) for (int i = 0; i <= n; i++) W(dq, 0, i, j) += W(qf, 0, i, j);
+  if (o->forcing_3d) for (int l = 0; l < nl; l++) for (int j = 0; j <= n; j++) for (int i = 0; i <= n; i++) W(dq, l, i, j) += W(&o->f[ORN_QFORC3D], l, i, j);
   for (int l = 0; l < nl; l++) for (int j = 0; j <= n; j++) for (int i = 0; i <= n; i++) W(dq, l, i, j) *= W(mk, 0, i, j);
 }
 

@@ -5,7 +5,7 @@ import numpy as np
 
 import orc
 
-PSI, Q, ZETA, TMP, PSIPG, S2, TOPO, QFORC, MASK, DQ, QPRED = range(11)
+PSI, Q, ZETA, TMP, PSIPG, S2, TOPO, QFORC, MASK, DQ, QPRED, QFORC3D = range(12)
 GS_LEX, GS_RB = 0, 1
 
 

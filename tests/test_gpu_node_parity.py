@@ -187,6 +187,22 @@ def test_stochastic_forcing(N, L_filt, strict):
     assert np.abs(g.noise()).max() > 0
 
 
+@pytest.mark.parametrize("strict", [True, False])
+def test_forcing_3d(strict):
+    """-DFORCING_3D (qg_baroclinic_ms.h:179-185): q_forcing_3d added to every layer of the tendency before the mask"""
+    N, nl = 32, 3
+    o, g = make_pair(N, nl, strict, mask=True, TOLERANCE=1e-9)
+    f3 = 1e-3 * np.random.default_rng(8).standard_normal((nl, N + 1, N + 1))
+    o.option("forcing_3d", 1); o.set(orn.QFORC3D, f3); g.set("QFORC3D", f3)
+    ref = orn.NodeOracle(orn.node_params(N, nl), smoother=orn.GS_RB, quiet=1, TOLERANCE=1e-9)
+    for _ in range(2):
+        o.step(True); g.step(True)
+    same(g.get("Q"), o.get(orn.Q), strict, 1e-7)
+    o.rhs_pv(); g.rhs_pv()
+    same(g.get("DQ"), o.get(orn.DQ), strict, 1e-7)
+    assert np.abs(o.get(orn.DQ)).max() > 1e-4
+
+
 def test_full_size_properties():
     """2048^2 x 3 vertex grid with an island: the elliptic solve converges, q -> psi -> q closes, KE finite"""
     N, nl = 2048, 3
