@@ -849,8 +849,9 @@ static void build_siglev(orc_t *o) {
   }
 }
 
-/* [BASILISK RULE] wavelet() / inverse_wavelet() of grid/multigrid-common.h (not in the tree, restated
- * from the published source): s restricted to all levels (mean of 4 children, BC on every level);
+/* [BASILISK RULE] wavelet() / inverse_wavelet() of grid/multigrid-common.h (not in the tree; the reference's
+ * own masked copies wavelet_mask() / inverse_wavelet_mask(), qg-node/wavelet_vertex.h:10-46, have exactly this
+ * structure with an extra factor mask_c): s restricted to all levels (mean of 4 children, BC on every level);
  * detail w_k = s_k - bilinear(s_{k+1}) on levels finer than the root, w_root = s_root; inverse:
  * s_root = w_root, s_k = bilinear(s_{k+1}) + w_k with boundary_level after each level.
  * Here with the scaling by sig_lev in between (msqg/qg.h:532-538), all layers at once. */
