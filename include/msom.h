@@ -272,6 +272,7 @@ double msomn_dt(msomn_t *m);
 int msomn_iter(msomn_t *m);
 int msomn_ke(msomn_t *m, double *ke);                                      /* event writestdout qg.c:171-178 */
 int msomn_last_mgstats(msomn_t *m, msom_mgstats *stats);
+int msomn_diag1d(msomn_t *m, double *out3);                                /* event write_1d_diag qg.h:361-399: ke, dissipation, forcing */
 /* NetCDF-3 output / restart of vertex fields (qg-node/netcdf_vertex_bas.h:95-424): one record of
  * "psi" and "q" appended to `path`; msomn_read_nc loads variable `varname` into `field` */
 int msomn_write_nc(msomn_t *m, const char *path);

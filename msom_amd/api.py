@@ -119,6 +119,7 @@ def load_library(strict=False):
         "msomn_iter": (ci, [vp]),
         "msomn_ke": (ci, [vp, _dp]),
         "msomn_last_mgstats": (ci, [vp, C.POINTER(MGStats)]),
+        "msomn_diag1d": (ci, [vp, _dp]),
         "msomn_write_nc": (ci, [vp, cs]),
         "msomn_read_nc": (ci, [vp, ci, cs, cs, ci]),
         "msomn_run": (ci, [vp, cs, C.c_long]),
@@ -561,6 +562,11 @@ class NodeQG:
         st = MGStats()
         self._chk(self.L.msomn_last_mgstats(self.h, C.byref(st)))
         return st
+
+    def diag1d(self):
+        out = (C.c_double * 3)()
+        self._chk(self.L.msomn_diag1d(self.h, out))
+        return np.array(out[:])
 
     def write_nc(self, path):
         self._chk(self.L.msomn_write_nc(self.h, path.encode()))

@@ -144,6 +144,7 @@ void launch_n_prolong(hipStream_t st, const double *c, const NatGeom &cg, double
 void launch_n_correct(hipStream_t st, double *a, const double *da, const NatGeom &g, int nl, double bcv);
 void launch_n_umax(hipStream_t st, const double *psi, double *out, const NatGeom &g, int nl, double D);
 void launch_n_add_noise(hipStream_t st, double *q, const double *n, const NatGeom &g, const NatGeom &cg, double dts);
+void launch_n_diag1d(hipStream_t st, const double *psi, const double *q, const double *qf, double *partial, double *out3, const NatGeom &g, double nu, double D);
 void launch_n_ke(hipStream_t st, const double *psi, double *partial, double *out, const NatGeom &g, double D);
 
 #endif

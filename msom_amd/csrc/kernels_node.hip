@@ -545,3 +545,34 @@ __global__ void k_n_add_noise(double *q, const double *__restrict__ n, NatGeom g
 void launch_n_add_noise(hipStream_t st, double *q, const double *n, const NatGeom &g, const NatGeom &cg, double dts) {
   hipLaunchKernelGGL(k_n_add_noise, grid2d(g.nx, g.ny), block2d(), 0, st, q, n, g, cg, dts);
 }
+
+// event write_1d_diag qg-node/qg.h:361-399: ke, dissipation and forcing sums over the cell loop (vertices i, j < N),
+// top layer; per-block partials [3][nblk], summed by launch_sum_final
+__global__ void k_n_diag1d(const double *__restrict__ psi, const double *__restrict__ q, const double *__restrict__ qf, double *partial, NatGeom g, double nu,
+                           double D2, double rD2) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  double v[3] = {0., 0., 0.};
+  if (i < g.nx - 1 && j < g.ny - 1) {
+    const size_t c = nat_idx(g, 0, j, i);
+    v[0] = 0.5 * psi[c] * DIVC(LAPN(psi, c, g.pitch), D2, rD2) * D2;
+    v[1] = nu * psi[c] * DIVC(LAPN(q, c, g.pitch), D2, rD2) * D2;
+    v[2] = psi[c] * qf[c] * D2;
+  }
+  __shared__ double sm[3][BY];
+  for (int k = 0; k < 3; k++) {
+    const double w = wave_sum_n(v[k]);
+    if (threadIdx.x == 0) sm[k][threadIdx.y] = w;
+  }
+  __syncthreads();
+  if (threadIdx.y == 0 && threadIdx.x < 3) {
+    double s = 0.;
+    for (int k = 0; k < BY; k++) s += sm[threadIdx.x][k];
+    partial[(size_t)threadIdx.x * (gridDim.x * gridDim.y + 64) + blockIdx.y * gridDim.x + blockIdx.x] = s;  // + 64: chunk sums of launch_sum_final
+  }
+}
+void launch_n_diag1d(hipStream_t st, const double *psi, const double *q, const double *qf, double *partial, double *out3, const NatGeom &g, double nu, double D) {
+  dim3 gr = grid2d(g.nx, g.ny);
+  hipLaunchKernelGGL(k_n_diag1d, gr, block2d(), 0, st, psi, q, qf, partial, g, nu, D * D, 1. / (D * D));
+  const int nb = (int)(gr.x * gr.y);
+  for (int k = 0; k < 3; k++) launch_sum_final(st, partial + (size_t)k * (nb + 64), out3 + k, nb);
+}

@@ -33,7 +33,7 @@ struct NLevel {
   double *da, *res, *mask, *S2;  // level 0: mask and S2 alias the model fields
   double *da2;                   // second correction buffer (the tiled smoother works out of place)
 };
-enum { NSC_RES = 0, NSC_UMAX = 1, NSC_KE = 2, NSC_COUNT = 8 };
+enum { NSC_RES = 0, NSC_UMAX = 1, NSC_KE = 2, NSC_DIAG = 3 /* 3 slots */, NSC_COUNT = 8 };
 
 struct msomn {
   NodeParams p;
@@ -143,7 +143,8 @@ static int node_alloc(msomn *m) {
   int r;
   if ((r = dalloc(&m->d_scal, NSC_COUNT))) return r;
   const int nblk = ((m->g.nx + 63) / 64) * ((m->g.ny + 3) / 4);
-  if ((r = dalloc(&m->partial, nblk)) || (r = dalloc(&m->d_row, m->N + 1))) return r;
+  // three partial arrays, each followed by the chunk sums of launch_sum_final
+  if ((r = dalloc(&m->partial, 3 * ((size_t)nblk + 64))) || (r = dalloc(&m->d_row, m->N + 1))) return r;
   HIPCHK(hipHostMalloc((void **)&m->h_scal, NSC_COUNT * sizeof(double)));
   HIPCHK(hipHostMalloc((void **)&m->h_row, (m->N + 1) * sizeof(double)));
   // set_vars qg-node/qg.h:426-430: mask = 1 on every vertex, its BC 0 on the four walls; S2 = N2[l]
@@ -644,6 +645,16 @@ extern "C" int msomn_ke(msomn_t *m, double *ke) {
   return MSOM_OK;
 }
 
+// event write_1d_diag (qg-node/qg.h:361-399): out = {ke, dissipation, forcing}
+extern "C" int msomn_diag1d(msomn_t *m, double *out3) {
+  if (!m || !out3) return MSOM_ERR_ARG;
+  launch_n_diag1d(m->st, m->f[MSOMN_PSI], m->f[MSOMN_Q], m->f[MSOMN_QFORC], m->partial, m->d_scal + NSC_DIAG, m->g, m->p.nu, m->D);
+  HIPCHK(hipMemcpyAsync(m->h_scal + NSC_DIAG, m->d_scal + NSC_DIAG, 3 * sizeof(double), hipMemcpyDeviceToHost, m->st));
+  HIPCHK(hipStreamSynchronize(m->st));
+  for (int k = 0; k < 3; k++) out3[k] = -m->h_scal[NSC_DIAG + k];
+  return MSOM_OK;
+}
+
 // ---- raw multigrid pieces (parity tests)
 #define NEED_LEVEL(m, k) if (!(m) || (k) < 0 || (k) >= (m)->nlev) { msom_set_error("bad level %d", (int)(k)); return MSOM_ERR_ARG; }
 extern "C" int msomn_dbg_relax(msomn_t *m, int k, double *da, const double *res, int nsweeps) {
@@ -757,9 +768,24 @@ extern "C" int msomn_run(msomn_t *m, const char *workdir, long nsteps_max) {
     if ((r = msomn_set_const(m))) return r;
   }
   snprintf(name, sizeof name, "%svars.nc", dpath);
-  double tout = 0.;
+  double tout = 0., tdiag = 0.;
+  const bool diag = p.dtdiag > 0;
+  char dname[800];
+  snprintf(dname, sizeof dname, "%sdiag_1d.dat", dpath);
   long steps = 0;
   for (;;) {
+    if (diag && tdiag <= p.tend + 1e-10 && m->t >= tdiag - 1e-12 * fmax(1., fabs(tdiag))) {  // write_1d_diag (qg.h:361-399)
+      if (FILE *fp = fopen(dname, "a")) {
+        if (m->iter == 0) fprintf(fp, "# time, ke, dissipation, forcing\n");
+        else {
+          double d3[3];
+          if ((r = msomn_diag1d(m, d3))) { fclose(fp); return r; }
+          fprintf(fp, "%e, %e, %e, %e\n", m->t, d3[0], d3[1], d3[2]);
+        }
+        fclose(fp);
+      }
+      tdiag += p.dtdiag;
+    }
     if ((r = msomn_forcing(m))) return r;  // forcing (i++)
     bool pending = tout <= p.tend + 1e-10;
     if (pending && m->t >= tout - 1e-12 * fmax(1., fabs(tout))) {  // output (t = 0; t <= tend + 1e-10; t += dtout)
@@ -775,7 +801,7 @@ extern "C" int msomn_run(msomn_t *m, const char *workdir, long nsteps_max) {
     fprintf(stdout, "i = %i, dt = %g, t = %g, ke_1 = %g\n", m->iter, m->dt, m->t, ke);  // writestdout
     if (!pending) break;
     if (nsteps_max >= 0 && steps >= nsteps_max) break;
-    m->tnext = tout;
+    m->tnext = diag && tdiag <= p.tend + 1e-10 ? fmin(tout, tdiag) : tout;
     if ((r = msomn_step(m, 0))) return r;
     steps++;
   }

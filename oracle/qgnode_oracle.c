@@ -520,6 +520,17 @@ double orn_ke(orn_t *o) { /* qg-node/qg.c:172-178 */
   for (int i = 0; i <= n; i++) for (int j = 0; j <= n; j++) ke -= 0.5 * W(psi, 0, i, j) * LAPN(psi, 0, i, j, D2) * D2;
   return ke;
 }
+/* event write_1d_diag qg-node/qg.h:361-399: sums over the CELL loop (vertices i, j = 0..N-1), top layer */
+void orn_diag1d(orn_t *o, double *out) {
+  const int n = o->N; const double D = o->L0 / n, D2 = D * D; vf *psi = &o->f[ORN_PSI], *q = &o->f[ORN_Q], *qf = &o->f[ORN_QFORC];
+  double ke = 0, d_ke = 0, f_ke = 0;
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) {
+    ke -= 0.5 * W(psi, 0, i, j) * LAPN(psi, 0, i, j, D2) * D2;
+    d_ke -= o->nu * W(psi, 0, i, j) * LAPN(q, 0, i, j, D2) * D2;
+    f_ke -= W(psi, 0, i, j) * W(qf, 0, i, j) * D2;
+  }
+  out[0] = ke; out[1] = d_ke; out[2] = f_ke;
+}
 double orn_time(orn_t *o) { return o->t; }
 double orn_dt(orn_t *o) { return o->dt; }
 void orn_set_tnext(orn_t *o, double t) { o->tnext_event = t; }

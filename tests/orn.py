@@ -32,7 +32,7 @@ def lib():
             ("orn_rhs_pv", None, [vp, ci, ci]), ("orn_comp_del2_zeta", None, [vp]), ("orn_relax_raw", None, [vp, ci, dp, dp, ci]),
             ("orn_residual_raw", cd, [vp, dp, dp, dp]), ("orn_restrict_raw", None, [vp, ci, dp, dp]),
             ("orn_prolong_raw", None, [vp, ci, dp, dp]), ("orn_get_level_mask", None, [vp, ci, dp]),
-            ("orn_get_noise", None, [vp, dp]), ("orn_set_noise", None, [vp, dp]), ("orn_filter_noise", None, [vp]),
+            ("orn_diag1d", None, [vp, dp]), ("orn_get_noise", None, [vp, dp]), ("orn_set_noise", None, [vp, dp]), ("orn_filter_noise", None, [vp]),
             ("orn_get_csig", None, [vp, ci, dp]), ("orn_cell_levels", ci, [vp]),
         ]:
             f = getattr(L, name)
@@ -154,6 +154,11 @@ class NodeOracle:
         f = np.empty((nl, 2 * (n1 - 1) + 1, 2 * (n1 - 1) + 1))
         self.L.orn_prolong_raw(self.h, lev, _p(coarse), _p(f))
         return f
+
+    def diag1d(self):
+        a = np.empty(3)
+        self.L.orn_diag1d(self.h, _p(a))
+        return a
 
     # stochastic forcing (cell scalars n_stoch, sig_lev)
     def noise(self):

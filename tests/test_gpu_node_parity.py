@@ -154,6 +154,8 @@ def test_time_steps(nl, N, strict):
         same(g.get(gf), o.get(of), strict, 1e-6)
     ke_o = o.ke()
     assert abs(g.ke() - ke_o) <= 1e-10 * abs(ke_o)
+    d_o, d_g = o.diag1d(), g.diag1d()                # event write_1d_diag: ke, dissipation, forcing
+    assert np.all(np.abs(d_g - d_o) <= 1e-10 * np.abs(d_o).max()) and np.all(d_o != 0)
     assert g.iter == 6
 
 
@@ -233,13 +235,15 @@ def test_full_size_properties():
 def test_netcdf_round_trip_and_driver(tmp_path):
     from scipy.io import netcdf_file
     N, nl = 32, 2
-    par = orn.node_params(N, nl, extra="noise_init = 1e-3\ntend = 0.2\ndtout = 0.1\n")
+    par = orn.node_params(N, nl, extra="noise_init = 1e-3\ntend = 0.2\ndtout = 0.1\ndtdiag = 0.05\n")
     g = NodeQG(par)
     g.set_option("quiet", 1)
     n = g.run(str(tmp_path))
     assert n > 0 and abs(g.t - 0.2) < 1e-12
     out = tmp_path / "outdir_0001"
     assert (out / "params.in").read_text() == par
+    rows = (out / "diag_1d.dat").read_text().splitlines()
+    assert rows[0].startswith("# time, ke") and len(rows) == 5 and abs(float(rows[-1].split(",")[0]) - 0.2) < 1e-9
     with netcdf_file(str(out / "vars.nc"), "r", mmap=False) as nc:
         assert nc.variables["psi"].shape == (3, nl, N + 1, N + 1)
         assert np.allclose(nc.variables["time"][:], [0, 0.1, 0.2])
