@@ -148,6 +148,8 @@ int msom_last_mgstats(msom_t *m, msom_mgstats *st);
 int msom_run(msom_t *m, const char *workdir, long nsteps_max);
 
 /* ---- .bas IO, msqg/auxiliar_input.h:24-59 (input_matrixl), :101-167 (output_matrixl, write_field) */
+/* tiled models: msom_write_* / msom_read_* / msom_read_inputs / msom_run are collective (every rank calls them): the
+ * global field is gathered and rank 0 writes; every rank reads the shared file and keeps its tile */
 int msom_write_bas(msom_t *m, int field, const char *path);
 int msom_read_bas(msom_t *m, int field, const char *path);
 

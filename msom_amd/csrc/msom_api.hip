@@ -1728,42 +1728,82 @@ extern "C" int msom_dbg_wavelet_apply(msom_t *m, int field) {
 
 // ------------------------------------------------------------------ .bas IO and the qg.c driver loop
 
+// tiles -> the global array [layers][gny][gnx] on the host of EVERY rank (all-gather of the tile interiors); collective
+static int gather_global(msom *m, int field, std::vector<double> &g) {
+  const int nlf = m->flayers[field];
+  const size_t cnt = (size_t)nlf * m->nx * m->ny;
+  g.resize((size_t)nlf * m->gnx * m->gny);
+  if (m->nranks == 1) return download(m, field, g.data());
+  double *recv = nullptr;
+  HIPCHK(hipMalloc(&recv, cnt * m->nranks * sizeof(double)));
+  launch_unpack(m->st, m->f[field], m->staging, m->g, nlf);
+  comm_begin(m);
+  int r = comm_allgather(m->comm, m->staging, recv, cnt);
+  comm_end(m);
+  std::vector<double> h(cnt * m->nranks);
+  if (!r) {
+    hipError_t e = hipMemcpyAsync(h.data(), recv, h.size() * sizeof(double), hipMemcpyDeviceToHost, m->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->st);
+    if (e != hipSuccess) { msom_set_error("HIP error %s in gather_global", hipGetErrorString(e)); r = MSOM_ERR_HIP; }
+  }
+  (void)hipFree(recv);
+  if (r) return r;
+  for (int q = 0; q < m->nranks; q++) {
+    const int tx = q % m->px, ty = q / m->px;
+    for (int l = 0; l < nlf; l++)
+      for (int j = 0; j < m->ny; j++)
+        memcpy(&g[((size_t)l * m->gny + ty * m->ny + j) * m->gnx + (size_t)tx * m->nx], &h[q * cnt + ((size_t)l * m->ny + j) * m->nx], m->nx * sizeof(double));
+  }
+  return MSOM_OK;
+}
+// the global array (held by every rank) -> this rank's tile; collective (the field's halo exchange)
+static int scatter_global(msom *m, int field, const std::vector<double> &g) {
+  const int nlf = m->flayers[field];
+  if (m->nranks == 1) return msom_set_field(m, field, g.data());
+  std::vector<double> t((size_t)nlf * m->nx * m->ny);
+  for (int l = 0; l < nlf; l++)
+    for (int j = 0; j < m->ny; j++)
+      memcpy(&t[((size_t)l * m->ny + j) * m->nx], &g[((size_t)l * m->gny + m->iy * m->ny + j) * m->gnx + (size_t)m->ix * m->nx], m->nx * sizeof(double));
+  return msom_set_field(m, field, t.data());
+}
+
+// .bas / NetCDF IO.  Tiled runs: the calls are collective; rank 0 writes the global field, every rank reads the (shared)
+// file and keeps its tile -- what output_matrix_mpi / input_matrixl do in the reference's MPI build (msqg/auxiliar_input.h)
 extern "C" int msom_write_bas(msom_t *m, int field, const char *path) {
   if (check_field(m, field) || !path) return MSOM_ERR_ARG;
-  if (m->gnx != m->gny || m->nranks > 1) { msom_set_error(".bas output needs a square single-tile grid"); return MSOM_ERR_STATE; }
-  std::vector<double> h((size_t)m->flayers[field] * m->nx * m->ny);
-  int r = download(m, field, h.data());
+  if (m->gnx != m->gny) { msom_set_error(".bas output needs a square grid"); return MSOM_ERR_STATE; }
+  std::vector<double> h;
+  int r = gather_global(m, field, h);
   if (r) return r;
-  return msom_bas_write(path, h.data(), m->flayers[field], m->nx, m->p.L0) ? MSOM_ERR_IO : MSOM_OK;
+  if (m->rank != 0) return MSOM_OK;
+  return msom_bas_write(path, h.data(), m->flayers[field], m->gnx, m->p.L0) ? MSOM_ERR_IO : MSOM_OK;
 }
 extern "C" int msom_read_bas(msom_t *m, int field, const char *path) {
   if (check_field(m, field) || !path) return MSOM_ERR_ARG;
-  if (m->gnx != m->gny || m->nranks > 1) { msom_set_error(".bas input needs a square single-tile grid"); return MSOM_ERR_STATE; }
-  std::vector<double> h((size_t)m->flayers[field] * m->nx * m->ny);
-  if (msom_bas_read(path, h.data(), m->flayers[field], m->nx, m->p.L0)) return MSOM_ERR_IO;
-  return msom_set_field(m, field, h.data());
+  if (m->gnx != m->gny) { msom_set_error(".bas input needs a square grid"); return MSOM_ERR_STATE; }
+  std::vector<double> h((size_t)m->flayers[field] * m->gnx * m->gny);
+  if (msom_bas_read(path, h.data(), m->flayers[field], m->gnx, m->p.L0)) return MSOM_ERR_IO;
+  return scatter_global(m, field, h);
 }
 
 extern "C" int msom_write_nc(msom_t *m, const char *path) {
   if (!m || !path) return MSOM_ERR_ARG;
-  if (m->nranks > 1) { msom_set_error("NetCDF output needs a single-tile grid"); return MSOM_ERR_STATE; }
   static const char *names[2] = {"psi", "q"};
-  const size_t n = (size_t)m->nl * m->nx * m->ny;
-  std::vector<double> hp(n), hq(n);
+  std::vector<double> hp, hq;
   int r;
-  if ((r = download(m, MSOM_PSI, hp.data())) || (r = download(m, MSOM_Q, hq.data()))) return r;
+  if ((r = gather_global(m, MSOM_PSI, hp)) || (r = gather_global(m, MSOM_Q, hq))) return r;
+  if (m->rank != 0) return MSOM_OK;
   struct stat sb;
-  if (stat(path, &sb) != 0 && msom_nc_create(path, m->nl, m->ny, m->nx, m->p.L0, 2, names)) return MSOM_ERR_IO;
+  if (stat(path, &sb) != 0 && msom_nc_create(path, m->nl, m->gny, m->gnx, m->p.L0, 2, names)) return MSOM_ERR_IO;
   const double *f[2] = {hp.data(), hq.data()};
-  return msom_nc_append(path, m->nl, m->ny, m->nx, 2, names, m->t, f) < 0 ? MSOM_ERR_IO : MSOM_OK;
+  return msom_nc_append(path, m->nl, m->gny, m->gnx, 2, names, m->t, f) < 0 ? MSOM_ERR_IO : MSOM_OK;
 }
 extern "C" int msom_read_nc(msom_t *m, int field, const char *path, const char *varname, int record) {
   if (check_field(m, field) || !path || !varname) return MSOM_ERR_ARG;
-  if (m->nranks > 1) { msom_set_error("NetCDF input needs a single-tile grid"); return MSOM_ERR_STATE; }
-  std::vector<double> h((size_t)m->flayers[field] * m->nx * m->ny);
-  int r = msom_nc_read(path, varname, record, m->flayers[field], m->ny, m->nx, h.data(), nullptr);
+  std::vector<double> h((size_t)m->flayers[field] * m->gnx * m->gny);
+  int r = msom_nc_read(path, varname, record, m->flayers[field], m->gny, m->gnx, h.data(), nullptr);
   if (r) return r == -2 ? MSOM_ERR_IO : MSOM_ERR_ARG;
-  return msom_set_field(m, field, h.data());
+  return scatter_global(m, field, h);
 }
 
 static bool file_exists(const char *path) {
@@ -1778,7 +1818,8 @@ extern "C" int msom_read_inputs(msom_t *m, const char *dir) {
   const char *d = dir ? dir : ".";
   const int nl = m->nl, N = m->gnx;
   int r;
-  if (!m->quiet) fprintf(stdout, "Read input files:\n");
+  const bool say = !m->quiet && m->rank == 0;  // tiled runs: rank 0 prints, every rank reads the shared files
+  if (say) fprintf(stdout, "Read input files:\n");
   snprintf(name, sizeof name, "%s/dh_%dl.bin", d, nl);
   if (FILE *fp = fopen(name, "r")) {
     std::vector<float> dh(nl);
@@ -1786,7 +1827,7 @@ extern "C" int msom_read_inputs(msom_t *m, const char *dir) {
     fclose(fp);
     if (got != (size_t)nl) { msom_set_error("short read on %s", name); return MSOM_ERR_IO; }
     for (int l = 0; l < nl; l++) m->dhf[l] = dh[l];
-    if (!m->quiet) fprintf(stdout, "%s .. ok\n", name);
+    if (say) fprintf(stdout, "%s .. ok\n", name);
   }
   struct { const char *fmt; int field; } files[] = {
       {"%s/psipg_%dl_N%d.bas", MSOM_PSIPG}, {"%s/frpg_%dl_N%d.bas", MSOM_FR}, {"%s/rdpg_%dl_N%d.bas", MSOM_RD},
@@ -1795,19 +1836,19 @@ extern "C" int msom_read_inputs(msom_t *m, const char *dir) {
     snprintf(name, sizeof name, f.fmt, d, nl, N);
     if (file_exists(name)) {
       if ((r = msom_read_bas(m, f.field, name))) return r;
-      if (!m->quiet) fprintf(stdout, "%s .. ok\n", name);
+      if (say) fprintf(stdout, "%s .. ok\n", name);
     }
   }
   snprintf(name, sizeof name, "%s/topo.bas", d);
   if (file_exists(name)) {
     if ((r = msom_read_bas(m, MSOM_TOPO, name))) return r;
-    if (!m->quiet) fprintf(stdout, "%s .. ok\n", name);
+    if (say) fprintf(stdout, "%s .. ok\n", name);
   }
   if (m->p.nptr > 0) {  // msqg/qg.c:75-90
     snprintf(name, sizeof name, "%s/ptr0.bas", d);
     if (file_exists(name)) {
       if ((r = msom_read_bas(m, MSOM_PTR, name))) return r;
-      if (!m->quiet) fprintf(stdout, "%s .. ok\n", name);
+      if (say) fprintf(stdout, "%s .. ok\n", name);
     }
     snprintf(name, sizeof name, "%s/ptr_relax.bas", d);
     if (file_exists(name) && (r = msom_read_bas(m, MSOM_PTR_RELAX, name))) return r;
@@ -1815,7 +1856,7 @@ extern "C" int msom_read_inputs(msom_t *m, const char *dir) {
   snprintf(name, sizeof name, "%s/p0.bas", d);
   if (file_exists(name)) {
     if ((r = msom_read_bas(m, MSOM_PSI, name))) return r;
-    if (!m->quiet) fprintf(stdout, "%s .. ok\n", name);
+    if (say) fprintf(stdout, "%s .. ok\n", name);
   }
   m->const_set = 0;
   return MSOM_OK;
@@ -1824,43 +1865,50 @@ extern "C" int msom_read_inputs(msom_t *m, const char *dir) {
 // backup_config, msqg/qg.h:782-835: params.in copy and the constant fields, written into the
 // output directory at t = 0 (event write_const, msqg/qg.c:95-97)
 static int backup_config(msom *m, const char *dpath) {
-  fprintf(stdout, "Backup config\n");
+  const bool root = m->rank == 0;  // tiled runs: the gathers are collective, rank 0 writes
+  if (root) fprintf(stdout, "Backup config\n");
   char name[700];
   const int nl = m->nl, N = m->gnx;
-  const size_t n2 = (size_t)m->nx * m->ny;
+  const size_t n2 = (size_t)m->gnx * m->gny;
   snprintf(name, sizeof name, "%sparams.in", dpath);
-  if (FILE *fp = fopen(name, "w")) {
-    fwrite(m->params_text.data(), 1, m->params_text.size(), fp);
-    fclose(fp);
-  } else {
-    msom_set_error("cannot write %s", name);
-    return MSOM_ERR_IO;
+  if (root) {
+    if (FILE *fp = fopen(name, "w")) {
+      fwrite(m->params_text.data(), 1, m->params_text.size(), fp);
+      fclose(fp);
+    } else {
+      msom_set_error("cannot write %s", name);
+      return MSOM_ERR_IO;
+    }
   }
   // sig_filt = min(afilt * Rd, Lfmax) (msqg/qg.h:1060) and Rd itself (:794-810)
-  std::vector<double> h(n2 * nl, 0.), rd(n2);
+  std::vector<double> h, rd;
   int r;
-  if ((r = download(m, MSOM_RD, rd.data()))) return r;
+  if ((r = gather_global(m, MSOM_RD, rd))) return r;
+  h.assign(n2, 0.);
   for (size_t k = 0; k < n2; k++) h[k] = fmin(m->p.afilt * rd[k], m->p.Lfmax);
   snprintf(name, sizeof name, "%ssig_filt.bas", dpath);
-  if (msom_bas_write(name, h.data(), 1, m->nx, m->p.L0)) return MSOM_ERR_IO;
+  if (root && msom_bas_write(name, h.data(), 1, N, m->p.L0)) return MSOM_ERR_IO;
   snprintf(name, sizeof name, "%srdpg_%dl_N%d.bas", dpath, nl, N);
-  if (msom_bas_write(name, rd.data(), 1, m->nx, m->p.L0)) return MSOM_ERR_IO;
+  if (root && msom_bas_write(name, rd.data(), 1, N, m->p.L0)) return MSOM_ERR_IO;
   snprintf(name, sizeof name, "%spsipg_%dl_N%d.bas", dpath, nl, N);
   if ((r = msom_write_bas(m, MSOM_PSIPG, name))) return r;
   // Frl has nl layers in the reference (nl - 1 used, the last one stays 0)
-  std::fill(h.begin(), h.end(), 0.);
-  if (nl > 1 && (r = download(m, MSOM_FR, h.data()))) return r;
-  if (nl == 1) std::fill(h.begin(), h.end(), 0.);
+  std::vector<double> fr;
+  if (nl > 1 && (r = gather_global(m, MSOM_FR, fr))) return r;
+  h.assign(n2 * nl, 0.);
+  if (nl > 1) memcpy(h.data(), fr.data(), n2 * (nl - 1) * sizeof(double));
   snprintf(name, sizeof name, "%sfrpg_%dl_N%d.bas", dpath, nl, N);
-  if (msom_bas_write(name, h.data(), nl, m->nx, m->p.L0)) return MSOM_ERR_IO;
+  if (root && msom_bas_write(name, h.data(), nl, N, m->p.L0)) return MSOM_ERR_IO;
   snprintf(name, sizeof name, "%sqforc_%dl_N%d.bas", dpath, nl, N);
   if ((r = msom_write_bas(m, MSOM_QFORC, name))) return r;
-  std::vector<float> dh(nl);
-  for (int l = 0; l < nl; l++) dh[l] = (float)m->dhf[l];
-  snprintf(name, sizeof name, "%sdh_%dl.bin", dpath, nl);
-  if (FILE *fp = fopen(name, "w")) {
-    fwrite(dh.data(), sizeof(float), nl, fp);
-    fclose(fp);
+  if (root) {
+    std::vector<float> dh(nl);
+    for (int l = 0; l < nl; l++) dh[l] = (float)m->dhf[l];
+    snprintf(name, sizeof name, "%sdh_%dl.bin", dpath, nl);
+    if (FILE *fp = fopen(name, "w")) {
+      fwrite(dh.data(), sizeof(float), nl, fp);
+      fclose(fp);
+    }
   }
   return MSOM_OK;
 }
@@ -1869,12 +1917,18 @@ static int backup_config(msom *m, const char *dpath) {
 // output t += dtout), then one predictor-corrector step.
 extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
   NEED_CONST(m);
-  if (m->nranks > 1) { msom_set_error("msom_run: tiled mode not implemented"); return MSOM_ERR_STATE; }
   const Params &p = m->p;
+  // tiled runs (one process / thread per tile): every call below that moves field data is collective; rank 0 alone
+  // creates the directory, prints and writes (the reference's pid() == 0 branches, msqg/qg.h:766-780)
+  const bool root = m->rank == 0;
+  if (m->nranks > 1 && (p.dtflt > 0 || p.ediag > -1)) {
+    msom_set_error("msom_run: the wavelet filter and the energy budgets need a single-tile grid");
+    return MSOM_ERR_STATE;
+  }
   char dpath[600] = "", name[700];
   const char *wd = workdir ? workdir : ".";
   // create_outdir, msqg/qg.h:766-776
-  for (int i = 1; i < 10000; i++) {
+  for (int i = 1; root && i < 10000; i++) {
     snprintf(dpath, sizeof dpath, "%s/outdir_%04d/", wd, i);
     if (mkdir(dpath, 0777) == 0) {
       fprintf(stdout, "Writing output in %s\n", dpath);
@@ -1897,11 +1951,14 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
     }
     if (p.ediag > -1 && (r = msom_energy_tend(m, m->dt))) return r;  // event comp_diag (i++), qg_energy.h:289-291
     // writestdout, msqg/qg.c:101-109
-    fprintf(stdout, "i = %i, dt = %g, t = %g, ke_1 = %g\n", m->iter, m->dt, m->t, msom_ke(m));
+    {
+      const double ke = msom_ke(m);
+      if (root) fprintf(stdout, "i = %i, dt = %g, t = %g, ke_1 = %g\n", m->iter, m->dt, m->t, ke);
+    }
     // output, msqg/qg.c:112-122
     bool out_pending = tout <= p.tend + 1e-10;
     if (out_pending && m->t >= tout - 1e-12 * fmax(1., fabs(tout))) {
-      fprintf(stdout, "write file\n");
+      if (root) fprintf(stdout, "write file\n");
       if ((r = invertq(m, m->f[MSOM_Q]))) return r;
       snprintf(name, sizeof name, "%spo%09d.bas", dpath, m->iter);
       if ((r = msom_write_bas(m, MSOM_PSI, name))) return r;

@@ -112,6 +112,38 @@ def test_large_tiles_default_agglomeration(strict):
     assert np.array_equal(assemble(out, "psi", px, py), g.get(F["PSI"]))
 
 
+def test_tiled_driver_loop_writes_the_same_files(tmp_path):
+    """msom_run on 2 x 2 tiles (collective gathers, rank 0 writes): po / qo .bas files, backup of the constant fields
+    and NetCDF output identical to the single-tile run; restart from the written file on the tiles"""
+    px = py = 2
+    tile, nl = 32, 3
+    gn = tile * px
+    params = orc.double_gyre_params(gn, nl, extra="MGLEVELS = 5\n").replace("tend  = 500.", "tend = 0.04").replace("dtout = 1.", "dtout = 0.02")
+    psi = orc.synthetic_psi(nl, gn, gn)
+    d1, d4 = tmp_path / "single", tmp_path / "tiled"
+    d1.mkdir(); d4.mkdir()
+    g = QG(params)
+    g.option("quiet", 1)
+    g.set(F["PSI"], psi); g.set_const()
+    g.run(str(d1))
+    g.write_nc(str(d1 / "vars.nc"))
+
+    def run(gt, rank):
+        gt.run(str(d4))
+        gt.write_nc(str(d4 / "vars.nc"))
+        gt.read_bas(F["PSI"], str(d4 / "outdir_0001" / "po000000000.bas"))      # collective read: every tile takes its part
+        return gt.get(F["PSI"])
+
+    out = run_tiled(params, px, py, psi, nsteps=0, strict=False, fn=run)
+    names = sorted(os.listdir(d1 / "outdir_0001"))
+    assert names == sorted(os.listdir(d4 / "outdir_0001")) and any(n.startswith("po") for n in names) and len(names) >= 12
+    for n in names:
+        assert (d1 / "outdir_0001" / n).read_bytes() == (d4 / "outdir_0001" / n).read_bytes(), n
+    assert (d1 / "vars.nc").read_bytes() == (d4 / "vars.nc").read_bytes()
+    back = np.concatenate([np.concatenate([out[iy * px + ix]["extra"] for ix in range(px)], axis=2) for iy in range(py)], axis=1)
+    assert np.array_equal(back, psi.astype("f4").astype("f8"))
+
+
 def test_tiled_strict_matches_oracle():
     """The tiled strict build is bit-exact against the (untiled) CPU oracle as well."""
     px, py, tile, nl = 2, 2, 32, 3
