@@ -996,28 +996,42 @@ __global__ void __launch_bounds__(BX *BY) k_relax_red_prolong2(RelaxPArgs p) {
 }
 template <int NL, bool UNIFORM>
 __device__ __forceinline__ void red_prolong2_pt(const RelaxPArgs &p, int kx, int J) {
-  RedCell<NL, UNIFORM, 0> c0;
-  RedCell<NL, UNIFORM, 1> c1;
-  c0.init(p, kx, J);
-  c1.init(p, kx, J);
   size_t cw[3][3];
 #pragma unroll
   for (int dj = -1; dj <= 1; dj++)
 #pragma unroll
     for (int di = -1; di <= 1; di++) cw[dj + 1][di + 1] = split_idx(p.cg, 0, J + dj, kx + di);
+  // one cell after the other (the second pass re-reads the window, L1 hits): fewer live registers, one more wave per SIMD
+  {
+    RedCell<NL, UNIFORM, 0> c0;
+    c0.init(p, kx, J);
 #pragma unroll
-  for (int l = 0; l < NL; l++) {
-    const double *cc = p.coarse + (size_t)l * p.cg.ls;
-    double c[3][3];
+    for (int l = 0; l < NL; l++) {
+      const double *cc = p.coarse + (size_t)l * p.cg.ls;
+      double c[3][3];
 #pragma unroll
-    for (int a = 0; a < 3; a++)
+      for (int a = 0; a < 3; a++)
 #pragma unroll
-      for (int b = 0; b < 3; b++) c[a][b] = cc[cw[a][b]];
-    c0.layer(p, l, c);
-    c1.layer(p, l, c);
+        for (int b = 0; b < 3; b++) c[a][b] = cc[cw[a][b]];
+      c0.layer(p, l, c);
+    }
+    c0.finish(p);
   }
-  c0.finish(p);
-  c1.finish(p);
+  {
+    RedCell<NL, UNIFORM, 1> c1;
+    c1.init(p, kx, J);
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      const double *cc = p.coarse + (size_t)l * p.cg.ls;
+      double c[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) c[a][b] = cc[cw[a][b]];
+      c1.layer(p, l, c);
+    }
+    c1.finish(p);
+  }
 }
 
 // Same cells per thread as k_relax_red_prolong2, with the coarse correction staged through LDS: a 64 x 4
@@ -1038,22 +1052,35 @@ __global__ void __launch_bounds__(BX *BY) k_relax_red_prolong3(RelaxPArgs p) {
   __syncthreads();
   const int kx = kx0 + threadIdx.x, J = J0 + threadIdx.y;
   if (kx >= p.g.hk || 2 * J >= p.g.ny) return;
-  RedCell<NL, UNIFORM, 0> c0;
-  RedCell<NL, UNIFORM, 1> c1;
-  c0.init(p, kx, J);
-  c1.init(p, kx, J);
+  // one cell after the other (the window is read from LDS twice): half the live registers of the two-cell loop
+  {
+    RedCell<NL, UNIFORM, 0> c0;
+    c0.init(p, kx, J);
 #pragma unroll
-  for (int l = 0; l < NL; l++) {
-    double c[3][3];
+    for (int l = 0; l < NL; l++) {
+      double c[3][3];
 #pragma unroll
-    for (int a = 0; a < 3; a++)
+      for (int a = 0; a < 3; a++)
 #pragma unroll
-      for (int b = 0; b < 3; b++) c[a][b] = C[l][threadIdx.y + a][threadIdx.x + b];
-    c0.layer(p, l, c);
-    c1.layer(p, l, c);
+        for (int b = 0; b < 3; b++) c[a][b] = C[l][threadIdx.y + a][threadIdx.x + b];
+      c0.layer(p, l, c);
+    }
+    c0.finish(p);
   }
-  c0.finish(p);
-  c1.finish(p);
+  {
+    RedCell<NL, UNIFORM, 1> c1;
+    c1.init(p, kx, J);
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      double c[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) c[a][b] = C[l][threadIdx.y + a][threadIdx.x + b];
+      c1.layer(p, l, c);
+    }
+    c1.finish(p);
+  }
 }
 
 // ------------------------------------------------------------------ coarse levels in ONE launch
