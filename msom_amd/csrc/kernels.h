@@ -84,7 +84,7 @@ int rhs_pipe_blocks(const NatGeom &g);
 // ---- kernels_mg.hip
 // coarse part of the multigrid cycle in one launch (k_mg_coarse): lev[0] = finest of the group
 #define MGC_MAXLEV 8
-#define MGC_MAXDIM 64
+#define MGC_MAXDIM 32
 #define MGC_NT 512
 struct CoarseLev { double *da, *res; const double *S; SplitGeom g; RelaxCoef rc; };
 struct CoarseArgs { CoarseLev lev[MGC_MAXLEV]; int n, walls, prolong_fused; };

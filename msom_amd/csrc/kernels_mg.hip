@@ -1084,7 +1084,7 @@ __global__ void __launch_bounds__(BX *BY) k_relax_red_prolong3(RelaxPArgs p) {
 }
 
 // ------------------------------------------------------------------ coarse levels in ONE launch
-// Levels of at most MGC_MAXDIM x MGC_MAXDIM cells are launch-latency bound (a colour half-sweep of a 32^2
+// Levels of at most MGC_MAXDIM x MGC_MAXDIM (32 x 32; measured: 64 loses, the single workgroup becomes the bottleneck) cells are launch-latency bound (a colour half-sweep of a 32^2
 // level takes ~1 us of work and ~4.5 us of launch): one 512-thread workgroup (256 VGPRs per wave: the fused prolongation needs ~150) runs the whole coarse part
 // of the cycle -- restrictions down, zero first guess on the coarsest level, nrelax red-black sweeps per
 // level, prolongation folded into the first red half-sweep on the way up -- with __syncthreads() where

@@ -108,6 +108,7 @@ struct msom {
   int nme_ft = 0;  // msqg/qg_energy.h:17
   // coarse levels (<= MGC_MAXDIM cells a side) solved by ONE launch (k_mg_coarse)
   CoarseArgs *d_cargs = nullptr;
+  int mgc_dim = MGC_MAXDIM;  // widest level of that group
   int mgc_first = -1, mgc_opt = 1;  // first (finest) level of the group, -1: none; option "mg_coarse"
   int res_ready = -1;  // field id whose first multigrid residual (levels 0, 1; SC_RESF; partial sums) the last tendency pass already produced
   int adv_fused = 1;   // fold q_out = q_in + dt dq into the tendency pass
@@ -567,6 +568,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "agg_size")) { m->agg_size = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "prolong_fused")) { m->prolong_fused = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "mg_coarse")) { m->mgc_opt = (int)v; if (m->const_set) return build_coefs(m); }
+  else if (!strcmp(key, "mg_coarse_dim")) { m->mgc_dim = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "block_variant")) { extern int g_block_variant; g_block_variant = (int)v; }
   else if (!strcmp(key, "rhs_dbg")) { extern int g_rhs_dbg; g_rhs_dbg = (int)v; }
   else if (!strcmp(key, "rhs_variant")) m->rhs_variant = (int)v;
@@ -781,7 +783,7 @@ static int setup_mg_coarse(msom *m) {
   int k0 = -1;
   for (int k = m->nlev - 1; k >= klo; k--) {
     const SplitGeom &g = glob ? m->gsg[k - m->agg_level] : m->sg[k];
-    if (g.nx > MGC_MAXDIM || g.ny > MGC_MAXDIM) break;
+    if (g.nx > m->mgc_dim || g.ny > m->mgc_dim) break;
     k0 = k;
   }
   if (k0 < 0 || m->nlev - k0 > MGC_MAXLEV) return MSOM_OK;

@@ -437,7 +437,7 @@ def test_lds_correct_residual_equals_plain(nx, ny, nl, extra, strict):
 @pytest.mark.parametrize("nx,ny,nl", [(256, 128, 6), (64, 64, 3), (32, 32, 1), (512, 64, 2)])
 @pytest.mark.parametrize("strict", [True, False])
 def test_one_launch_coarse_levels_equal_per_kernel_path(nx, ny, nl, strict):
-    """option mg_coarse: the levels of at most 64 cells a side solved by ONE workgroup (k_mg_coarse) give the
+    """option mg_coarse: the levels of at most 32 cells a side (option mg_coarse_dim) solved by ONE workgroup (k_mg_coarse) give the
     same psi as the kernel-per-half-sweep path (bit for bit in the strict build)"""
     txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else ""))
     out = {}
