@@ -655,3 +655,52 @@ def test_more_layers_than_supported_is_rejected():
     txt = orc.double_gyre_params(32, 8).replace("nl = 8", "nl = 9")
     with pytest.raises(MsomError, match="supported range"):
         QG(txt)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_configurations_strict_vs_oracle(seed):
+    """differential test over random parameter combinations (layers, aspect ratio, slip, both viscosities, drag,
+    variable Rossby number, background flow, topography, 3-D forcing, non-uniform Froude field): three RK2 steps,
+    strict build bit-exact against the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    nl = int(rng.choice([1, 2, 3, 4, 6]))
+    nx = int(rng.choice([32, 64, 128, 256]))
+    ny = int(rng.choice([nx, max(16, nx // 2), min(256, nx * 2)]))
+    extra = ""
+    if rng.random() < 0.5:
+        extra += f"sbc = {rng.choice([0.5, 2.0, 100.0])}\n"
+    if rng.random() < 0.5:
+        extra += f"Re = {rng.choice([200.0, 1500.0])}\n"
+    if rng.random() < 0.3:
+        extra += "Re4 = 0\n"
+    if rng.random() < 0.5:
+        extra += f"Eks = {rng.choice([0.001, 0.01])}\n"
+    if rng.random() < 0.3:
+        extra += "varRo = 1\n"
+    pg = rng.random() < 0.4 and nl > 1
+    if pg:
+        extra += "upg = [" + ",".join(f"{v:.2f}" for v in rng.uniform(-0.3, 0.3, nl)) + "]\nvpg = [" + ",".join(f"{v:.2f}" for v in rng.uniform(-0.3, 0.3, nl)) + "]\n"
+        if rng.random() < 0.5:
+            extra += "flsrv = 1\n"
+    o, g = make_pair(nx, ny, nl, strict=True, extra=extra, TOLERANCE=float(rng.choice([1e-3, 1e-8])))
+    redo = False
+    if rng.random() < 0.4:
+        tp = 0.05 * rand_field(seed + 50, (1, ny, nx))
+        o.set(orc.TOPO, tp); g.set(F["TOPO"], tp)
+        o.option("flag_topo", 1); g.option("flag_topo", 1)
+    if rng.random() < 0.4:
+        qf = rand_field(seed + 60, (nl, ny, nx), 1e-6)
+        o.set(orc.QFORC, qf); g.set(F["QFORC"], qf)
+    if nl > 1 and rng.random() < 0.4:
+        x = (np.arange(nx) + 0.5) / nx
+        fr = np.stack([o.param(f"Fr_{l}") * (1 + 0.3 * np.sin(2 * np.pi * (l + 1) * x))[None, :] * np.ones((ny, 1)) for l in range(nl - 1)])
+        o.set(orc.FR, fr); g.set(F["FR"], fr)
+        redo = True
+    if redo:
+        o.set_const(); g.set_const()
+    for _ in range(3):
+        o.step(); g.step()
+    desc = f"nl={nl} {nx}x{ny} {extra!r}"
+    assert g.t == o.t, desc
+    assert np.array_equal(g.get(F["PSI"]), o.get(orc.PSI)), desc
+    assert np.array_equal(g.get(F["Q"]), o.get(orc.Q)), desc
