@@ -264,3 +264,36 @@ def test_error_convention():
     g = NodeQG(orn.node_params(16, 2))
     with pytest.raises(MsomError, match="set_const"):
         g.step()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_configurations_strict_vs_oracle(seed):
+    """vertex model: random layer counts, sizes, slip factors, viscosities, ragged land masks, topography, background
+    flow, beta-plane S2 (flag_ms), time-dependent forcing; three RK2 steps, strict build bit-exact against the oracle"""
+    rng = np.random.default_rng(500 + seed)
+    nl = int(rng.choice([1, 2, 3, 4]))
+    N = int(rng.choice([16, 32, 64, 128]))
+    extra = f"gp_low = {rng.choice([0.0, 0.02])}\ntau1 = {rng.choice([0.0, 5e-4])}\ntf1 = 0.4\ntf2 = 0.9\nflag_ms = {int(rng.integers(0, 2))}\n"
+    par = orn.node_params(N, nl, bc_fac=float(rng.choice([0.0, 0.5, 1.0])), nu=float(rng.choice([2.0, 5.0])), nu4=float(rng.choice([0.0, 1.5])), extra=extra)
+    tol = float(rng.choice([1e-5, 1e-9]))
+    o = orn.NodeOracle(par, smoother=orn.GS_RB, quiet=1, TOLERANCE=tol)
+    g = NodeQG(par, strict=True)
+    g.set_option("quiet", 1); g.set_option("TOLERANCE", tol)
+    mk = np.ones((1, N + 1, N + 1))
+    for _ in range(int(rng.integers(0, 4))):       # random rectangular islands
+        i0, j0 = rng.integers(1, N - 3, 2)
+        mk[0, j0: j0 + rng.integers(1, N // 4 + 1), i0: i0 + rng.integers(1, N // 4 + 1)] = 0
+    mk[0, 0, :] = mk[0, -1, :] = mk[0, :, 0] = mk[0, :, -1] = 0
+    psi = orn.node_psi(nl, N) * mk
+    for m_, set_ in ((o, lambda f, a: o.set(getattr(orn, f), a)), (g, lambda f, a: g.set(f, a))):
+        set_("MASK", mk)
+        if nl > 1 and seed % 2 == 0:
+            set_("TOPO", topo_field(N))
+            set_("PSIPG", 0.3 * orn.node_psi(nl, N)[::-1].copy())
+        set_("PSI", psi)
+        m_.set_const()
+    for _ in range(3):
+        o.step(True); g.step(True)
+    desc = f"nl={nl} N={N} {par[-120:]!r}"
+    assert (g.t, g.dt) == (o.t, o.dt), desc
+    assert np.array_equal(g.get("PSI"), o.get(orn.PSI)) and np.array_equal(g.get("Q"), o.get(orn.Q)), desc
