@@ -7,6 +7,8 @@ g.set(F["PSI"], orc.synthetic_psi(nl,N,N)); g.set_const()
 for k in sys.argv[1:] or ["rhs", "sweep", "block2", "block2p", "advance", "residual"]:
     if k.startswith("dbg"):
         g.option("rhs_dbg", int(k[3:])); print("rhs_dbg", k[3:]); continue
+    if k.startswith("rv"):
+        g.option("rhs_variant", int(k[2:])); print("rhs_variant", k[2:]); continue
     if k.startswith("rr"):
         g.option("rhs_resid", int(k[2:])); print("rhs_resid", k[2:]); continue
     if k.startswith("bv"):
