@@ -18,13 +18,7 @@
 // zeta and tmp outside a wall are the Dirichlet ghosts (-interior; corner = +interior),
 // optionally overridden by the partial-slip formula (msqg/qg.h:185-198).  Outside a tile edge
 // that is not a wall the values are computed from the exchanged 3-cell halo of psi.
-#include "kernels.h"
-
-#ifdef MSOM_STRICT
-#define DIVC(x, c, rc) ((x) / (c))
-#else
-#define DIVC(x, c, rc) ((x) * (rc))
-#endif
+#include "rhs_inl.h"
 
 #define FTX 64            // tile width  = one wavefront
 // FTY = tile height, FNT = threads per workgroup are template parameters (tuning variants)
@@ -60,19 +54,6 @@ __device__ __forceinline__ double lane_next(double v) {
 __device__ __forceinline__ double wave_max_f(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
   return v;
-}
-
-// -J(p,q), msqg/qg.h:252-262, from 3x3 register windows [dy+1][dx+1]
-__device__ __forceinline__ double mjac9(const double (&p)[3][3], const double (&q)[3][3], double D12, double rD12) {
-#define P(a, b) p[(b) + 1][(a) + 1]
-#define Q(a, b) q[(b) + 1][(a) + 1]
-  const double s = (Q(1, 0) - Q(-1, 0)) * (P(0, 1) - P(0, -1)) + (Q(0, -1) - Q(0, 1)) * (P(1, 0) - P(-1, 0)) +
-                   Q(1, 0) * (P(1, 1) - P(1, -1)) - Q(-1, 0) * (P(-1, 1) - P(-1, -1)) - Q(0, 1) * (P(1, 1) - P(-1, 1)) +
-                   Q(0, -1) * (P(1, -1) - P(-1, -1)) + P(0, 1) * (Q(1, 1) - Q(-1, 1)) - P(0, -1) * (Q(1, -1) - Q(-1, -1)) -
-                   P(1, 0) * (Q(1, 1) - Q(1, -1)) + P(-1, 0) * (Q(-1, 1) - Q(-1, -1));
-#undef P
-#undef Q
-  return DIVC(s, D12, rD12);
 }
 
 // One element of lap(src) -> dst with the wall boundary conditions.  dst is a W x H LDS tile
@@ -662,8 +643,13 @@ void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const 
                       double *umax_partial, double *umax_out, const NatGeom &g, int nl, int walls, int uniformS, const double *Su,
                       int have_qforc, double D, double beta, double iRe, double iRe4, double cs, double cb, double slip_c,
                       const LayerCoef &lc, int variant, const double *q_in, double *q_out, double dt, const RhsResid *rr) {
-  RhsArgs a;
   extern int g_rhs_dbg;
+  if (variant == 6) {
+    launch_rhs_lpw(st, psi, S, qforc, wind, dq, g, nl, walls, uniformS, Su, have_qforc, D, beta, iRe, iRe4, cs, cb, slip_c, lc, q_in, q_out, dt,
+                   g_rhs_dbg >> 8);  // tuning: rhs_dbg = rows << 8 overrides the chunk height
+    return;
+  }
+  RhsArgs a;
   a.dbg = g_rhs_dbg;
   a.res = a.res_c = a.res_max = a.bsum_partial = nullptr;
   if (rr && variant == 1 && q_out) {

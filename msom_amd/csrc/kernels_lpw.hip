@@ -1,0 +1,277 @@
+// kernels_lpw.hip -- the PV tendency dq/dt = F(psi) (+ the fused advance), "one layer per wavefront" schedule.
+//
+// Same arithmetic as kernels_fused.hip (comp_del2 -> advection_pv -> dissip -> ekman_friction -> surface_forcing ->
+// qforcing -> advance_qg, msqg/qg.h:172-246,288-380,407-474,594-606), different mapping.  PMC counters of
+// k_rhs_fused_pipe at 4096^2 x 6 (profiles/r01_pmc_sq_rhs.json): ~200 vector instructions per cell and layer, waves
+// parked on s_waitcnt / s_barrier 58 % of their life (155 KB of LDS tiles => 2 waves per SIMD).  Here:
+//
+//  * a workgroup is nl wavefronts; wavefront l owns layer l of a strip of 64 columns (58 of them produce output, 3 on
+//    each side are the halo) and marches up the rows of a chunk;
+//  * zeta = lap(psi), tmp = lap(zeta), lap(tmp) and the two Arakawa Jacobians come from sliding REGISTER windows:
+//    a lane keeps its own column of psi (5 rows), zeta (4), tmp (3) and psi_{l+1} (3); the x +- 1 neighbours are
+//    fetched from the adjacent lanes by whole-wave DPP shifts (no LDS tiles, no barriers for the stencils);
+//  * wall ghosts of zeta / tmp (Dirichlet mirror, partial slip, corners; msqg/qg.h:185-198) are produced in the lane /
+//    row that holds the ghost position, from the neighbouring lane (x walls) or the neighbouring row (y walls);
+//  * the only cross-wave traffic is the vertical coupling: every wave publishes 2 numbers per cell (3 in the validation
+//    build) in a double-buffered LDS ring and finalises its rows one barrier interval later (1 barrier per LPW_R rows);
+//  * psi rows, psi_{l+1} rows and q_in are prefetched one interval ahead into registers.
+#include "rhs_inl.h"
+
+#define LPW_W 58  // output columns of a strip (64 lanes - 2 x 3 halo)
+#define LPW_R 4   // rows per barrier interval
+#ifdef MSOM_STRICT
+#define LPW_NV 3  // zeta, tmp, jd
+#else
+#define LPW_NV 2  // X = iRe zeta + iRe4 tmp, jd
+#endif
+
+struct LpwArgs {
+  const double *psi, *S, *qforc, *wind, *q_in;
+  double *dq, *q_out;  // q_out != 0: q_out = q_in + dt * dq (msqg/qg.h:602), dq not stored
+  double dt;
+  NatGeom g;
+  int nl, walls, uniformS, have_qforc, H;
+  double D, beta, iRe, iRe4, cs, cb, slip_c;
+  LayerCoef lc;
+  double Su[MSOM_MAXNL];
+};
+
+template <int R>
+__global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
+  __shared__ double ring[2][MSOM_MAXNL][R][LPW_NV][64];
+  const int lane = threadIdx.x & 63;
+  const int l = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nl = a.nl, nx = a.g.nx, ny = a.g.ny;
+  const ptrdiff_t pitch = a.g.pitch;
+  const int x0 = blockIdx.x * LPW_W, y0 = blockIdx.y * a.H, y1 = min(ny, y0 + a.H);
+  const int gi = x0 - 3 + lane, gic = min(gi, nx + 2);  // lanes past the padded row re-read its last column (never stored)
+  const double D = a.D, D2 = D * D, rD2 = 1. / D2, D12 = 12. * D * D, rD12 = 1. / D12, D2x = 2 * D, rD2x = 1. / D2x;
+  const bool lower = l + 1 < nl, upper = l > 0;
+  // lanes / rows that hold the first ghost line of a wall
+  const int lW = ((a.walls & WALL_W) && x0 == 0) ? 2 : -1;
+  const int eL = nx - x0 + 3;
+  const int lE = ((a.walls & WALL_E) && eL <= 63) ? eL : -1;
+  const bool bcx = lW >= 0 || lE >= 0;
+  const bool south = (a.walls & WALL_S) != 0, north = (a.walls & WALL_N) != 0;
+  const bool slip = a.slip_c > 0.;
+  const bool out_ok = lane >= 3 && lane <= 60 && gi < nx;
+  const double *pP = a.psi + nat_idx(a.g, l, 0, gic);
+  const double *pQ = pP + a.g.ls;  // psi of the layer below (read only when lower)
+
+  // register windows; index k of P, Z, T, Q = row j - 1 + k of the current output row j
+  double P[5], PL[4], PR[4], Z[4], ZL[4], ZR[4], T[3], TL[2], TR[2], Q[3], QL[3], QR[3];
+#pragma unroll
+  for (int k = 0; k < 5; k++) P[k] = 0.;
+#pragma unroll
+  for (int k = 0; k < 4; k++) PL[k] = PR[k] = Z[k] = ZL[k] = ZR[k] = 0.;
+#pragma unroll
+  for (int k = 0; k < 3; k++) T[k] = Q[k] = QL[k] = QR[k] = 0.;
+  TL[0] = TL[1] = TR[0] = TR[1] = 0.;
+
+  // values of a row kept for the finalisation one interval later
+#ifdef MSOM_STRICT
+  double abA[R], jdA[R], lapTA[R], zcA[R], tcA[R];
+#else
+  double tlA[R];
+#endif
+  double pnext[R], qnext[R], qreg[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+#ifdef MSOM_STRICT
+    abA[r] = jdA[r] = lapTA[r] = zcA[r] = tcA[r] = 0.;
+#else
+    tlA[r] = 0.;
+#endif
+    pnext[r] = qnext[r] = qreg[r] = 0.;
+  }
+
+  auto ld = [&](const double *base, int j) -> double { return base[(ptrdiff_t)min(j, ny + 2) * pitch]; };
+  auto lap5 = [&](double c, double w, double e, double n, double s) -> double { return DIVC(e + w + n + s - 4 * c, D2, rD2); };
+  // x walls: the ghost lane takes -dst(mirror lane) or the partial-slip value c (src(mirror) - src(ghost))
+  auto xfix = [&](double raw, double so, double sw, double se) -> double {
+    if (bcx) {
+      if (slip) {
+        if (lane == lW) raw = a.slip_c * (se - so);
+        if (lane == lE) raw = a.slip_c * (sw - so);
+      } else {
+        const double re = lane_above(raw), rw = lane_below(raw);
+        if (lane == lW) raw = -re;
+        if (lane == lE) raw = -rw;
+      }
+    }
+    return raw;
+  };
+  // y walls: the ghost row from its mirror row (dm with neighbours dmw, dme); corners take +dst(mirror, mirror)
+  auto yghost = [&](double dm, double dmw, double dme, double sm, double sg) -> double {
+    double v = slip ? a.slip_c * (sm - sg) : -dm;
+    if (lane == lW) v = dme;
+    if (lane == lE) v = dmw;
+    return v;
+  };
+
+  // one marching step: psi row j + 3 and psi_{l+1} row j + 1 enter, zeta row j + 2 and tmp row j + 1 are built, the
+  // centre terms of row j are computed and published (slot r of ring buffer b)
+  auto row = [&](int j, double pnew, double qnew, bool centre, int b, int r) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) P[k] = P[k + 1];
+    P[4] = pnew;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { PL[k] = PL[k + 1]; PR[k] = PR[k + 1]; Z[k] = Z[k + 1]; ZL[k] = ZL[k + 1]; ZR[k] = ZR[k + 1]; }
+    T[0] = T[1]; T[1] = T[2]; TL[0] = TL[1]; TR[0] = TR[1];
+#pragma unroll
+    for (int k = 0; k < 2; k++) { Q[k] = Q[k + 1]; QL[k] = QL[k + 1]; QR[k] = QR[k + 1]; }
+    Q[2] = qnew; QL[2] = lane_below(qnew); QR[2] = lane_above(qnew);
+    PL[3] = lane_below(P[3]); PR[3] = lane_above(P[3]);
+    // zeta row j + 2
+    double z;
+    if (north && j + 2 == ny) z = yghost(Z[2], ZL[2], ZR[2], P[2], P[3]);
+    else z = xfix(lap5(P[3], PL[3], PR[3], P[4], P[2]), P[3], PL[3], PR[3]);
+    Z[3] = z; ZL[3] = lane_below(z); ZR[3] = lane_above(z);
+    if (south && j + 2 == 0) {  // row -1 is the ghost of row 0, which exists only now
+      Z[2] = yghost(Z[3], ZL[3], ZR[3], P[3], P[2]);
+      ZL[2] = lane_below(Z[2]); ZR[2] = lane_above(Z[2]);
+    }
+    // tmp = lap(zeta), row j + 1
+    double t;
+    if (north && j + 1 == ny) t = yghost(T[1], TL[0], TR[0], Z[1], Z[2]);
+    else t = xfix(lap5(Z[2], ZL[2], ZR[2], Z[3], Z[1]), Z[2], ZL[2], ZR[2]);
+    T[2] = t; TL[1] = lane_below(t); TR[1] = lane_above(t);
+    if (south && j + 1 == 0) T[1] = yghost(T[2], TL[1], TR[1], Z[2], Z[1]);
+    if (!centre) return;
+
+    double p[3][3], zz[3][3], p1[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      p[k][0] = PL[k]; p[k][1] = P[k]; p[k][2] = PR[k];
+      zz[k][0] = ZL[k]; zz[k][1] = Z[k]; zz[k][2] = ZR[k];
+      p1[k][0] = QL[k]; p1[k][1] = Q[k]; p1[k][2] = QR[k];
+    }
+    const double adv = mjac9(p, zz, D12, rD12);
+    const double be = DIVC(a.beta * (p[1][0] - p[1][2]), D2x, rD2x);
+    const double jd = lower ? mjac9(p, p1, D12, rD12) : 0.;
+    const double zc = Z[1], tc = T[1];
+    const double lapT = DIVC(TR[0] + TL[0] + T[2] + T[0] - 4 * tc, D2, rD2);
+#ifdef MSOM_STRICT
+    abA[r] = adv + be; jdA[r] = jd; lapTA[r] = lapT; zcA[r] = zc; tcA[r] = tc;
+    ring[b][l][r][0][lane] = zc;
+    ring[b][l][r][1][lane] = tc;
+    ring[b][l][r][2][lane] = jd;
+#else
+    // everything of layer l that does not need the neighbouring layers; the stretching terms share X = iRe zeta + iRe4 tmp
+    double tl = adv + be + a.iRe4 * lapT + tc * a.iRe;
+    if (l == 0) tl -= a.cs * zc + a.wind[min(j, ny - 1)];
+    if (l == nl - 1) tl -= a.cb * zc;
+    tlA[r] = tl;
+    ring[b][l][r][0][lane] = a.iRe * zc + a.iRe4 * tc;
+    ring[b][l][r][1][lane] = jd;
+#endif
+  };
+
+  // finalise row j (slot r of ring buffer b): vertical coupling, forcing, advance; additions in the order of
+  // msqg/qg.h:315-380,407-473 in the validation build
+  auto finish = [&](int j, int b, int r) {
+    const size_t c = nat_idx(a.g, l, j, gic);
+    double s0 = 0., s1 = 0.;
+    if (nl > 1) {
+      if (upper) s0 = a.uniformS ? a.Su[l - 1] : a.S[c - a.g.ls];
+      if (lower) s1 = a.uniformS ? a.Su[l] : a.S[c];
+    }
+#ifdef MSOM_STRICT
+    const double zc = zcA[r], tc = tcA[r];
+    double zm = 0., tm = 0., zp = 0., tp = 0., ju = 0.;
+    if (upper) { zm = ring[b][l - 1][r][0][lane]; tm = ring[b][l - 1][r][1][lane]; ju = -ring[b][l - 1][r][2][lane]; }
+    if (lower) { zp = ring[b][l + 1][r][0][lane]; tp = ring[b][l + 1][r][1][lane]; }
+    double t = abA[r];
+    if (nl > 1) {
+      if (upper) t = t + s0 * ju * a.lc.idh0[l];
+      if (lower) t = t + s1 * jdA[r] * a.lc.idh1[l];
+    }
+    t = 0. + t;  // updates were zeroed, then += (msqg/qg.h:611-613, 315)
+    double dq = t;
+    auto stretch = [&](double fac, double pm, double pc, double pp) -> double {
+      if (l == 0) return fac * s1 * (pp - pc) * a.lc.idh1[l];
+      if (l < nl - 1) return fac * (s0 * (pm - pc) * a.lc.idh0[l] + s1 * (pp - pc) * a.lc.idh1[l]);
+      return fac * s0 * (pm - pc) * a.lc.idh0[l];
+    };
+    if (a.iRe != 0.) {
+      if (nl > 1) dq = 1. * dq + stretch(a.iRe, zm, zc, zp);
+      dq += tc * a.iRe;
+    }
+    if (a.iRe4 != 0.) {
+      if (nl > 1) dq = 1. * dq + stretch(a.iRe4, tm, tc, tp);
+      dq = 1. * dq + a.iRe4 * lapTA[r];
+    }
+    if (l == 0) dq -= a.cs * zc;
+    if (l == nl - 1) dq -= a.cb * zc;
+    if (l == 0) dq -= a.wind[j];
+#else
+    double dq = tlA[r];
+    const double xc = ring[b][l][r][0][lane];
+    if (nl > 1) {
+      if (upper) dq += s0 * a.lc.idh0[l] * ((ring[b][l - 1][r][0][lane] - xc) - ring[b][l - 1][r][1][lane]);
+      if (lower) dq += s1 * a.lc.idh1[l] * ((ring[b][l + 1][r][0][lane] - xc) + ring[b][l][r][1][lane]);
+    }
+#endif
+    if (a.have_qforc) dq += a.qforc[c];
+    if (out_ok) {
+      if (a.q_out) a.q_out[c] = qreg[r] + dq * a.dt;
+      else a.dq[c] = dq;
+    }
+  };
+
+  // rows of the first interval start travelling before the warm-up
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    pnext[r] = ld(pP, y0 + r + 3);
+    if (lower) qnext[r] = ld(pQ, y0 + r + 1);
+  }
+  // warm-up: fill the windows below the chunk (psi rows y0 - 3 .., no centre terms)
+  for (int j = y0 - 6; j < y0; j++) row(j, ld(pP, j + 3), (lower && j + 1 >= y0 - 1) ? ld(pQ, j + 1) : 0., false, 0, 0);
+
+  const int nblk = (y1 - y0 + R - 1) / R;
+  for (int k = 0; k <= nblk; k++) {
+    const int b = k & 1;
+    if (k > 0) {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const int j = y0 + (k - 1) * R + r;
+        if (j < y1) finish(j, b ^ 1, r);
+      }
+    }
+    if (k < nblk) {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const int j = y0 + k * R + r;
+        if (j < y1) {
+          const double pn = pnext[r], qn = qnext[r];
+          pnext[r] = ld(pP, j + R + 3);  // the slot is free: next interval's row starts travelling now
+          if (lower) qnext[r] = ld(pQ, j + R + 1);
+          if (a.q_out) qreg[r] = a.q_in[nat_idx(a.g, l, j, gic)];
+          row(j, pn, qn, true, b, r);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq, const NatGeom &g,
+                    int nl, int walls, int uniformS, const double *Su, int have_qforc, double D, double beta, double iRe, double iRe4, double cs,
+                    double cb, double slip_c, const LayerCoef &lc, const double *q_in, double *q_out, double dt, int chunk_rows) {
+  LpwArgs a;
+  a.psi = psi; a.S = S; a.qforc = qforc; a.wind = wind; a.q_in = q_in; a.dq = dq; a.q_out = q_out; a.dt = dt;
+  a.g = g; a.nl = nl; a.walls = walls; a.uniformS = uniformS; a.have_qforc = have_qforc;
+  a.D = D; a.beta = beta; a.iRe = iRe; a.iRe4 = iRe4; a.cs = cs; a.cb = cb; a.slip_c = slip_c; a.lc = lc;
+  for (int l = 0; l < MSOM_MAXNL; l++) a.Su[l] = Su ? Su[l] : 0.;
+  const int strips = (g.nx + LPW_W - 1) / LPW_W;
+  int H = chunk_rows;
+  if (H <= 0) {  // enough workgroups to fill 256 CUs a few times over, chunks long enough to amortise the 6 warm-up rows
+    const int want = (1024 + strips - 1) / strips;
+    H = (g.ny + want - 1) / want;
+    H = ((H + 7) / 8) * 8;
+    if (H > 64) H = 64;
+  }
+  if (H < 8) H = 8;
+  a.H = H;
+  hipLaunchKernelGGL((k_rhs_lpw<LPW_R>), dim3(strips, (g.ny + H - 1) / H), dim3(64 * nl), 0, st, a);
+}
