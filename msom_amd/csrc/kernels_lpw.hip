@@ -57,6 +57,16 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
   const bool out_ok = lane >= 3 && lane <= 60 && gi < nx;
   const double *pP = a.psi + nat_idx(a.g, l, 0, gic);
   const double *pQ = pP + a.g.ls;  // psi of the layer below (read only when lower)
+  // per-layer constants of this wavefront (scalar registers for the whole kernel)
+  const double idh0 = a.lc.idh0[l], idh1 = a.lc.idh1[l];
+  const double su0 = (nl > 1 && upper) ? a.Su[l - 1] : 0., su1 = (nl > 1 && lower) ? a.Su[l] : 0.;
+  // wind stress curl of the chunk's rows (layer 0): lane k holds row y0 + k (H <= 64), read back with v_readlane
+  const double windv = l == 0 ? a.wind[min(y0 + lane, ny - 1)] : 0.;
+  auto wind_row = [&](int j) -> double {
+    const long long b = __double_as_longlong(windv);
+    const int lo = __builtin_amdgcn_readlane((int)b, j - y0), hi = __builtin_amdgcn_readlane((int)(b >> 32), j - y0);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  };
 
   // register windows; index k of P, Z, T, Q = row j - 1 + k of the current output row j
   double P[5], PL[4], PR[4], Z[4], ZL[4], ZR[4], T[3], TL[2], TR[2], Q[3], QL[3], QR[3];
@@ -159,7 +169,7 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
 #else
     // everything of layer l that does not need the neighbouring layers; the stretching terms share X = iRe zeta + iRe4 tmp
     double tl = adv + be + a.iRe4 * lapT + tc * a.iRe;
-    if (l == 0) tl -= a.cs * zc + a.wind[min(j, ny - 1)];
+    if (l == 0) tl -= a.cs * zc + wind_row(j);
     if (l == nl - 1) tl -= a.cb * zc;
     tlA[r] = tl;
     ring[b][l][r][0][lane] = a.iRe * zc + a.iRe4 * tc;
@@ -168,14 +178,8 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
   };
 
   // finalise row j (slot r of ring buffer b): vertical coupling, forcing, advance; additions in the order of
-  // msqg/qg.h:315-380,407-473 in the validation build
-  auto finish = [&](int j, int b, int r) {
-    const size_t c = nat_idx(a.g, l, j, gic);
-    double s0 = 0., s1 = 0.;
-    if (nl > 1) {
-      if (upper) s0 = a.uniformS ? a.Su[l - 1] : a.S[c - a.g.ls];
-      if (lower) s1 = a.uniformS ? a.Su[l] : a.S[c];
-    }
+  // msqg/qg.h:315-380,407-473 in the validation build.  Returns the value to store (q_out or dq)
+  auto finish = [&](int j, int b, int r, double s0, double s1, double fq) -> double {
 #ifdef MSOM_STRICT
     const double zc = zcA[r], tc = tcA[r];
     double zm = 0., tm = 0., zp = 0., tp = 0., ju = 0.;
@@ -183,15 +187,15 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
     if (lower) { zp = ring[b][l + 1][r][0][lane]; tp = ring[b][l + 1][r][1][lane]; }
     double t = abA[r];
     if (nl > 1) {
-      if (upper) t = t + s0 * ju * a.lc.idh0[l];
-      if (lower) t = t + s1 * jdA[r] * a.lc.idh1[l];
+      if (upper) t = t + s0 * ju * idh0;
+      if (lower) t = t + s1 * jdA[r] * idh1;
     }
     t = 0. + t;  // updates were zeroed, then += (msqg/qg.h:611-613, 315)
     double dq = t;
     auto stretch = [&](double fac, double pm, double pc, double pp) -> double {
-      if (l == 0) return fac * s1 * (pp - pc) * a.lc.idh1[l];
-      if (l < nl - 1) return fac * (s0 * (pm - pc) * a.lc.idh0[l] + s1 * (pp - pc) * a.lc.idh1[l]);
-      return fac * s0 * (pm - pc) * a.lc.idh0[l];
+      if (l == 0) return fac * s1 * (pp - pc) * idh1;
+      if (l < nl - 1) return fac * (s0 * (pm - pc) * idh0 + s1 * (pp - pc) * idh1);
+      return fac * s0 * (pm - pc) * idh0;
     };
     if (a.iRe != 0.) {
       if (nl > 1) dq = 1. * dq + stretch(a.iRe, zm, zc, zp);
@@ -203,20 +207,17 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
     }
     if (l == 0) dq -= a.cs * zc;
     if (l == nl - 1) dq -= a.cb * zc;
-    if (l == 0) dq -= a.wind[j];
+    if (l == 0) dq -= wind_row(j);
 #else
     double dq = tlA[r];
     const double xc = ring[b][l][r][0][lane];
     if (nl > 1) {
-      if (upper) dq += s0 * a.lc.idh0[l] * ((ring[b][l - 1][r][0][lane] - xc) - ring[b][l - 1][r][1][lane]);
-      if (lower) dq += s1 * a.lc.idh1[l] * ((ring[b][l + 1][r][0][lane] - xc) + ring[b][l][r][1][lane]);
+      if (upper) dq += s0 * idh0 * ((ring[b][l - 1][r][0][lane] - xc) - ring[b][l - 1][r][1][lane]);
+      if (lower) dq += s1 * idh1 * ((ring[b][l + 1][r][0][lane] - xc) + ring[b][l][r][1][lane]);
     }
 #endif
-    if (a.have_qforc) dq += a.qforc[c];
-    if (out_ok) {
-      if (a.q_out) a.q_out[c] = qreg[r] + dq * a.dt;
-      else a.dq[c] = dq;
-    }
+    if (a.have_qforc) dq += fq;
+    return a.q_out ? qreg[r] + dq * a.dt : dq;
   };
 
   // rows of the first interval start travelling before the warm-up
@@ -228,27 +229,40 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
   // warm-up: fill the windows below the chunk (psi rows y0 - 3 .., no centre terms)
   for (int j = y0 - 6; j < y0; j++) row(j, ld(pP, j + 3), (lower && j + 1 >= y0 - 1) ? ld(pQ, j + 1) : 0., false, 0, 0);
 
+  // Rows past the end of a ragged chunk are computed on clamped addresses and never stored: the unrolled body has no
+  // row-dependent branch (precise s_waitcnt counters, no register shuffles at control-flow joins).
+  double *const outp = a.q_out ? a.q_out : a.dq;
   const int nblk = (y1 - y0 + R - 1) / R;
   for (int k = 0; k <= nblk; k++) {
     const int b = k & 1;
     if (k > 0) {
+      const int jb = y0 + (k - 1) * R;
+      double s0[R], s1[R], fq[R], val[R];
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        const int j = y0 + (k - 1) * R + r;
-        if (j < y1) finish(j, b ^ 1, r);
+      for (int r = 0; r < R; r++) {  // per-cell inputs of the finalisation first, one wait for all of them
+        const size_t c = nat_idx(a.g, l, min(jb + r, ny - 1), gic);
+        s0[r] = su0; s1[r] = su1; fq[r] = 0.;
+        if (nl > 1 && !a.uniformS) {
+          if (upper) s0[r] = a.S[c - a.g.ls];
+          if (lower) s1[r] = a.S[c];
+        }
+        if (a.have_qforc) fq[r] = a.qforc[c];
       }
+#pragma unroll
+      for (int r = 0; r < R; r++) val[r] = finish(jb + r, b ^ 1, r, s0[r], s1[r], fq[r]);
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (out_ok && jb + r < y1) outp[nat_idx(a.g, l, jb + r, gic)] = val[r];
     }
     if (k < nblk) {
 #pragma unroll
       for (int r = 0; r < R; r++) {
         const int j = y0 + k * R + r;
-        if (j < y1) {
-          const double pn = pnext[r], qn = qnext[r];
-          pnext[r] = ld(pP, j + R + 3);  // the slot is free: next interval's row starts travelling now
-          if (lower) qnext[r] = ld(pQ, j + R + 1);
-          if (a.q_out) qreg[r] = a.q_in[nat_idx(a.g, l, j, gic)];
-          row(j, pn, qn, true, b, r);
-        }
+        const double pn = pnext[r], qn = qnext[r];
+        pnext[r] = ld(pP, j + R + 3);  // the slot is free: next interval's row starts travelling now
+        if (lower) qnext[r] = ld(pQ, j + R + 1);
+        if (a.q_out) qreg[r] = a.q_in[nat_idx(a.g, l, min(j, ny - 1), gic)];
+        row(j, pn, qn, true, b, r);
       }
     }
     __syncthreads();
