@@ -36,7 +36,9 @@ struct LpwArgs {
   double Su[MSOM_MAXNL];
 };
 
-template <int R>
+// UNI: uniform S (constants), QF: 3-D forcing present, ADV: advance fused.  Compile-time so that the unrolled row body
+// is straight-line code: s_waitcnt counters stay exact and a wave never waits for a prefetch it does not need yet
+template <int R, bool UNI, bool QF, bool ADV>
 __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
   __shared__ double ring[2][MSOM_MAXNL][R][LPW_NV][64];
   const int lane = threadIdx.x & 63;
@@ -56,7 +58,9 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
   const bool slip = a.slip_c > 0.;
   const bool out_ok = lane >= 3 && lane <= 60 && gi < nx;
   const double *pP = a.psi + nat_idx(a.g, l, 0, gic);
-  const double *pQ = pP + a.g.ls;  // psi of the layer below (read only when lower)
+  // psi of the layer below; the bottom layer re-reads its own rows (value unused) so that every wave issues the same
+  // sequence of loads and the s_waitcnt counters are exact
+  const double *pQ = lower ? pP + a.g.ls : pP;
   // per-layer constants of this wavefront (scalar registers for the whole kernel)
   const double idh0 = a.lc.idh0[l], idh1 = a.lc.idh1[l];
   const double su0 = (nl > 1 && upper) ? a.Su[l - 1] : 0., su1 = (nl > 1 && lower) ? a.Su[l] : 0.;
@@ -84,7 +88,7 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
 #else
   double tlA[R];
 #endif
-  double pnext[R], qnext[R], qreg[R];
+  double pnext[R], qnext[R], qreg[R], fqreg[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
 #ifdef MSOM_STRICT
@@ -92,7 +96,7 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
 #else
     tlA[r] = 0.;
 #endif
-    pnext[r] = qnext[r] = qreg[r] = 0.;
+    pnext[r] = qnext[r] = qreg[r] = fqreg[r] = 0.;
   }
 
   auto ld = [&](const double *base, int j) -> double { return base[(ptrdiff_t)min(j, ny + 2) * pitch]; };
@@ -216,52 +220,69 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
       if (lower) dq += s1 * idh1 * ((ring[b][l + 1][r][0][lane] - xc) + ring[b][l][r][1][lane]);
     }
 #endif
-    if (a.have_qforc) dq += fq;
-    return a.q_out ? qreg[r] + dq * a.dt : dq;
+    if (QF) dq += fq;
+    return ADV ? qreg[r] + dq * a.dt : dq;
   };
 
   // rows of the first interval start travelling before the warm-up
 #pragma unroll
   for (int r = 0; r < R; r++) {
     pnext[r] = ld(pP, y0 + r + 3);
-    if (lower) qnext[r] = ld(pQ, y0 + r + 1);
+    qnext[r] = ld(pQ, y0 + r + 1);
   }
   // warm-up: fill the windows below the chunk (psi rows y0 - 3 .., no centre terms)
   for (int j = y0 - 6; j < y0; j++) row(j, ld(pP, j + 3), (lower && j + 1 >= y0 - 1) ? ld(pQ, j + 1) : 0., false, 0, 0);
 
   // Rows past the end of a ragged chunk are computed on clamped addresses and never stored: the unrolled body has no
   // row-dependent branch (precise s_waitcnt counters, no register shuffles at control-flow joins).
-  double *const outp = a.q_out ? a.q_out : a.dq;
+  double *const outp = ADV ? a.q_out : a.dq;
   const int nblk = (y1 - y0 + R - 1) / R;
+  // enter the loop with no load in flight: the compiler merges the pending-load state of the pre-header with that of
+  // the back-edge, and a pre-header full of warm-up loads made it drain every prefetch at the top of each interval
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   for (int k = 0; k <= nblk; k++) {
     const int b = k & 1;
     if (k > 0) {
       const int jb = y0 + (k - 1) * R;
-      double s0[R], s1[R], fq[R], val[R];
+      double s0[R], s1[R], val[R];
 #pragma unroll
-      for (int r = 0; r < R; r++) {  // per-cell inputs of the finalisation first, one wait for all of them
-        const size_t c = nat_idx(a.g, l, min(jb + r, ny - 1), gic);
-        s0[r] = su0; s1[r] = su1; fq[r] = 0.;
-        if (nl > 1 && !a.uniformS) {
+      for (int r = 0; r < R; r++) {
+        s0[r] = su0; s1[r] = su1;
+        if (!UNI && nl > 1) {  // general S field: read per cell (not prefetched)
+          const size_t c = nat_idx(a.g, l, min(jb + r, ny - 1), gic);
           if (upper) s0[r] = a.S[c - a.g.ls];
           if (lower) s1[r] = a.S[c];
         }
-        if (a.have_qforc) fq[r] = a.qforc[c];
       }
 #pragma unroll
-      for (int r = 0; r < R; r++) val[r] = finish(jb + r, b ^ 1, r, s0[r], s1[r], fq[r]);
+      for (int r = 0; r < R; r++) {
+        val[r] = finish(jb + r, b ^ 1, r, s0[r], s1[r], fqreg[r]);
+        asm volatile("" : "+v"(val[r]));  // keep the last use of the prefetched q_in outside the predicated store
+      }
 #pragma unroll
       for (int r = 0; r < R; r++)
         if (out_ok && jb + r < y1) outp[nat_idx(a.g, l, jb + r, gic)] = val[r];
     }
     if (k < nblk) {
+      const int j0 = y0 + k * R;
+      // the inputs of the NEXT finalisation first: they are the oldest loads in flight when it starts
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        const int j = y0 + k * R + r;
-        const double pn = pnext[r], qn = qnext[r];
-        pnext[r] = ld(pP, j + R + 3);  // the slot is free: next interval's row starts travelling now
-        if (lower) qnext[r] = ld(pQ, j + R + 1);
-        if (a.q_out) qreg[r] = a.q_in[nat_idx(a.g, l, min(j, ny - 1), gic)];
+        const size_t c = nat_idx(a.g, l, min(j0 + r, ny - 1), gic);
+        if (ADV) qreg[r] = a.q_in[c];
+        if (QF) fqreg[r] = a.qforc[c];
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const int j = j0 + r;
+        // a REAL register copy (opaque to the compiler): the prefetch register is dead right here, so the next
+        // interval's load can land in the same physical register and no in-flight register is moved at the loop
+        // back-edge (a coalesced copy made the allocator shuffle loaded registers there => s_waitcnt vmcnt(0))
+        double pn, qn;
+        asm volatile("v_mov_b64 %0, %1" : "=v"(pn) : "v"(pnext[r]));
+        asm volatile("v_mov_b64 %0, %1" : "=v"(qn) : "v"(qnext[r]));
+        pnext[r] = ld(pP, j + R + 3);
+        qnext[r] = ld(pQ, j + R + 1);
         row(j, pn, qn, true, b, r);
       }
     }
@@ -287,5 +308,16 @@ void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const do
   }
   if (H < 8) H = 8;
   a.H = H;
-  hipLaunchKernelGGL((k_rhs_lpw<LPW_R>), dim3(strips, (g.ny + H - 1) / H), dim3(64 * nl), 0, st, a);
+  const dim3 gr(strips, (g.ny + H - 1) / H), bl(64 * nl);
+  const int sel = (uniformS ? 4 : 0) | (have_qforc ? 2 : 0) | (q_out ? 1 : 0);
+  switch (sel) {
+    case 0: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, false, false, false>), gr, bl, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, false, false, true>), gr, bl, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, false, true, false>), gr, bl, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, false, true, true>), gr, bl, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, true, false, false>), gr, bl, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, true, false, true>), gr, bl, 0, st, a); break;
+    case 6: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, true, true, false>), gr, bl, 0, st, a); break;
+    default: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, true, true, true>), gr, bl, 0, st, a); break;
+  }
 }
