@@ -239,7 +239,7 @@ def main():
                 "avg_launch_ms": launch_ms,
                 "launches_timed": 2 * sweep_n,
                 "tendency_kernel": {
-                    "kernel": "k_rhs_fused_pipe<32, 512, false> (Arakawa Jacobians + beta + dissipation + drag + forcing + advance, one pass over psi)",
+                    "kernel": "k_rhs_lpw<4, true, false, true> (Arakawa Jacobians + beta + dissipation + drag + forcing + advance, one pass over psi)",
                     "avg_launch_ms": rhs_ms,
                     "algorithmic_bytes_per_launch": 3.0 * w,
                     "achieved_GBs": 3.0 * w / (rhs_ms * 1e-3) / 1e9 if rhs_ms > 0 else 0.0,
@@ -247,7 +247,7 @@ def main():
                     "fp64_flop_per_point_layer": 215,
                     "achieved_fp64_TFLOPs": 215.0 * N * N * nl / (rhs_ms * 1e-3) / 1e12 if rhs_ms > 0 else 0.0,
                     "note": "fused: reads psi and q_in once, writes q_out once (the reference's loop chain moves ~25 w); "
-                            "LDS-latency / fp64-issue bound (155 KB of LDS per workgroup, 256 VGPRs), not HBM bound",
+                            "one layer per wavefront, stencils from register windows + whole-wave DPP shifts; fp64-issue / wait bound (3 waves per SIMD), not HBM bound",
                 },
                 "residual_kernels": {
                     "avg_launch_ms": resid_ms, "launches_timed": resid_n,

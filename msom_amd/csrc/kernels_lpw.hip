@@ -230,8 +230,16 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
     pnext[r] = ld(pP, y0 + r + 3);
     qnext[r] = ld(pQ, y0 + r + 1);
   }
-  // warm-up: fill the windows below the chunk (psi rows y0 - 3 .., no centre terms)
-  for (int j = y0 - 6; j < y0; j++) row(j, ld(pP, j + 3), (lower && j + 1 >= y0 - 1) ? ld(pQ, j + 1) : 0., false, 0, 0);
+  // warm-up: fill the windows below the chunk (psi rows y0 - 3 .. y0 + 2, psi_{l+1} rows y0 - 1, y0; no centre terms).
+  // All eight rows are requested before the first one is used (one memory latency per chunk instead of six)
+  {
+    double wp[6], wq[2];
+#pragma unroll
+    for (int k = 0; k < 6; k++) wp[k] = ld(pP, y0 - 3 + k);
+    wq[0] = ld(pQ, y0 - 1); wq[1] = ld(pQ, y0);
+#pragma unroll
+    for (int k = 0; k < 6; k++) row(y0 - 6 + k, wp[k], k >= 4 ? wq[k - 4] : 0., false, 0, 0);
+  }
 
   // Rows past the end of a ragged chunk are computed on clamped addresses and never stored: the unrolled body has no
   // row-dependent branch (precise s_waitcnt counters, no register shuffles at control-flow joins).

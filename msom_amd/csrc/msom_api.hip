@@ -99,7 +99,7 @@ struct msom {
   int block_sweeps = 0;  // experimental temporally blocked smoother (2 sweeps per pass); measured not faster at nl = 6
   int mg_fused = 1;  // fused residual+restriction and correction+residual passes of the multigrid cycle
   double *psi_alt = nullptr;  // second psi buffer (the fused correction writes out of place)
-  int rhs_variant = 1;  // 1: software-pipelined fused tendency kernel (default), 0: phase-by-phase version
+  int rhs_variant = 6;  // 6: one layer per wavefront, register windows (kernels_lpw.hip, default); 1: LDS tiles, software-pipelined; 0: LDS tiles, phase by phase
   int fused = 1;  // one-pass PV tendency kernel (kernels_fused.hip) when the configuration allows
   unsigned seed = 1, noise_draw = 0;
   int quiet = 0;
@@ -1187,7 +1187,9 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
     if (m->bc == BC_PERIODIC) launch_fill_periodic(m->st, m->f[MSOM_PSI], m->g, nl, 3);
     if (!m->adv_fused) adv_out = -1;
     // the advance rides along: the pass can also emit the first residual of the inversion of q[adv_out]
-    const bool use_rr = adv_out >= 0 && m->rhs_resid && m->rhs_variant == 1 && m->mg_fused && m->nlev > 1 && m->bc != BC_PERIODIC;
+    // the residual by-product exists only in the LDS-tile kernel: asking for it selects that kernel
+    const int variant = (m->rhs_resid && m->rhs_variant == 6) ? 1 : m->rhs_variant;
+    const bool use_rr = adv_out >= 0 && m->rhs_resid && variant == 1 && m->mg_fused && m->nlev > 1 && m->bc != BC_PERIODIC;
     RhsResid rr;
     if (use_rr) {
       rr.res = m->res[0]; rr.res_c = m->res[1]; rr.res_max = m->d_scal + SC_RESF; rr.bsum_partial = m->partial_rr;
@@ -1197,7 +1199,7 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
     launch_rhs_fused(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, m->f[dqfield], nullptr,
                      nullptr, m->g, nl, m->walls & WALL_ALL, m->uniformS, m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe,
                      iRe4, Eks / (p.Rom * 2 * m->dhf[0]), Ekb / (p.Rom * 2 * m->dhf[nl - 1]),
-                     p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, m->rhs_variant, adv_out >= 0 ? m->f[adv_in] : nullptr,
+                     p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, variant, adv_out >= 0 ? m->f[adv_in] : nullptr,
                      adv_out >= 0 ? m->f[adv_out] : nullptr, adv_dt, use_rr ? &rr : nullptr);
     if (use_rr) m->res_ready = adv_out;
     if (advanced && adv_out >= 0) *advanced = 1;
