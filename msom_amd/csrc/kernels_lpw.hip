@@ -19,10 +19,15 @@
 
 #define LPW_W 58  // output columns of a strip (64 lanes - 2 x 3 halo)
 #define LPW_R 4   // rows per barrier interval
+// A workgroup is floor(LPW_MAXW / nl) strips x nl layers.  12 wavefronts = 3 per SIMD is what the register budget of the
+// product build allows (<= 168 VGPRs); a 6-wave workgroup (one strip of 6 layers) left every CU with ONE resident
+// workgroup (2 + 2 + 1 + 1 waves on the SIMDs: the second one did not fit) -- measured 6 waves per CU
 #ifdef MSOM_STRICT
 #define LPW_NV 3  // zeta, tmp, jd
+#define LPW_MAXW 8
 #else
 #define LPW_NV 2  // X = iRe zeta + iRe4 tmp, jd
+#define LPW_MAXW 12
 #endif
 
 struct LpwArgs {
@@ -30,7 +35,7 @@ struct LpwArgs {
   double *dq, *q_out;  // q_out != 0: q_out = q_in + dt * dq (msqg/qg.h:602), dq not stored
   double dt;
   NatGeom g;
-  int nl, walls, uniformS, have_qforc, H;
+  int nl, walls, uniformS, have_qforc, H, NS;  // NS strips per workgroup
   double D, beta, iRe, iRe4, cs, cb, slip_c;
   LayerCoef lc;
   double Su[MSOM_MAXNL];
@@ -39,13 +44,16 @@ struct LpwArgs {
 // UNI: uniform S (constants), QF: 3-D forcing present, ADV: advance fused.  Compile-time so that the unrolled row body
 // is straight-line code: s_waitcnt counters stay exact and a wave never waits for a prefetch it does not need yet
 template <int R, bool UNI, bool QF, bool ADV>
-__global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
-  __shared__ double ring[2][MSOM_MAXNL][R][LPW_NV][64];
+__global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
+  __shared__ double ring[2][LPW_MAXW][R][LPW_NV][64];
   const int lane = threadIdx.x & 63;
-  const int l = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // ring slot; wv +- 1 = neighbouring layers of the strip
   const int nl = a.nl, nx = a.g.nx, ny = a.g.ny;
+  const int l = wv % nl;
   const ptrdiff_t pitch = a.g.pitch;
-  const int x0 = blockIdx.x * LPW_W, y0 = blockIdx.y * a.H, y1 = min(ny, y0 + a.H);
+  // strips past the right edge (last workgroup of a row) repeat the last strip and store nothing
+  const int strip = blockIdx.x * a.NS + wv / nl, nstrips = (nx + LPW_W - 1) / LPW_W;
+  const int x0 = min(strip, nstrips - 1) * LPW_W, y0 = blockIdx.y * a.H, y1 = min(ny, y0 + a.H);
   const int gi = x0 - 3 + lane, gic = min(gi, nx + 2);  // lanes past the padded row re-read its last column (never stored)
   const double D = a.D, D2 = D * D, rD2 = 1. / D2, D12 = 12. * D * D, rD12 = 1. / D12, D2x = 2 * D, rD2x = 1. / D2x;
   const bool lower = l + 1 < nl, upper = l > 0;
@@ -56,7 +64,7 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
   const bool bcx = lW >= 0 || lE >= 0;
   const bool south = (a.walls & WALL_S) != 0, north = (a.walls & WALL_N) != 0;
   const bool slip = a.slip_c > 0.;
-  const bool out_ok = lane >= 3 && lane <= 60 && gi < nx;
+  const bool out_ok = lane >= 3 && lane <= 60 && gi < nx && strip < nstrips;
   const double *pP = a.psi + nat_idx(a.g, l, 0, gic);
   // psi of the layer below; the bottom layer re-reads its own rows (value unused) so that every wave issues the same
   // sequence of loads and the s_waitcnt counters are exact
@@ -167,17 +175,17 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
     const double lapT = DIVC(TR[0] + TL[0] + T[2] + T[0] - 4 * tc, D2, rD2);
 #ifdef MSOM_STRICT
     abA[r] = adv + be; jdA[r] = jd; lapTA[r] = lapT; zcA[r] = zc; tcA[r] = tc;
-    ring[b][l][r][0][lane] = zc;
-    ring[b][l][r][1][lane] = tc;
-    ring[b][l][r][2][lane] = jd;
+    ring[b][wv][r][0][lane] = zc;
+    ring[b][wv][r][1][lane] = tc;
+    ring[b][wv][r][2][lane] = jd;
 #else
     // everything of layer l that does not need the neighbouring layers; the stretching terms share X = iRe zeta + iRe4 tmp
     double tl = adv + be + a.iRe4 * lapT + tc * a.iRe;
     if (l == 0) tl -= a.cs * zc + wind_row(j);
     if (l == nl - 1) tl -= a.cb * zc;
     tlA[r] = tl;
-    ring[b][l][r][0][lane] = a.iRe * zc + a.iRe4 * tc;
-    ring[b][l][r][1][lane] = jd;
+    ring[b][wv][r][0][lane] = a.iRe * zc + a.iRe4 * tc;
+    ring[b][wv][r][1][lane] = jd;
 #endif
   };
 
@@ -187,8 +195,8 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
 #ifdef MSOM_STRICT
     const double zc = zcA[r], tc = tcA[r];
     double zm = 0., tm = 0., zp = 0., tp = 0., ju = 0.;
-    if (upper) { zm = ring[b][l - 1][r][0][lane]; tm = ring[b][l - 1][r][1][lane]; ju = -ring[b][l - 1][r][2][lane]; }
-    if (lower) { zp = ring[b][l + 1][r][0][lane]; tp = ring[b][l + 1][r][1][lane]; }
+    if (upper) { zm = ring[b][wv - 1][r][0][lane]; tm = ring[b][wv - 1][r][1][lane]; ju = -ring[b][wv - 1][r][2][lane]; }
+    if (lower) { zp = ring[b][wv + 1][r][0][lane]; tp = ring[b][wv + 1][r][1][lane]; }
     double t = abA[r];
     if (nl > 1) {
       if (upper) t = t + s0 * ju * idh0;
@@ -214,10 +222,10 @@ __global__ void __launch_bounds__(64 * MSOM_MAXNL) k_rhs_lpw(LpwArgs a) {
     if (l == 0) dq -= wind_row(j);
 #else
     double dq = tlA[r];
-    const double xc = ring[b][l][r][0][lane];
+    const double xc = ring[b][wv][r][0][lane];
     if (nl > 1) {
-      if (upper) dq += s0 * idh0 * ((ring[b][l - 1][r][0][lane] - xc) - ring[b][l - 1][r][1][lane]);
-      if (lower) dq += s1 * idh1 * ((ring[b][l + 1][r][0][lane] - xc) + ring[b][l][r][1][lane]);
+      if (upper) dq += s0 * idh0 * ((ring[b][wv - 1][r][0][lane] - xc) - ring[b][wv - 1][r][1][lane]);
+      if (lower) dq += s1 * idh1 * ((ring[b][wv + 1][r][0][lane] - xc) + ring[b][wv][r][1][lane]);
     }
 #endif
     if (QF) dq += fq;
@@ -316,7 +324,9 @@ void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const do
   }
   if (H < 8) H = 8;
   a.H = H;
-  const dim3 gr(strips, (g.ny + H - 1) / H), bl(64 * nl);
+  a.NS = LPW_MAXW / nl < 1 ? 1 : LPW_MAXW / nl;
+  if (a.NS > strips) a.NS = strips;
+  const dim3 gr((strips + a.NS - 1) / a.NS, (g.ny + H - 1) / H), bl(64 * nl * a.NS);
   const int sel = (uniformS ? 4 : 0) | (have_qforc ? 2 : 0) | (q_out ? 1 : 0);
   switch (sel) {
     case 0: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, false, false, false>), gr, bl, 0, st, a); break;
