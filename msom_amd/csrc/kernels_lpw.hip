@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
 
   // one marching step: psi row j + 3 and psi_{l+1} row j + 1 enter, zeta row j + 2 and tmp row j + 1 are built, the
   // centre terms of row j are computed and published (slot r of ring buffer b)
-  auto row = [&](int j, double pnew, double qnew, bool centre, int b, int r) {
+  auto row = [&](int j, double pnew, double qnew, bool centre, bool yedge, int b, int r) {
 #pragma unroll
     for (int k = 0; k < 4; k++) P[k] = P[k + 1];
     P[4] = pnew;
@@ -144,21 +144,19 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
     for (int k = 0; k < 2; k++) { Q[k] = Q[k + 1]; QL[k] = QL[k + 1]; QR[k] = QR[k + 1]; }
     Q[2] = qnew; QL[2] = lane_below(qnew); QR[2] = lane_above(qnew);
     PL[3] = lane_below(P[3]); PR[3] = lane_above(P[3]);
-    // zeta row j + 2
-    double z;
-    if (north && j + 2 == ny) z = yghost(Z[2], ZL[2], ZR[2], P[2], P[3]);
-    else z = xfix(lap5(P[3], PL[3], PR[3], P[4], P[2]), P[3], PL[3], PR[3]);
+    // zeta row j + 2, tmp = lap(zeta) row j + 1.  Ghost ROWS exist only next to a y wall: `yedge` (wave-uniform, set per
+    // interval) keeps the row tests out of the interior intervals
+    double z = xfix(lap5(P[3], PL[3], PR[3], P[4], P[2]), P[3], PL[3], PR[3]);
+    if (yedge && north && j + 2 == ny) z = yghost(Z[2], ZL[2], ZR[2], P[2], P[3]);
     Z[3] = z; ZL[3] = lane_below(z); ZR[3] = lane_above(z);
-    if (south && j + 2 == 0) {  // row -1 is the ghost of row 0, which exists only now
+    if (yedge && south && j + 2 == 0) {  // row -1 is the ghost of row 0, which exists only now
       Z[2] = yghost(Z[3], ZL[3], ZR[3], P[3], P[2]);
       ZL[2] = lane_below(Z[2]); ZR[2] = lane_above(Z[2]);
     }
-    // tmp = lap(zeta), row j + 1
-    double t;
-    if (north && j + 1 == ny) t = yghost(T[1], TL[0], TR[0], Z[1], Z[2]);
-    else t = xfix(lap5(Z[2], ZL[2], ZR[2], Z[3], Z[1]), Z[2], ZL[2], ZR[2]);
+    double t = xfix(lap5(Z[2], ZL[2], ZR[2], Z[3], Z[1]), Z[2], ZL[2], ZR[2]);
+    if (yedge && north && j + 1 == ny) t = yghost(T[1], TL[0], TR[0], Z[1], Z[2]);
     T[2] = t; TL[1] = lane_below(t); TR[1] = lane_above(t);
-    if (south && j + 1 == 0) T[1] = yghost(T[2], TL[1], TR[1], Z[2], Z[1]);
+    if (yedge && south && j + 1 == 0) T[1] = yghost(T[2], TL[1], TR[1], Z[2], Z[1]);
     if (!centre) return;
 
     double p[3][3], zz[3][3], p1[3][3];
@@ -246,7 +244,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
     for (int k = 0; k < 6; k++) wp[k] = ld(pP, y0 - 3 + k);
     wq[0] = ld(pQ, y0 - 1); wq[1] = ld(pQ, y0);
 #pragma unroll
-    for (int k = 0; k < 6; k++) row(y0 - 6 + k, wp[k], k >= 4 ? wq[k - 4] : 0., false, 0, 0);
+    for (int k = 0; k < 6; k++) row(y0 - 6 + k, wp[k], k >= 4 ? wq[k - 4] : 0., false, true, 0, 0);
   }
 
   // Rows past the end of a ragged chunk are computed on clamped addresses and never stored: the unrolled body has no
@@ -281,6 +279,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
     }
     if (k < nblk) {
       const int j0 = y0 + k * R;
+      const bool yedge = j0 + R + 2 > ny;  // rows j0 .. j0 + R - 1 build zeta / tmp rows up to j0 + R + 1
       // the inputs of the NEXT finalisation first: they are the oldest loads in flight when it starts
 #pragma unroll
       for (int r = 0; r < R; r++) {
@@ -299,7 +298,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
         asm volatile("v_mov_b64 %0, %1" : "=v"(qn) : "v"(qnext[r]));
         pnext[r] = ld(pP, j + R + 3);
         qnext[r] = ld(pQ, j + R + 1);
-        row(j, pn, qn, true, b, r);
+        row(j, pn, qn, true, yedge, b, r);
       }
     }
     __syncthreads();
