@@ -115,6 +115,10 @@ void launch_relax_red_prolong(hipStream_t st, double *da, const double *coarse, 
                               const SplitGeom &sg, int nl, const RelaxCoef &rc, int uniformS, int walls);
 void launch_correct(hipStream_t st, double *a, const NatGeom &g, const double *da, const SplitGeom &sg, int nl, int walls);
 
+// ---- kernels_march.hip: K = 2..4 consecutive half-sweeps in one pass (register windows, out of place)
+int launch_relax_march(hipStream_t st, const double *in, double *out, const double *res, const SplitGeom &sg, int nl, const RelaxCoef &rc, int c1,
+                       int K, int walls, int chunk_rows = 0);
+
 // ---- kernels_wavelet.hip
 void launch_wv_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl);
 void launch_wv_recon(hipStream_t st, const double *s, const double *sc, const double *rc, const double *sig, double *out, const NatGeom &fg,

@@ -1,0 +1,207 @@
+// kernels_march.hip -- K consecutive red-black HALF-sweeps of relax_layer (msqg/poisson_layer.h:75-149) in one pass.
+//
+// The plain smoother (k_relax_color_x2) is HBM-bound at 3 w / 2 per half-sweep: it reads the other colour, reads the
+// residual of its colour and writes its colour.  A half-sweep only needs the values the previous half-sweep produced
+// at the four neighbours, so K of them can be chained while the data is in registers: a wavefront marches up the rows
+// of a strip, half-sweep s runs one row behind half-sweep s - 1, and only the first one reads da from memory
+// (w / 2), only the last two write (w): 2.5 w (+ halo) for K half-sweeps instead of 1.5 K w.
+//
+//  * split layout: a row is [even-x half | odd-x half]; lane k holds the cell pair (2k, 2k+1) of every row, i.e.
+//    one cell of each colour.  N/S neighbours are the lane's own values of rows r +- 1, one of E/W is the lane's
+//    own other-colour value of row r, the other one sits in the adjacent lane: one whole-wave DPP shift per
+//    value (rhs_inl.h), no LDS, no barriers -- every wavefront is an independent workgroup;
+//  * per half-sweep a 3-row window of the previous half-sweep's values (nl doubles per row and lane);
+//  * the column solve is the uniform-S Thomas recurrence of relax_color_pt, same expression order => bit-identical;
+//  * wall ghosts (homogeneous Dirichlet, lagged: ghost = -value of the wall cell at ITS last update) are recreated in
+//    the lane / row that holds the ghost position: after half-sweep s the ghost positions of its colour take
+//    -(value of the mirrored wall cell after half-sweep s - 1); the ghosts of the input come from memory;
+//  * out of place (in -> out): a chunk re-computes K rows of its neighbours (cone of dependence), which those
+//    neighbours overwrite; lanes: 2 x ceil(K/2) halo lanes of 64.
+// Used on one GPU (no halo exchange between half-sweeps), walls (not the periodic domain), uniform S, nl >= 2.
+#include "mg_inl.h"
+#include "rhs_inl.h"
+
+struct MarchArgs {
+  const double *in, *res;
+  double *out;
+  SplitGeom g;
+  int c1;  // colour of the first half-sweep (0 red, 1 black)
+  int walls, H;
+  RelaxCoef rc;
+};
+
+template <int NL, int K>
+__global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
+  constexpr int HL = (K + 1) / 2, OW = 64 - 2 * HL;
+  // residual windows: half-sweeps 1, 3 use the residual of colour c1 at rows t, t - 2; half-sweeps 2, 4 that of the
+  // other colour at rows t - 1, t - 3.  Every residual value is read from memory ONCE and waits in registers
+  constexpr int D1 = K >= 3 ? 3 : 1, D2 = K >= 4 ? 3 : 1;
+  const int lane = threadIdx.x;
+  const int kx = (int)blockIdx.x * OW - HL + lane;
+  const int y0 = blockIdx.y * p.H, y1 = min(p.g.ny, y0 + p.H);
+  const int hk = p.g.hk, ny = p.g.ny, hp = p.g.hp;
+  const ptrdiff_t rp = p.g.rp;
+  const size_t ls = p.g.ls;
+  const int kxc = min(max(kx, -2), hk + 1);  // stays inside the padded half row
+  const bool own_lane = lane >= HL && lane < 64 - HL && kx < hk;  // kx >= 0 follows from lane >= HL
+  const bool wallW = (p.walls & WALL_W) && kx - lane < 0, wallE = (p.walls & WALL_E) && kx - lane + 63 >= hk;  // wave-uniform
+  const bool wallS = (p.walls & WALL_S) != 0, wallN = (p.walls & WALL_N) != 0;
+  const double sqD = p.rc.sqD;
+  auto off = [&](int half, int r) -> ptrdiff_t { return (ptrdiff_t)(min(max(r, -1), ny) + 1) * rp + half * hp + MSOM_SP + kxc; };
+
+  double W[K][3][NL];  // W[s]: values after half-sweep s (s = 0: the input) of rows r - 1, r, r + 1 of the half-sweep that reads them
+#pragma unroll
+  for (int s = 0; s < K; s++)
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int l = 0; l < NL; l++) W[s][q][l] = 0.;
+
+  double R1[D1][NL], R2[D2][NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+#pragma unroll
+    for (int d = 0; d < D1; d++) R1[d][l] = 0.;
+#pragma unroll
+    for (int d = 0; d < D2; d++) R2[d][l] = 0.;
+  }
+  const int c0 = 1 - p.c1;  // colour of the input values
+  // rows y0 - K and y0 - K + 1 of the input fill the first window before half-sweep 1 starts at row y0 - K + 1
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int r = y0 - K + q;
+    const double *src = p.in + off((r + c0) & 1, r);
+#pragma unroll
+    for (int l = 0; l < NL; l++) W[0][q + 1][l] = src[l * ls];
+  }
+  for (int t = y0 - K + 1; t <= y1 + K - 2; t++) {
+#pragma unroll
+    for (int s = 0; s < K; s++)
+#pragma unroll
+      for (int l = 0; l < NL; l++) { W[s][0][l] = W[s][1][l]; W[s][1][l] = W[s][2][l]; }
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+#pragma unroll
+      for (int d = D1 - 1; d > 0; d--) R1[d][l] = R1[d - 1][l];
+#pragma unroll
+      for (int d = D2 - 1; d > 0; d--) R2[d][l] = R2[d - 1][l];
+    }
+    {
+      const double *src = p.in + off((t + 1 + c0) & 1, t + 1);
+      const double *r1 = p.res + off((t + p.c1) & 1, min(max(t, 0), ny - 1));           // colour c1, row t
+      const double *r2 = p.res + off((t - 1 + c0) & 1, min(max(t - 1, 0), ny - 1));      // colour c0, row t - 1
+#pragma unroll
+      for (int l = 0; l < NL; l++) { W[0][2][l] = src[l * ls]; R1[0][l] = r1[l * ls]; R2[0][l] = r2[l * ls]; }
+    }
+#pragma unroll
+    for (int s = 1; s <= K; s++) {
+      const int r = t - (s - 1);                 // row of half-sweep s
+      const int px = (r + p.c1 + s - 1) & 1;     // x parity (= half) of its cells in that row
+      double x[NL];
+      if (wallS && r == -1) {                    // ghost row: -(wall row after the previous half-sweep)
+#pragma unroll
+        for (int l = 0; l < NL; l++) x[l] = -W[s - 1][2][l];
+      } else if (wallN && r == ny) {
+#pragma unroll
+        for (int l = 0; l < NL; l++) x[l] = -W[s - 1][0][l];
+      } else {
+        double rhs[NL], rs[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) rs[l] = (s & 1) ? R1[(s - 1) < D1 ? (s - 1) : 0][l] : R2[(s - 2) >= 0 && (s - 2) < D2 ? (s - 2) : 0][l];
+        if (px) {  // odd-half cells: W is the lane's own even-half value, E the next lane's
+#pragma unroll
+          for (int l = 0; l < NL; l++) {
+            const double a = W[s - 1][1][l];
+            double v = -sqD * rs[l];
+            v += lane_above(a) + a;
+            v += W[s - 1][2][l] + W[s - 1][0][l];
+            rhs[l] = v;
+          }
+        } else {   // even-half cells: E is the lane's own odd-half value, W the previous lane's
+#pragma unroll
+          for (int l = 0; l < NL; l++) {
+            const double a = W[s - 1][1][l];
+            double v = -sqD * rs[l];
+            v += a + lane_below(a);
+            v += W[s - 1][2][l] + W[s - 1][0][l];
+            rhs[l] = v;
+          }
+        }
+#pragma unroll
+        for (int l = 1; l < NL; l++) rhs[l] -= p.rc.w[l] * rhs[l - 1];
+        x[NL - 1] = rhs[NL - 1] * p.rc.it1[NL - 1];
+#pragma unroll
+        for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - p.rc.t2[l] * x[l + 1]) * p.rc.it1[l];
+        // ghost columns of this colour in this row: x = -1 is an odd-half position, x = nx an even-half one
+        if (wallW && px == 1) {
+#pragma unroll
+          for (int l = 0; l < NL; l++) {
+            const double gv = -lane_above(W[s - 1][1][l]);
+            if (kx == -1) x[l] = gv;
+          }
+        }
+        if (wallE && px == 0) {
+#pragma unroll
+          for (int l = 0; l < NL; l++) {
+            const double gv = -lane_below(W[s - 1][1][l]);
+            if (kx == hk) x[l] = gv;
+          }
+        }
+      }
+      if (s < K) {
+#pragma unroll
+        for (int l = 0; l < NL; l++) W[s][2][l] = x[l];
+      }
+      if (s >= K - 1 && r >= y0 && r < y1 && own_lane) {  // the last update of each colour is what the level keeps
+        double *dst = p.out + off(px, r);
+#pragma unroll
+        for (int l = 0; l < NL; l++) dst[l * ls] = x[l];
+        const int i = 2 * kx + px;
+        if (i == 0 || i == p.g.nx - 1 || r == 0 || r == ny - 1) {
+#pragma unroll
+          for (int l = 0; l < NL; l++) split_write_ghosts(p.out, p.g, l, r, i, x[l], p.walls);
+        }
+      }
+    }
+  }
+}
+
+template <int NL>
+static int march_dispatch(hipStream_t st, const MarchArgs &a, int K) {
+  const int hk = a.g.hk;
+  auto grid = [&](int ow) { return dim3((hk + ow - 1) / ow, (a.g.ny + a.H - 1) / a.H); };
+  switch (K) {
+    case 2: hipLaunchKernelGGL((k_relax_march<NL, 2>), grid(62), dim3(64), 0, st, a); return 0;
+    case 3: hipLaunchKernelGGL((k_relax_march<NL, 3>), grid(60), dim3(64), 0, st, a); return 0;
+    case 4: hipLaunchKernelGGL((k_relax_march<NL, 4>), grid(60), dim3(64), 0, st, a); return 0;
+  }
+  return -1;
+}
+
+// K (2..4) half-sweeps starting with colour c1, in -> out; returns -1 if (nl, K) has no instantiation
+int launch_relax_march(hipStream_t st, const double *in, double *out, const double *res, const SplitGeom &sg, int nl, const RelaxCoef &rc, int c1,
+                       int K, int walls, int chunk_rows) {
+  MarchArgs a;
+  a.in = in; a.out = out; a.res = res; a.g = sg; a.c1 = c1; a.walls = walls; a.rc = rc;
+  int H = chunk_rows;
+  if (H <= 0) {  // >= 2048 independent wavefronts where the level allows, chunks tall enough for the 2 K re-computed rows
+    // one round of at most 2048 independent wavefronts (8 per CU at <= 256 VGPRs), chunks tall enough for the 2 K
+    // re-computed rows
+    const int strips = (sg.hk + 59) / 60, want = 2048 / strips > 0 ? 2048 / strips : 1;
+    H = (sg.ny + want - 1) / want;
+    H = ((H + 7) / 8) * 8;
+    if (H < 32) H = 32;
+  }
+  a.H = H;
+  if (nl >= 7 && K > 3) return -1;  // 4 windows of 7 or 8 layers do not fit 256 VGPRs
+  switch (nl) {
+    case 2: return march_dispatch<2>(st, a, K);
+    case 3: return march_dispatch<3>(st, a, K);
+    case 4: return march_dispatch<4>(st, a, K);
+    case 5: return march_dispatch<5>(st, a, K);
+    case 6: return march_dispatch<6>(st, a, K);
+    case 7: return march_dispatch<7>(st, a, K);
+    case 8: return march_dispatch<8>(st, a, K);
+  }
+  return -1;
+}

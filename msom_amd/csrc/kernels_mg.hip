@@ -20,6 +20,7 @@
 // boundary_level() call.  A ghost is read only by the cell it mirrors, so the thread that
 // updates a wall cell also rewrites its ghost(s); no separate boundary kernel is launched.
 #include "kernels.h"
+#include "mg_inl.h"
 
 #ifdef MSOM_STRICT
 #define DIVC(x, c, rc) ((x) / (c))
@@ -51,33 +52,6 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// writes the homogeneous-Dirichlet ghosts that mirror cell (i, j) (edges: -v, corners: +v)
-__device__ __forceinline__ void split_write_ghosts(double *f, const SplitGeom &g, int l, int j, int i, double v, int walls) {
-  if (walls & WALL_PER) {  // periodic images of an edge cell
-    const bool w = i == 0, e = i == g.nx - 1, s = j == 0, n = j == g.ny - 1;
-    if (!(w | e | s | n)) return;
-    if (w) f[split_idx(g, l, j, g.nx)] = v;
-    if (e) f[split_idx(g, l, j, -1)] = v;
-    if (s) f[split_idx(g, l, g.ny, i)] = v;
-    if (n) f[split_idx(g, l, -1, i)] = v;
-    if (w && s) f[split_idx(g, l, g.ny, g.nx)] = v;
-    if (w && n) f[split_idx(g, l, -1, g.nx)] = v;
-    if (e && s) f[split_idx(g, l, g.ny, -1)] = v;
-    if (e && n) f[split_idx(g, l, -1, -1)] = v;
-    return;
-  }
-  const bool w = i == 0 && (walls & WALL_W), e = i == g.nx - 1 && (walls & WALL_E);
-  const bool s = j == 0 && (walls & WALL_S), n = j == g.ny - 1 && (walls & WALL_N);
-  if (!(w | e | s | n)) return;
-  if (w) f[split_idx(g, l, j, -1)] = -v;
-  if (e) f[split_idx(g, l, j, g.nx)] = -v;
-  if (s) f[split_idx(g, l, -1, i)] = -v;
-  if (n) f[split_idx(g, l, g.ny, i)] = -v;
-  if (w && s) f[split_idx(g, l, -1, -1)] = v;
-  if (w && n) f[split_idx(g, l, g.ny, -1)] = v;
-  if (e && s) f[split_idx(g, l, -1, g.nx)] = v;
-  if (e && n) f[split_idx(g, l, g.ny, g.nx)] = v;
-}
 __device__ __forceinline__ void nat_write_ghosts(double *f, const NatGeom &g, int l, int j, int i, double v, int walls) {
   if (walls & WALL_PER) {
     const bool w = i == 0, e = i == g.nx - 1, s = j == 0, n = j == g.ny - 1;

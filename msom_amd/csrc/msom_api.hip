@@ -35,6 +35,7 @@
 // RES0, RES1 and UMAX[nl] are contiguous: one max all-reduce / one copy brings them to the host
 enum { SC_BSUM = 2, SC_KE = 3, SC_SCRATCH = 4, SC_RES0 = 6, SC_RES1 = 7, SC_UMAX = 8 /* MAXNL */, SC_RESF = 16 /* max|res| from the fused tendency pass */, SC_LSUM = 32 /* MAXNL */, SC_COUNT = 64 };
 
+static int g_march_rows = 0;  // tuning knob: chunk height of k_relax_march (0 = automatic)
 struct ProfSlot {
   std::vector<hipEvent_t> ev;  // pairs (start, stop)
   size_t used = 0;
@@ -97,6 +98,8 @@ struct msom {
   int stochastic = 0, corrector_step = 0, noise_mode = 0;
   int prolong_fused = 1;  // first red half-sweep of a level interpolates its neighbours from the coarser level
   int block_sweeps = 0;  // experimental temporally blocked smoother (2 sweeps per pass); measured not faster at nl = 6
+  int march = 1;         // chained half-sweeps in register windows (kernels_march.hip) on wide single-GPU levels
+  int march_k = 4;       // at most this many half-sweeps per pass (2..4)
   int mg_fused = 1;  // fused residual+restriction and correction+residual passes of the multigrid cycle
   double *psi_alt = nullptr;  // second psi buffer (the fused correction writes out of place)
   int rhs_variant = 6;  // 6: one layer per wavefront, register windows (kernels_lpw.hip, default); 1: LDS tiles, software-pipelined; 0: LDS tiles, phase by phase
@@ -122,7 +125,7 @@ struct msom {
   msom_mgstats mg = {0, 0, 0, 0, 0};
   // profiling of the finest-level smoother sweep
   int profile = 0;
-  ProfSlot prof_sweep, prof_resid, prof_block;
+  ProfSlot prof_sweep, prof_resid, prof_block, prof_march[5];  // prof_march[K]: passes of K chained half-sweeps
 };
 
 static void free_agglomeration(msom *m);
@@ -533,7 +536,7 @@ extern "C" int msom_destroy(msom_t *m) {
   if (m->d_scal) hipFree(m->d_scal);
   if (m->h_scal) hipHostFree(m->h_scal);
   if (m->d_wind) hipFree(m->d_wind);
-  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block})
+  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4]})
     for (auto e : ps->ev) hipEventDestroy(e);
   if (m->comm) comm_destroy(m->comm);
   if (m->ev_c2x) hipEventDestroy(m->ev_c2x);
@@ -562,6 +565,9 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "profile")) m->profile = (int)v;
   else if (!strcmp(key, "fused")) m->fused = (int)v;
   else if (!strcmp(key, "mg_fused")) m->mg_fused = (int)v;
+  else if (!strcmp(key, "march")) m->march = (int)v;
+  else if (!strcmp(key, "march_rows")) g_march_rows = (int)v;
+  else if (!strcmp(key, "march_k")) m->march_k = (int)v < 2 ? 2 : ((int)v > 4 ? 4 : (int)v);
   else if (!strcmp(key, "block_sweeps")) { m->block_sweeps = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "mg_global_sum")) m->mg_global_sum = (int)v;
   else if (!strcmp(key, "agglomerate")) { m->agglomerate = (int)v; if (m->const_set) return build_coefs(m); }
@@ -936,6 +942,11 @@ static Lev glob_lev(msom *m, int k) {
 static bool block_ok(msom *m, const Lev &L) {
   return m->block_sweeps && m->uniformS && !L.tiled && !(m->walls & WALL_PER) && L.sg->nx >= 64 && L.sg->ny >= 16;
 }
+// can the level chain its half-sweeps in registers (k_relax_march)?  One GPU (no halo exchange between half-sweeps),
+// walls, uniform S, wide enough for 60-lane strips and independent chunks
+static bool march_ok(msom *m, const Lev &L) {
+  return m->march && !m->block_sweeps && m->uniformS && m->nl >= 2 && !L.tiled && L.walls == WALL_ALL && L.sg->nx >= 512 && L.sg->ny >= 64;
+}
 // is the prolongation coarse -> L folded into the first smoothing pass of L?
 static bool fuse_prolong(msom *m, const Lev &L, int nrelax) {
   if (block_ok(m, L) && nrelax >= 2) return true;
@@ -949,6 +960,27 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
   const bool prof = m->profile && L.fine;
   const int nl = m->nl;
   int it = 0;
+  if (march_ok(m, L)) {
+    // 2 nrelax half-sweeps; the first red one may carry the prolongation (in place), the others go in passes of
+    // up to march_k, ping-ponging between the two correction buffers; a single left-over half-sweep runs in place
+    int n = 2 * nrelax, c = 0;
+    if (coarse && n > 0) {
+      launch_relax_red_prolong(m->st, *L.da, *coarse->da, *coarse->sg, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, L.walls);
+      n--; c = 1;
+    }
+    while (n >= 2) {
+      const int kmax = nl >= 7 && m->march_k > 3 ? 3 : m->march_k;
+      int K = n < kmax ? n : kmax;
+      if (n - K == 1 && K > 2) K--;
+      if (prof) prof_begin(m, m->prof_march[K]);
+      launch_relax_march(m->st, *L.da, *L.da_alt, L.res, *L.sg, nl, *L.rc, c, K, L.walls, g_march_rows);
+      if (prof) prof_end(m, m->prof_march[K]);
+      std::swap(*L.da, *L.da_alt);
+      n -= K; c = (c + K) & 1;
+    }
+    if (n == 1) launch_relax_color(m->st, *L.da, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, c, L.walls, L.fine);
+    return;
+  }
   if (block_ok(m, L)) {
     for (; it + 2 <= nrelax; it += 2) {
       const bool pl = coarse && it == 0;
@@ -2141,12 +2173,13 @@ extern "C" int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, doubl
 
 extern "C" int msom_profile_reset(msom_t *m) {
   if (!m) return MSOM_ERR_ARG;
-  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block}) { ps->used = 0; ps->total_ms = 0; ps->launches = 0; }
+  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4]}) { ps->used = 0; ps->total_ms = 0; ps->launches = 0; }
   return MSOM_OK;
 }
 extern "C" int msom_profile_read(msom_t *m, const char *kernel, double *avg_ms, long *launches) {
   if (!m || !kernel) return MSOM_ERR_ARG;
-  ProfSlot *ps = !strcmp(kernel, "sweep") ? &m->prof_sweep : !strcmp(kernel, "residual") ? &m->prof_resid : !strcmp(kernel, "block2") ? &m->prof_block : nullptr;
+  ProfSlot *ps = !strcmp(kernel, "sweep") ? &m->prof_sweep : !strcmp(kernel, "residual") ? &m->prof_resid : !strcmp(kernel, "block2") ? &m->prof_block :
+                 !strcmp(kernel, "march2") ? &m->prof_march[2] : !strcmp(kernel, "march3") ? &m->prof_march[3] : !strcmp(kernel, "march4") ? &m->prof_march[4] : nullptr;
   if (!ps) { msom_set_error("unknown kernel %s", kernel); return MSOM_ERR_ARG; }
   prof_collect(m, *ps);
   if (avg_ms) *avg_ms = ps->launches ? ps->total_ms / ps->launches : 0.;
@@ -2170,6 +2203,8 @@ extern "C" int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double
     } else if (!strcmp(kernel, "advection")) {
       launch_advection(m->st, m->f[MSOM_ZETA], m->f[MSOM_PSI], m->f[MSOM_PSIPG], m->f[MSOM_ZETAPG], m->f[MSOM_S], m->f[MSOM_Q], m->f[MSOM_TMP], m->g,
                        m->nl, m->have_pg, m->have_zpg, m->stochastic, D, m->p.beta, m->p.itr_stoch, m->lc);
+    } else if (!strncmp(kernel, "march", 5) && kernel[5] >= '2' && kernel[5] <= '4') {
+      launch_relax_march(m->st, m->da[0], m->da_alt[0], m->res[0], m->sg[0], m->nl, m->rc[0], 1, kernel[5] - '0', m->walls, g_march_rows);
     } else if (!strcmp(kernel, "block2")) {
       launch_relax_block2(m->st, m->da[0], nullptr, m->sg[0], m->res[0], m->da_alt[0], m->sg[0], m->nl, m->rc[0], m->walls, 1);
     } else if (!strcmp(kernel, "block2p")) {

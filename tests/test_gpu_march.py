@@ -1,0 +1,77 @@
+"""GPU parity of the chained half-sweep smoother (msom_amd/csrc/kernels_march.hip, option march): K = 2..4 red-black
+half-sweeps of relax_layer per pass, values of the intermediate half-sweeps only in registers.  Same per-cell arithmetic
+as the half-sweep-per-launch path: BIT-EXACT in the strict build (against that path and against the CPU oracle); the
+product build differs by fp64 round-off only (FMA contraction is chosen per kernel), tolerance at the assertion."""
+import numpy as np
+import pytest
+
+import orc
+from msom_amd import QG, FIELDS as F
+from test_gpu_parity import make_pair, rel
+
+pytestmark = pytest.mark.gpu
+
+SLIP = "sbc = 1.5\nRe = 300\nEks = 0.001\n"
+
+
+def run(txt, strict, nl, ny, nx, steps=2, **opts):
+    g = QG(txt, strict=strict)
+    g.option("quiet", 1); g.option("TOLERANCE", 1e-8)
+    g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx))
+    g.set_const()
+    for k, v in opts.items():
+        g.option(k, v)
+    for _ in range(steps):
+        g.step()
+    st = g.mgstats()
+    out = (g.get(F["PSI"]), g.get(F["Q"]), (st.i, st.resa))
+    g.close()
+    return out
+
+
+@pytest.mark.parametrize("nx,ny,nl", [(512, 64, 3), (1024, 128, 6), (512, 512, 2), (2048, 64, 4), (512, 128, 8), (1024, 64, 5), (512, 64, 7)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_march_equals_half_sweep_per_launch(nx, ny, nl, strict):
+    """two RK2 steps (four inversions, TOLERANCE 1e-8 => several cycles): psi, q, cycle count and final residual"""
+    txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else ""))
+    a = run(txt, strict, nl, ny, nx, march=0)
+    b = run(txt, strict, nl, ny, nx, march=1)
+    if strict:
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    else:
+        assert rel(b[0], a[0]) <= 1e-10 and a[2][0] == b[2][0]
+
+
+@pytest.mark.parametrize("k,rows", [(2, 0), (3, 0), (4, 0), (4, 32), (3, 48), (4, 16), (2, 80)])
+def test_march_pass_lengths_and_chunk_heights(k, rows):
+    """the result depends neither on how the 2 nrelax - 1 half-sweeps are cut into passes nor on the chunk height"""
+    nx, ny, nl = 512, 128, 3
+    txt = orc.double_gyre_params(nx, nl, extra=f"Ny = {ny}\n" + SLIP)
+    a = run(txt, True, nl, ny, nx, march=0)
+    b = run(txt, True, nl, ny, nx, march=1, march_k=k, march_rows=rows)
+    assert np.array_equal(a[0], b[0]) and a[2] == b[2]
+
+
+def test_march_against_oracle():
+    """strict build with the chained smoother against the CPU oracle, bit for bit"""
+    nx, ny, nl = 512, 64, 3
+    o, g = make_pair(nx, ny, nl, strict=True, TOLERANCE=1e-6)
+    g.option("march", 1)
+    for _ in range(2):
+        o.step(); g.step()
+    assert g.t == o.t
+    assert np.array_equal(g.get(F["PSI"]), o.get(orc.PSI))
+    assert np.array_equal(g.get(F["Q"]), o.get(orc.Q))
+
+
+def test_march_off_where_it_does_not_apply():
+    """periodic domain / general S field: the option is ignored (no error, same result as march = 0)"""
+    nx, ny, nl = 512, 64, 2
+    txt = orc.double_gyre_params(nx, nl, extra=f"Ny = {ny}\nsbc = -1\n")
+    a = run(txt, True, nl, ny, nx, march=0)
+    b = run(txt, True, nl, ny, nx, march=1)
+    assert np.array_equal(a[0], b[0])
+    txt = orc.double_gyre_params(nx, nl, extra=f"Ny = {ny}\n")
+    a = run(txt, True, nl, ny, nx, march=0, uniform_S=0)
+    b = run(txt, True, nl, ny, nx, march=1, uniform_S=0)
+    assert np.array_equal(a[0], b[0])
