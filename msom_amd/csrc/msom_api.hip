@@ -943,9 +943,12 @@ static bool block_ok(msom *m, const Lev &L) {
   return m->block_sweeps && m->uniformS && !L.tiled && !(m->walls & WALL_PER) && L.sg->nx >= 64 && L.sg->ny >= 16;
 }
 // can the level chain its half-sweeps in registers (k_relax_march)?  One GPU (no halo exchange between half-sweeps),
-// walls, uniform S, wide enough for 60-lane strips and independent chunks
+// walls, uniform S, and a level big enough to be HBM-bound: a marching wavefront pays one memory latency per row, which
+// only ~2000 concurrent chunks hide (measured at nl = 6: 4096^2 1.54 -> 1.05 ms per 7 half-sweeps, 2048^2 385 -> 310 us,
+// but 1024^2 105 -> 238 us).  march = 2 forces it on every level that is wide enough (tests)
 static bool march_ok(msom *m, const Lev &L) {
-  return m->march && !m->block_sweeps && m->uniformS && m->nl >= 2 && !L.tiled && L.walls == WALL_ALL && L.sg->nx >= 512 && L.sg->ny >= 64;
+  if (!m->march || m->block_sweeps || !m->uniformS || m->nl < 2 || L.tiled || L.walls != WALL_ALL || L.sg->nx < 512 || L.sg->ny < 64) return false;
+  return m->march >= 2 || (size_t)L.sg->nx * L.sg->ny * m->nl >= ((size_t)1 << 24);
 }
 // is the prolongation coarse -> L folded into the first smoothing pass of L?
 static bool fuse_prolong(msom *m, const Lev &L, int nrelax) {

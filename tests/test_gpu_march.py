@@ -35,7 +35,7 @@ def test_march_equals_half_sweep_per_launch(nx, ny, nl, strict):
     """two RK2 steps (four inversions, TOLERANCE 1e-8 => several cycles): psi, q, cycle count and final residual"""
     txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else ""))
     a = run(txt, strict, nl, ny, nx, march=0)
-    b = run(txt, strict, nl, ny, nx, march=1)
+    b = run(txt, strict, nl, ny, nx, march=2)
     if strict:
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
     else:
@@ -48,7 +48,7 @@ def test_march_pass_lengths_and_chunk_heights(k, rows):
     nx, ny, nl = 512, 128, 3
     txt = orc.double_gyre_params(nx, nl, extra=f"Ny = {ny}\n" + SLIP)
     a = run(txt, True, nl, ny, nx, march=0)
-    b = run(txt, True, nl, ny, nx, march=1, march_k=k, march_rows=rows)
+    b = run(txt, True, nl, ny, nx, march=2, march_k=k, march_rows=rows)
     assert np.array_equal(a[0], b[0]) and a[2] == b[2]
 
 
@@ -56,7 +56,7 @@ def test_march_against_oracle():
     """strict build with the chained smoother against the CPU oracle, bit for bit"""
     nx, ny, nl = 512, 64, 3
     o, g = make_pair(nx, ny, nl, strict=True, TOLERANCE=1e-6)
-    g.option("march", 1)
+    g.option("march", 2)
     for _ in range(2):
         o.step(); g.step()
     assert g.t == o.t
@@ -69,9 +69,9 @@ def test_march_off_where_it_does_not_apply():
     nx, ny, nl = 512, 64, 2
     txt = orc.double_gyre_params(nx, nl, extra=f"Ny = {ny}\nsbc = -1\n")
     a = run(txt, True, nl, ny, nx, march=0)
-    b = run(txt, True, nl, ny, nx, march=1)
+    b = run(txt, True, nl, ny, nx, march=2)
     assert np.array_equal(a[0], b[0])
     txt = orc.double_gyre_params(nx, nl, extra=f"Ny = {ny}\n")
     a = run(txt, True, nl, ny, nx, march=0, uniform_S=0)
-    b = run(txt, True, nl, ny, nx, march=1, uniform_S=0)
+    b = run(txt, True, nl, ny, nx, march=2, uniform_S=0)
     assert np.array_equal(a[0], b[0])

@@ -17,4 +17,5 @@ for rep in range(2):
         for k, v in opts.items(): g.option(k, v)
         run(2)
         print(f"{name:24s} {run():8.3f} ms/step", flush=True)
-        for k, v in opts.items(): g.option(k, 1.0 - v if v in (0.0, 1.0) else 0)
+        for k, v in opts.items():
+            if v in (0.0, 1.0): g.option(k, 1.0 - v)   # binary switches go back; other values stay (list them last)
