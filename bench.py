@@ -180,13 +180,16 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    sweep_ms, sweep_n = g.profile_read("sweep")      # one sweep = red + black launch
+    sweep_ms, sweep_n = g.profile_read("sweep")      # one sweep = red + black launch (half-sweep-per-launch path)
+    m4_ms, m4_n = g.profile_read("march4")           # finest-level passes of 4 / 3 chained half-sweeps (one GPU)
+    m3_ms, m3_n = g.profile_read("march3")
     resid_ms, resid_n = g.profile_read("residual")
     st = g.mgstats()
     ke = g.ke()
     # second kernel of the step (the Jacobian / PV-tendency pass): a short back-to-back microbenchmark after the timed
     # region (HIP events on the library's stream); every rank takes part (tiles exchange the psi halo)
     rhs_ms = g.bench_kernel("rhs_adv", 5)
+    plain_ms = g.bench_kernel("sweep", 5) / 2.0     # one plain colour half-sweep launch, for comparison
 
     if rank == 0:
         w = 8.0 * N * N * nl                       # bytes of one layered fp64 field of the tile
@@ -194,17 +197,28 @@ def main():
         sigma = 0.0 if uniform else (nl - 1) / nl
         # algorithmic bytes of ONE colour half-sweep launch: read the other colour's da (w/2),
         # read own-colour res (w/2) [+ own-colour S], write own-colour da (w/2)
-        launch_bytes = (3.0 + sigma) * w / 2.0
-        launch_ms = sweep_ms / 2.0
+        plain_bytes = (3.0 + sigma) * w / 2.0
+        marched = m4_n + m3_n > 0
+        if marched:
+            # the smoother's finest-level pass: K chained half-sweeps per launch (kernels_march.hip).  Algorithmic bytes
+            # of ONE launch, whatever K: the other colour's da in (w/2), the residual of both colours (w), both colours
+            # of da out (w)
+            K, launch_ms, launches = (4, m4_ms, m4_n) if m4_n * m4_ms >= m3_n * m3_ms else (3, m3_ms, m3_n)
+            launch_bytes = 2.5 * w
+            kernel = f"k_relax_march<{nl}, {K}> (finest level: {K} chained red-black colour half-sweeps per pass, intermediate values in registers)"
+            pmc_file = "r01_pmc_traffic_march.json"
+        else:
+            K, launch_bytes, launch_ms, launches = 1, plain_bytes, sweep_ms / 2.0, 2 * sweep_n
+            kernel = f"k_relax_color_x2<{nl}, {'true' if uniform else 'false'}, true> (finest-level red-black colour half-sweep)"
+            pmc_file = "r01_pmc_traffic_relax_fine.json"
         achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        kernel = f"k_relax_color_x2<{nl}, {'true' if uniform else 'false'}, true> (finest-level red-black colour half-sweep)"
         # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
         # collected separately with rocprofv3 --pmc and stored under profiles/
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_relax_fine.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             if N == 4096 and nl == 6 and uniform and world == 1:
-                traffic = pmc["traffic_bytes_per_launch"]
+                traffic = pmc["traffic_bytes_per_launch"] if K == 1 else pmc[f"traffic_bytes_per_launch_K{K}"]
         except Exception:
             pass
         out = {
@@ -237,7 +251,14 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "avg_launch_ms": launch_ms,
-                "launches_timed": 2 * sweep_n,
+                "launches_timed": launches,
+                "half_sweeps_per_launch": K,
+                "plain_half_sweep_kernel": {
+                    "kernel": f"k_relax_color_x2<{nl}, {'true' if uniform else 'false'}, true> (one colour half-sweep per launch; used on tiles and small levels)",
+                    "avg_launch_ms": plain_ms, "algorithmic_bytes_per_launch": plain_bytes,
+                    "achieved_GBs": plain_bytes / (plain_ms * 1e-3) / 1e9 if plain_ms > 0 else 0.0,
+                    "note": "K of these move 1.5 K w; the chained pass moves 2.5 w for the same K half-sweeps",
+                },
                 "tendency_kernel": {
                     "kernel": "k_rhs_lpw<4, true, false, true> (Arakawa Jacobians + beta + dissipation + drag + forcing + advance, one pass over psi)",
                     "avg_launch_ms": rhs_ms,
