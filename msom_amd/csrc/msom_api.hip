@@ -2207,7 +2207,9 @@ extern "C" int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double
       launch_advection(m->st, m->f[MSOM_ZETA], m->f[MSOM_PSI], m->f[MSOM_PSIPG], m->f[MSOM_ZETAPG], m->f[MSOM_S], m->f[MSOM_Q], m->f[MSOM_TMP], m->g,
                        m->nl, m->have_pg, m->have_zpg, m->stochastic, D, m->p.beta, m->p.itr_stoch, m->lc);
     } else if (!strncmp(kernel, "march", 5) && kernel[5] >= '2' && kernel[5] <= '4') {
-      launch_relax_march(m->st, m->da[0], m->da_alt[0], m->res[0], m->sg[0], m->nl, m->rc[0], 1, kernel[5] - '0', m->walls, g_march_rows);
+      const bool rev = kernel[6] == 'r';  // "march3r": da_alt -> da (the direction of the second pass of a level)
+      launch_relax_march(m->st, rev ? m->da_alt[0] : m->da[0], rev ? m->da[0] : m->da_alt[0], m->res[0], m->sg[0], m->nl, m->rc[0], 1, kernel[5] - '0', m->walls,
+                         g_march_rows);
     } else if (!strcmp(kernel, "block2")) {
       launch_relax_block2(m->st, m->da[0], nullptr, m->sg[0], m->res[0], m->da_alt[0], m->sg[0], m->nl, m->rc[0], m->walls, 1);
     } else if (!strcmp(kernel, "block2p")) {
