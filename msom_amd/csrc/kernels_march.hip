@@ -37,8 +37,10 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
   // other colour at rows t - 1, t - 3.  Every residual value is read from memory ONCE and waits in registers
   constexpr int D1 = K >= 3 ? 3 : 1, D2 = K >= 4 ? 3 : 1;
   const int lane = threadIdx.x;
-  const int kx = (int)blockIdx.x * OW - HL + lane;
-  const int y0 = blockIdx.y * p.H, y1 = min(p.g.ny, y0 + p.H);
+  unsigned bx, by;
+  xcd_remap(bx, by);
+  const int kx = (int)bx * OW - HL + lane;
+  const int y0 = by * p.H, y1 = min(p.g.ny, y0 + p.H);
   const int hk = p.g.hk, ny = p.g.ny, hp = p.g.hp;
   const ptrdiff_t rp = p.g.rp;
   const size_t ls = p.g.ls;
