@@ -32,4 +32,17 @@ __device__ __forceinline__ void split_write_ghosts(double *f, const SplitGeom &g
   if (e && n) f[split_idx(g, l, g.ny, g.nx)] = v;
 }
 
+// XCD-aware block numbering.  Workgroups are dealt round-robin over the 8 XCDs (linear ids b and b + 8 share an L2), so
+// neighbouring strips of a row-major grid land on 8 different L2s and each of them fetches the cache lines the strips
+// share (halo columns, partial 128-B lines at unaligned strip edges).  This renumbering gives every XCD one contiguous
+// range of the row-major grid; ids that are dispatched together stay neighbours.  Pure permutation of (bx, by).
+__device__ __forceinline__ void xcd_remap(unsigned &bx, unsigned &by) {
+  const unsigned nbx = gridDim.x, total = nbx * gridDim.y;
+  const unsigned lin = blockIdx.y * nbx + blockIdx.x;
+  const unsigned c = lin & 7, q = total >> 3, r = total & 7;
+  const unsigned flat = c * q + (c < r ? c : r) + (lin >> 3);
+  bx = flat % nbx;
+  by = flat / nbx;
+}
+
 #endif
