@@ -26,7 +26,7 @@ struct MarchArgs {
   double *out;
   SplitGeom g;
   int c1;  // colour of the first half-sweep (0 red, 1 black)
-  int walls, H;
+  int walls, H, remap;
   RelaxCoef rc;
 };
 
@@ -37,8 +37,8 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
   // other colour at rows t - 1, t - 3.  Every residual value is read from memory ONCE and waits in registers
   constexpr int D1 = K >= 3 ? 3 : 1, D2 = K >= 4 ? 3 : 1;
   const int lane = threadIdx.x;
-  unsigned bx, by;
-  xcd_remap(bx, by);
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if (p.remap) xcd_remap(bx, by);
   const int kx = (int)bx * OW - HL + lane;
   const int y0 = by * p.H, y1 = min(p.g.ny, y0 + p.H);
   const int hk = p.g.hk, ny = p.g.ny, hp = p.g.hp;
@@ -168,6 +168,8 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
   }
 }
 
+int g_march_remap = 1;  // XCD-contiguous block numbering (option march_xcd)
+
 template <int NL>
 static int march_dispatch(hipStream_t st, const MarchArgs &a, int K) {
   const int hk = a.g.hk;
@@ -184,7 +186,8 @@ static int march_dispatch(hipStream_t st, const MarchArgs &a, int K) {
 int launch_relax_march(hipStream_t st, const double *in, double *out, const double *res, const SplitGeom &sg, int nl, const RelaxCoef &rc, int c1,
                        int K, int walls, int chunk_rows) {
   MarchArgs a;
-  a.in = in; a.out = out; a.res = res; a.g = sg; a.c1 = c1; a.walls = walls; a.rc = rc;
+  extern int g_march_remap;
+  a.in = in; a.out = out; a.res = res; a.g = sg; a.c1 = c1; a.walls = walls; a.rc = rc; a.remap = g_march_remap;
   int H = chunk_rows;
   if (H <= 0) {  // >= 2048 independent wavefronts where the level allows, chunks tall enough for the 2 K re-computed rows
     // one round of at most 2048 independent wavefronts (8 per CU at <= 256 VGPRs), chunks tall enough for the 2 K
