@@ -24,6 +24,11 @@
 struct MarchArgs {
   const double *in, *res;
   double *out;
+  // tiles of a multi-GPU run: rows below / above a tile edge that is not a wall come from halo arrays (the KR nearest
+  // rows of the neighbour tile, same row layout, hls doubles per layer); the columns beyond W / E edges sit in the row pads
+  const double *in_s, *in_n, *res_s, *res_n;
+  size_t hls;
+  int KR;
   SplitGeom g;
   int c1;  // colour of the first half-sweep (0 red, 1 black)
   int walls, H, remap;
@@ -50,6 +55,13 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
   const bool wallS = (p.walls & WALL_S) != 0, wallN = (p.walls & WALL_N) != 0;
   const double sqD = p.rc.sqD;
   auto off = [&](int half, int r) -> ptrdiff_t { return (ptrdiff_t)(min(max(r, -1), ny) + 1) * rp + half * hp + MSOM_SP + kxc; };
+  // row r of a field whose rows beyond the tile live in halo arrays (wave-uniform choice); lstride = doubles per layer
+  auto rowsrc = [&](const double *f, const double *fs, const double *fn, int half, int r, size_t &lstride) -> const double * {
+    if (r < 0 && fs) { lstride = p.hls; return fs + (ptrdiff_t)(max(r, -p.KR) + p.KR + 1) * rp + half * hp + MSOM_SP + kxc; }
+    if (r >= ny && fn) { lstride = p.hls; return fn + (ptrdiff_t)(min(r - ny, p.KR - 1) + 1) * rp + half * hp + MSOM_SP + kxc; }
+    lstride = ls;
+    return f + off(half, r);
+  };
 
   double W[K][3][NL];  // W[s]: values after half-sweep s (s = 0: the input) of rows r - 1, r, r + 1 of the half-sweep that reads them
 #pragma unroll
@@ -72,9 +84,10 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     const int r = y0 - K + q;
-    const double *src = p.in + off((r + c0) & 1, r);
+    size_t st;
+    const double *src = rowsrc(p.in, p.in_s, p.in_n, (r + c0) & 1, r, st);
 #pragma unroll
-    for (int l = 0; l < NL; l++) W[0][q + 1][l] = src[l * ls];
+    for (int l = 0; l < NL; l++) W[0][q + 1][l] = src[l * st];
   }
   for (int t = y0 - K + 1; t <= y1 + K - 2; t++) {
 #pragma unroll
@@ -89,11 +102,15 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
       for (int d = D2 - 1; d > 0; d--) R2[d][l] = R2[d - 1][l];
     }
     {
-      const double *src = p.in + off((t + 1 + c0) & 1, t + 1);
-      const double *r1 = p.res + off((t + p.c1) & 1, min(max(t, 0), ny - 1));           // colour c1, row t
-      const double *r2 = p.res + off((t - 1 + c0) & 1, min(max(t - 1, 0), ny - 1));      // colour c0, row t - 1
+      size_t s0, s1, s2;
+      const double *src = rowsrc(p.in, p.in_s, p.in_n, (t + 1 + c0) & 1, t + 1, s0);
+      // residual rows: beyond a wall they are never used (clamped), beyond a tile edge they come from the halo arrays
+      const int t1 = (t < 0 && !p.res_s) ? 0 : ((t >= ny && !p.res_n) ? ny - 1 : t);
+      const int t2 = (t - 1 < 0 && !p.res_s) ? 0 : ((t - 1 >= ny && !p.res_n) ? ny - 1 : t - 1);
+      const double *r1 = rowsrc(p.res, p.res_s, p.res_n, (t + p.c1) & 1, t1, s1);           // colour c1, row t
+      const double *r2 = rowsrc(p.res, p.res_s, p.res_n, (t - 1 + c0) & 1, t2, s2);         // colour c0, row t - 1
 #pragma unroll
-      for (int l = 0; l < NL; l++) { W[0][2][l] = src[l * ls]; R1[0][l] = r1[l * ls]; R2[0][l] = r2[l * ls]; }
+      for (int l = 0; l < NL; l++) { W[0][2][l] = src[l * s0]; R1[0][l] = r1[l * s1]; R2[0][l] = r2[l * s2]; }
     }
 #pragma unroll
     for (int s = 1; s <= K; s++) {
@@ -184,8 +201,10 @@ static int march_dispatch(hipStream_t st, const MarchArgs &a, int K) {
 
 // K (2..4) half-sweeps starting with colour c1, in -> out; returns -1 if (nl, K) has no instantiation
 int launch_relax_march(hipStream_t st, const double *in, double *out, const double *res, const SplitGeom &sg, int nl, const RelaxCoef &rc, int c1,
-                       int K, int walls, int chunk_rows) {
+                       int K, int walls, int chunk_rows, const MarchHalo *h) {
   MarchArgs a;
+  a.in_s = h ? h->in_s : nullptr; a.in_n = h ? h->in_n : nullptr; a.res_s = h ? h->res_s : nullptr; a.res_n = h ? h->res_n : nullptr;
+  a.hls = h ? h->ls : 0; a.KR = h ? h->rows : 0;
   extern int g_march_remap;
   a.in = in; a.out = out; a.res = res; a.g = sg; a.c1 = c1; a.walls = walls; a.rc = rc; a.remap = g_march_remap;
   int H = chunk_rows;

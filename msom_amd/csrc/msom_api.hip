@@ -36,6 +36,7 @@
 enum { SC_BSUM = 2, SC_KE = 3, SC_SCRATCH = 4, SC_RES0 = 6, SC_RES1 = 7, SC_UMAX = 8 /* MAXNL */, SC_RESF = 16 /* max|res| from the fused tendency pass */, SC_LSUM = 32 /* MAXNL */, SC_COUNT = 64 };
 
 static int g_march_rows = 0;  // tuning knob: chunk height of k_relax_march (0 = automatic)
+#define MARCH_HALO 4    // rows (= cells in x) of neighbour data a pass of up to 4 chained half-sweeps reads
 struct ProfSlot {
   std::vector<hipEvent_t> ev;  // pairs (start, stop)
   size_t used = 0;
@@ -68,6 +69,8 @@ struct msom {
   int nlev = 0;
   std::vector<SplitGeom> sg;
   std::vector<double *> da, da_alt, res, S;
+  // chained smoother on tiles: the MARCH_HALO nearest rows of the S / N neighbour tiles (correction, residual), per level
+  std::vector<double *> mh_da_s, mh_da_n, mh_res_s, mh_res_n;
   std::vector<RelaxCoef> rc;
   size_t max_split = 0;
   // agglomerated coarse levels (tiled mode): levels >= agg_level live on the gathered global grid
@@ -319,6 +322,39 @@ static int exch_split(msom *m, double *f, const SplitGeom &sg, int nl, int corne
   return r;
 }
 
+// Deep halo of a split field for the chained smoother (kernels_march.hip): MARCH_HALO cells beyond the W / E tile edges
+// go into the row pads of the field itself, MARCH_HALO rows beyond the S / N edges into the halo arrays fs / fn
+// (geometry hg: MARCH_HALO rows of the level).  Two phases, the second one carries the freshly received pad columns,
+// so the corner regions arrive too.  Edges without a neighbour (walls) are left alone.
+static int exch_split_deep(msom *m, double *f, const SplitGeom &sg, double *fs, double *fn, const SplitGeom &hg, int nl) {
+  hipStream_t cs = m->st2;
+  const int H = MARCH_HALO;
+  Xfer x[2];
+  int n = 0;
+  comm_begin(m);
+  auto pack = [&](int dir, int i0, int j0, int w, int h) {
+    launch_split_pack_strip(cs, f, sg, nl, i0, j0, w, h, comm_sendbuf(m->comm, dir));
+    x[n++] = {m->nb[dir], AXIS(dir), comm_sendbuf(m->comm, dir), comm_recvbuf(m->comm, dir), (size_t)w * h * nl};
+  };
+  // rows -1 and ny ride along: next to a y wall they are the neighbour's wall ghosts, which the cells of the halo
+  // columns read like any other row
+  if (m->nb[DIR_W] >= 0) pack(DIR_W, 0, -1, H, sg.ny + 2);
+  if (m->nb[DIR_E] >= 0) pack(DIR_E, sg.nx - H, -1, H, sg.ny + 2);
+  int r = comm_exchange(m->comm, x, n);
+  if (r) return r;
+  if (m->nb[DIR_W] >= 0) launch_split_unpack_strip(cs, f, sg, nl, -H, -1, H, sg.ny + 2, comm_recvbuf(m->comm, DIR_W));
+  if (m->nb[DIR_E] >= 0) launch_split_unpack_strip(cs, f, sg, nl, sg.nx, -1, H, sg.ny + 2, comm_recvbuf(m->comm, DIR_E));
+  n = 0;
+  const int x0 = -H, xw = sg.nx + 2 * H;
+  if (m->nb[DIR_S] >= 0) pack(DIR_S, x0, 0, xw, H);
+  if (m->nb[DIR_N] >= 0) pack(DIR_N, x0, sg.ny - H, xw, H);
+  if ((r = comm_exchange(m->comm, x, n))) return r;
+  if (m->nb[DIR_S] >= 0) launch_split_unpack_strip(cs, fs, hg, nl, x0, 0, xw, H, comm_recvbuf(m->comm, DIR_S));
+  if (m->nb[DIR_N] >= 0) launch_split_unpack_strip(cs, fn, hg, nl, x0, 0, xw, H, comm_recvbuf(m->comm, DIR_N));
+  comm_end(m);
+  return MSOM_OK;
+}
+
 // ------------------------------------------------------------------ lifecycle
 
 static int alloc_all(msom *m) {
@@ -478,7 +514,7 @@ static msom *create_common(const Params &p0, int px, int py, int rank, const voi
   }
   if (alloc_all(m) != MSOM_OK ||
       (m->nranks > 1 && comm_create(&m->comm, rank, m->nranks, id128, m->st2,
-                                    (size_t)3 * ((m->nx > m->ny ? m->nx : m->ny) + 6) * m->nl) != MSOM_OK) ||
+                                    (size_t)MARCH_HALO * ((m->nx > m->ny ? m->nx : m->ny) + 16) * m->nl) != MSOM_OK) ||
       set_vars(m) != MSOM_OK) {
     msom_destroy(m);
     return nullptr;
@@ -518,6 +554,8 @@ extern "C" int msom_destroy(msom_t *m) {
   for (int k = 0; k < m->nlev; k++) {
     if (m->da[k]) hipFree(m->da[k]);
     if (m->da_alt[k]) hipFree(m->da_alt[k]);
+    for (auto *v : {&m->mh_da_s, &m->mh_da_n, &m->mh_res_s, &m->mh_res_n})
+      if (k < v->size() && (*v)[k]) hipFree((*v)[k]);
     if (m->res[k]) hipFree(m->res[k]);
     if (m->S[k]) hipFree(m->S[k]);
   }
@@ -930,13 +968,14 @@ struct Lev {
   int walls;
   bool tiled;   // needs halo exchanges
   bool fine;    // level 0 (profiling tag)
+  int k;        // tile level index (-1: gathered global level)
 };
 static Lev tile_lev(msom *m, int k) {
-  return Lev{&m->da[k], &m->da_alt[k], m->res[k], m->S[k], &m->sg[k], &m->rc[k], m->walls, m->nranks > 1, k == 0};
+  return Lev{&m->da[k], &m->da_alt[k], m->res[k], m->S[k], &m->sg[k], &m->rc[k], m->walls, m->nranks > 1, k == 0, k};
 }
 static Lev glob_lev(msom *m, int k) {
   const int q = k - m->agg_level;
-  return Lev{&m->gda[q], &m->gda_alt[q], m->gres[q], nullptr, &m->gsg[q], &m->rc[k], WALL_ALL, false, false};
+  return Lev{&m->gda[q], &m->gda_alt[q], m->gres[q], nullptr, &m->gsg[q], &m->rc[k], WALL_ALL, false, false, -1};
 }
 
 // can the level use the temporally blocked smoother (k_relax_block: 2 sweeps per pass)?
@@ -948,7 +987,9 @@ static bool block_ok(msom *m, const Lev &L) {
 // only ~2000 concurrent chunks hide (measured at nl = 6: 4096^2 1.54 -> 1.05 ms per 7 half-sweeps, 2048^2 385 -> 310 us,
 // but 1024^2 105 -> 238 us).  march = 2 forces it on every level that is wide enough (tests)
 static bool march_ok(msom *m, const Lev &L) {
-  if (!m->march || m->block_sweeps || !m->uniformS || m->nl < 2 || L.tiled || L.walls != WALL_ALL || L.sg->nx < 512 || L.sg->ny < 64) return false;
+  if (!m->march || m->block_sweeps || !m->uniformS || m->nl < 2 || (m->walls & WALL_PER) || (!L.tiled && L.walls != WALL_ALL) || L.sg->nx < 512 ||
+      L.sg->ny < 64)
+    return false;
   return m->march >= 2 || (size_t)L.sg->nx * L.sg->ny * m->nl >= ((size_t)1 << 24);
 }
 // is the prolongation coarse -> L folded into the first smoothing pass of L?
@@ -966,8 +1007,28 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
   int it = 0;
   if (march_ok(m, L)) {
     // 2 nrelax half-sweeps; the first red one may carry the prolongation (in place), the others go in passes of
-    // up to march_k, ping-ponging between the two correction buffers; a single left-over half-sweep runs in place
+    // up to march_k, ping-ponging between the two correction buffers; a single left-over half-sweep runs in place.
+    // Tiles: a pass reads MARCH_HALO cells / rows of its neighbours (exchanged once per pass instead of once per
+    // half-sweep; the cone of dependence is re-computed, bit-identically, on both sides of the edge)
     int n = 2 * nrelax, c = 0;
+    MarchHalo mh{nullptr, nullptr, nullptr, nullptr, 0, MARCH_HALO};
+    SplitGeom hg = make_split(L.sg->nx, MARCH_HALO);
+    if (L.tiled) {
+      const int k = L.k;
+      if (m->mh_da_s.size() < (size_t)m->nlev) {
+        m->mh_da_s.assign(m->nlev, nullptr); m->mh_da_n.assign(m->nlev, nullptr); m->mh_res_s.assign(m->nlev, nullptr); m->mh_res_n.assign(m->nlev, nullptr);
+      }
+      if (!m->mh_da_s[k]) {
+        for (auto *v : {&m->mh_da_s, &m->mh_da_n, &m->mh_res_s, &m->mh_res_n}) {
+          if (hipMalloc(&(*v)[k], hg.ls * nl * sizeof(double)) != hipSuccess) { m->sticky = MSOM_ERR_HIP; return; }
+          hipMemsetAsync((*v)[k], 0, hg.ls * nl * sizeof(double), m->st);
+        }
+      }
+      mh.ls = hg.ls;
+      mh.in_s = m->nb[DIR_S] >= 0 ? m->mh_da_s[k] : nullptr; mh.in_n = m->nb[DIR_N] >= 0 ? m->mh_da_n[k] : nullptr;
+      mh.res_s = m->nb[DIR_S] >= 0 ? m->mh_res_s[k] : nullptr; mh.res_n = m->nb[DIR_N] >= 0 ? m->mh_res_n[k] : nullptr;
+      STICKY(m, exch_split_deep(m, L.res, *L.sg, m->mh_res_s[k], m->mh_res_n[k], hg, nl));  // constant during the sweeps
+    }
     if (coarse && n > 0) {
       launch_relax_red_prolong(m->st, *L.da, *coarse->da, *coarse->sg, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, L.walls);
       n--; c = 1;
@@ -976,13 +1037,19 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
       const int kmax = nl >= 7 && m->march_k > 3 ? 3 : m->march_k;
       int K = n < kmax ? n : kmax;
       if (n - K == 1 && K > 2) K--;
+      if (L.tiled) STICKY(m, exch_split_deep(m, *L.da, *L.sg, m->mh_da_s[L.k], m->mh_da_n[L.k], hg, nl));
       if (prof) prof_begin(m, m->prof_march[K]);
-      launch_relax_march(m->st, *L.da, *L.da_alt, L.res, *L.sg, nl, *L.rc, c, K, L.walls, g_march_rows);
+      launch_relax_march(m->st, *L.da, *L.da_alt, L.res, *L.sg, nl, *L.rc, c, K, L.walls, g_march_rows, L.tiled ? &mh : nullptr);
       if (prof) prof_end(m, m->prof_march[K]);
       std::swap(*L.da, *L.da_alt);
       n -= K; c = (c + K) & 1;
     }
-    if (n == 1) launch_relax_color(m->st, *L.da, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, c, L.walls, L.fine);
+    if (n == 1) {
+      if (L.tiled) STICKY(m, exch_split(m, *L.da, *L.sg, nl, 0));
+      launch_relax_color(m->st, *L.da, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, c, L.walls, L.fine);
+    }
+    // boundary_level(da, l) after the last half-sweep; it also carries the corner ghosts the prolongation reads
+    if (L.tiled) STICKY(m, exch_split(m, *L.da, *L.sg, nl, corners_last));
     return;
   }
   if (block_ok(m, L)) {

@@ -238,3 +238,40 @@ def test_coarse_level_agglomeration_is_bit_identical(px, py, tile, nl, agg_size,
     assert out[0]["st"].i == g.mgstats().i and out[0]["st"].resa == g.mgstats().resa
     assert np.array_equal(assemble(out, "q", px, py), g.get(F["Q"]))
     assert np.array_equal(assemble(out, "psi", px, py), g.get(F["PSI"]))
+
+
+@pytest.mark.parametrize("px,py,tx,ty,nl", [(2, 1, 512, 64, 3), (1, 2, 512, 64, 2), (2, 2, 512, 128, 6), (2, 2, 1024, 64, 4)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_chained_smoother_on_tiles(px, py, tx, ty, nl, strict):
+    """option march = 2 on tiles: a pass of chained half-sweeps reads 4 rows / cells of its neighbour tiles (one deep
+    halo exchange per pass instead of one exchange per half-sweep) and re-computes the cone of dependence.  Strict build
+    (uniform-S solver switched on): equal to the single tile, with and without the chained smoother, bit for bit.
+    Product build: the levels that take the chained pass differ between a tile and the whole grid and FMA contraction is
+    chosen per kernel, so the comparison is to fp64 round-off (1e-10 of max|psi|, same cycle counts)"""
+    gnx, gny = tx * px, ty * py
+    levels = int(np.log2(min(tx, ty)))
+    params = orc.double_gyre_params(gnx, nl, extra=(f"Ny = {gny}\n" if gny != gnx else "") + f"MGLEVELS = {levels}\n")
+    psi = orc.synthetic_psi(nl, gny, gnx)
+    out = run_tiled(params, px, py, psi, nsteps=2, strict=strict, opts={"march": 2, "TOLERANCE": 1e-7, "uniform_S": 1})
+    ref = []
+    for march in (0, 2):
+        g = QG(params, strict=strict)
+        g.option("quiet", 1); g.option("march", march); g.option("TOLERANCE", 1e-7); g.option("uniform_S", 1)
+        g.set(F["PSI"], psi)
+        g.set_const()
+        g.set_tnext(float("inf"))
+        dts = [g.step() for _ in range(2)]
+        assert g.param("uniform_S") == 1.0
+        ref.append((dts, g.get(F["Q"]), g.get(F["PSI"]), g.mgstats().i))
+        g.close()
+    for r in range(px * py):
+        assert out[r]["st"].i == ref[1][3]
+    q, p = assemble(out, "q", px, py), assemble(out, "psi", px, py)
+    if strict:
+        for r in range(px * py):
+            assert out[r]["dts"] == ref[1][0], r
+        assert np.array_equal(q, ref[1][1]) and np.array_equal(p, ref[1][2])
+        assert np.array_equal(ref[0][1], ref[1][1]) and np.array_equal(ref[0][2], ref[1][2])
+    else:
+        assert np.abs(p - ref[1][2]).max() <= 1e-10 * np.abs(ref[1][2]).max()
+        assert np.abs(q - ref[1][1]).max() <= 1e-10 * np.abs(ref[1][1]).max()
