@@ -275,3 +275,26 @@ def test_chained_smoother_on_tiles(px, py, tx, ty, nl, strict):
     else:
         assert np.abs(p - ref[1][2]).max() <= 1e-10 * np.abs(ref[1][2]).max()
         assert np.abs(q - ref[1][1]).max() <= 1e-10 * np.abs(ref[1][1]).max()
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_chained_smoother_default_on_big_tiles(strict):
+    """default options on tiles that are big enough for the chained smoother to switch itself on (2 x 1 tiles of
+    2048^2 x 4 = 2^24 cell-layers each): same comparison as above, one step"""
+    px, py, tx, ty, nl = 2, 1, 2048, 2048, 4
+    gnx, gny = tx * px, ty * py
+    params = orc.double_gyre_params(gnx, nl, extra=f"Ny = {gny}\nMGLEVELS = 11\n")
+    psi = orc.synthetic_psi(nl, gny, gnx)
+    out = run_tiled(params, px, py, psi, nsteps=1, strict=strict, opts={"uniform_S": 1})
+    g = QG(params, strict=strict)
+    g.option("quiet", 1); g.option("uniform_S", 1)
+    g.set(F["PSI"], psi)
+    g.set_const()
+    g.set_tnext(float("inf"))
+    g.step()
+    p = assemble(out, "psi", px, py)
+    if strict:
+        assert np.array_equal(p, g.get(F["PSI"]))
+    else:
+        assert np.abs(p - g.get(F["PSI"])).max() <= 1e-10 * np.abs(g.get(F["PSI"])).max()
+    assert out[0]["st"].i == g.mgstats().i
