@@ -214,7 +214,7 @@ int launch_relax_march(hipStream_t st, const double *in, double *out, const doub
     const int strips = (sg.hk + 59) / 60, want = 2048 / strips > 0 ? 2048 / strips : 1;
     H = (sg.ny + want - 1) / want;
     H = ((H + 7) / 8) * 8;
-    if (H < 32) H = 32;
+    if (H < 16) H = 16;
   }
   a.H = H;
   if (nl >= 7 && K > 3) return -1;  // 4 windows of 7 or 8 layers do not fit 256 VGPRs
