@@ -120,7 +120,7 @@ void launch_correct(hipStream_t st, double *a, const NatGeom &g, const double *d
 // out like `rows` rows of the level (ls doubles per layer)
 struct MarchHalo { const double *in_s, *in_n, *res_s, *res_n; size_t ls; int rows; };
 int launch_relax_march(hipStream_t st, const double *in, double *out, const double *res, const SplitGeom &sg, int nl, const RelaxCoef &rc, int c1,
-                       int K, int walls, int chunk_rows = 0, const MarchHalo *h = nullptr);
+                       int K, int walls, int chunk_rows = 0, const MarchHalo *h = nullptr, const double *coarse = nullptr, const SplitGeom *cg = nullptr);
 
 // ---- kernels_wavelet.hip
 void launch_wv_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl);

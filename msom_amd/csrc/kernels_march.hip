@@ -29,15 +29,20 @@ struct MarchArgs {
   const double *in_s, *in_n, *res_s, *res_n;
   size_t hls;
   int KR;
+  // PL variant: the input of the first half-sweep is the bilinear prolongation of the coarser level's correction
+  // (mspg/elliptic.h:74-86), interpolated on the fly and never stored; `in` is not read
+  const double *coarse;
+  SplitGeom cg;
   SplitGeom g;
   int c1;  // colour of the first half-sweep (0 red, 1 black)
   int walls, H, remap;
   RelaxCoef rc;
 };
 
-template <int NL, int K>
+template <int NL, int K, bool PL>
 __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
-  constexpr int HL = (K + 1) / 2, OW = 64 - 2 * HL;
+  // halo lanes per side: K cells of cone; the prolongation variant needs one more coarse cell (DPP neighbour) beyond them
+  constexpr int HL = PL ? (K + 2) / 2 : (K + 1) / 2, OW = 64 - 2 * HL;
   // residual windows: half-sweeps 1, 3 use the residual of colour c1 at rows t, t - 2; half-sweeps 2, 4 that of the
   // other colour at rows t - 1, t - 3.  Every residual value is read from memory ONCE and waits in registers
   constexpr int D1 = K >= 3 ? 3 : 1, D2 = K >= 4 ? 3 : 1;
@@ -63,6 +68,39 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
     return f + off(half, r);
   };
 
+  // PL: colour-c0 cells of fine row r from the coarse level.  Fine cell (x, r): coarse cell (I, J) = (x >> 1, r >> 1) and
+  // its neighbours towards the cell's quadrant (prolong_pt, kernels_mg.hip).  Lane k holds x = 2k, 2k + 1 => I = k for
+  // both; the x-neighbour I +- 1 is the adjacent lane's coarse cell (DPP).  Ghost rows / columns of the prolongated
+  // field are -P(wall cell) (what the red + prolongation kernel writes as lagged ghosts).
+  const int chp = p.cg.hp;
+  const ptrdiff_t crp = p.cg.rp;
+  const size_t cls = p.cg.ls;
+  const int Ic = min(max(kx, -1), p.cg.nx);  // coarse column of this lane (ghosts -1 and nx_c included)
+  const ptrdiff_t coff = (Ic & 1) * chp + MSOM_SP + (Ic >> 1);
+  auto prolong_row = [&](int r, int half, double (&dst)[NL]) {
+    bool neg = false;
+    int rr = r;
+    if (r < 0) { rr = 0; neg = wallS; }
+    if (r >= ny) { rr = ny - 1; neg = wallN; }
+    const int J = rr >> 1, cy = (rr & 1) ? 1 : -1;
+    const double *c0p = p.coarse + (ptrdiff_t)(J + 1) * crp + coff, *c1p = p.coarse + (ptrdiff_t)(J + cy + 1) * crp + coff;
+    const bool gw = !neg && wallW && half == 1, ge = !neg && wallE && half == 0;  // a ghost column of this colour in this row
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      const double a0 = c0p[l * cls], a1 = c1p[l * cls];
+      const double b0 = half ? lane_above(a0) : lane_below(a0), b1 = half ? lane_above(a1) : lane_below(a1);
+      double v = BILINEAR(a0, b0, a1, b1);
+      if (neg) v = -v;
+      if (gw | ge) {  // -P(wall cell): the wall cell is the lane's / the neighbour lane's cell of the OTHER half
+        const double o0 = half ? lane_below(a0) : lane_above(a0), o1 = half ? lane_below(a1) : lane_above(a1);
+        const double po = BILINEAR(a0, o0, a1, o1);
+        const double gv = gw ? -lane_above(po) : -lane_below(po);
+        if (gw ? kx == -1 : kx == hk) v = gv;
+      }
+      dst[l] = v;
+    }
+  };
+
   double W[K][3][NL];  // W[s]: values after half-sweep s (s = 0: the input) of rows r - 1, r, r + 1 of the half-sweep that reads them
 #pragma unroll
   for (int s = 0; s < K; s++)
@@ -84,10 +122,13 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     const int r = y0 - K + q;
-    size_t st;
-    const double *src = rowsrc(p.in, p.in_s, p.in_n, (r + c0) & 1, r, st);
+    if (PL) prolong_row(r, (r + c0) & 1, W[0][q + 1]);
+    else {
+      size_t st;
+      const double *src = rowsrc(p.in, p.in_s, p.in_n, (r + c0) & 1, r, st);
 #pragma unroll
-    for (int l = 0; l < NL; l++) W[0][q + 1][l] = src[l * st];
+      for (int l = 0; l < NL; l++) W[0][q + 1][l] = src[l * st];
+    }
   }
   for (int t = y0 - K + 1; t <= y1 + K - 2; t++) {
 #pragma unroll
@@ -102,15 +143,19 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
       for (int d = D2 - 1; d > 0; d--) R2[d][l] = R2[d - 1][l];
     }
     {
-      size_t s0, s1, s2;
-      const double *src = rowsrc(p.in, p.in_s, p.in_n, (t + 1 + c0) & 1, t + 1, s0);
+      size_t s0 = 0, s1, s2;
+      const double *src = PL ? p.res : rowsrc(p.in, p.in_s, p.in_n, (t + 1 + c0) & 1, t + 1, s0);
       // residual rows: beyond a wall they are never used (clamped), beyond a tile edge they come from the halo arrays
       const int t1 = (t < 0 && !p.res_s) ? 0 : ((t >= ny && !p.res_n) ? ny - 1 : t);
       const int t2 = (t - 1 < 0 && !p.res_s) ? 0 : ((t - 1 >= ny && !p.res_n) ? ny - 1 : t - 1);
       const double *r1 = rowsrc(p.res, p.res_s, p.res_n, (t + p.c1) & 1, t1, s1);           // colour c1, row t
       const double *r2 = rowsrc(p.res, p.res_s, p.res_n, (t - 1 + c0) & 1, t2, s2);         // colour c0, row t - 1
 #pragma unroll
-      for (int l = 0; l < NL; l++) { W[0][2][l] = src[l * s0]; R1[0][l] = r1[l * s1]; R2[0][l] = r2[l * s2]; }
+      for (int l = 0; l < NL; l++) {
+        if (!PL) W[0][2][l] = src[l * s0];
+        R1[0][l] = r1[l * s1]; R2[0][l] = r2[l * s2];
+      }
+      if (PL) prolong_row(t + 1, (t + 1 + c0) & 1, W[0][2]);
     }
 #pragma unroll
     for (int s = 1; s <= K; s++) {
@@ -192,17 +237,25 @@ static int march_dispatch(hipStream_t st, const MarchArgs &a, int K) {
   const int hk = a.g.hk;
   auto grid = [&](int ow) { return dim3((hk + ow - 1) / ow, (a.g.ny + a.H - 1) / a.H); };
   switch (K) {
-    case 2: hipLaunchKernelGGL((k_relax_march<NL, 2>), grid(62), dim3(64), 0, st, a); return 0;
-    case 3: hipLaunchKernelGGL((k_relax_march<NL, 3>), grid(60), dim3(64), 0, st, a); return 0;
-    case 4: hipLaunchKernelGGL((k_relax_march<NL, 4>), grid(60), dim3(64), 0, st, a); return 0;
+    case 2: hipLaunchKernelGGL((k_relax_march<NL, 2, false>), grid(62), dim3(64), 0, st, a); return 0;
+    case 3:
+      if (a.coarse) hipLaunchKernelGGL((k_relax_march<NL, 3, true>), grid(60), dim3(64), 0, st, a);
+      else hipLaunchKernelGGL((k_relax_march<NL, 3, false>), grid(60), dim3(64), 0, st, a);
+      return 0;
+    case 4:
+      if (a.coarse) hipLaunchKernelGGL((k_relax_march<NL, 4, true>), grid(58), dim3(64), 0, st, a);
+      else hipLaunchKernelGGL((k_relax_march<NL, 4, false>), grid(60), dim3(64), 0, st, a);
+      return 0;
   }
   return -1;
 }
 
 // K (2..4) half-sweeps starting with colour c1, in -> out; returns -1 if (nl, K) has no instantiation
 int launch_relax_march(hipStream_t st, const double *in, double *out, const double *res, const SplitGeom &sg, int nl, const RelaxCoef &rc, int c1,
-                       int K, int walls, int chunk_rows, const MarchHalo *h) {
+                       int K, int walls, int chunk_rows, const MarchHalo *h, const double *coarse, const SplitGeom *cg) {
   MarchArgs a;
+  a.coarse = coarse; a.cg = cg ? *cg : sg;
+  if (coarse && (K < 3 || h)) return -1;  // the prolongation variant exists for K = 3, 4 on whole (untiled) levels
   a.in_s = h ? h->in_s : nullptr; a.in_n = h ? h->in_n : nullptr; a.res_s = h ? h->res_s : nullptr; a.res_n = h ? h->res_n : nullptr;
   a.hls = h ? h->ls : 0; a.KR = h ? h->rows : 0;
   extern int g_march_remap;

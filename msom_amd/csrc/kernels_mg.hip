@@ -28,14 +28,6 @@
 #define DIVC(x, c, rc) ((x) * (rc))
 #endif
 
-// Basilisk's bilinear prolongation weight rule.  The product build pins the FMA contraction
-// so that every kernel that interpolates (k_prolong, k_relax_red_prolong, k_relax_block) and
-// every expansion inside them rounds identically; division by 16 is exact either way.
-#ifdef MSOM_STRICT
-#define BILINEAR(cn, cfx, cfy, cff) ((9. * (cn) + 3. * ((cfx) + (cfy)) + (cff)) / 16.)
-#else
-#define BILINEAR(cn, cfx, cfy, cff) (fma(9., (cn), fma(3., (cfx) + (cfy), (cff))) * 0.0625)
-#endif
 
 #define BX 64
 #define BY 4

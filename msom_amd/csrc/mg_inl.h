@@ -4,6 +4,15 @@
 
 #include "kernels.h"
 
+// Basilisk's bilinear prolongation weight rule.  The product build pins the FMA contraction
+// so that every kernel that interpolates (k_prolong, k_relax_red_prolong, k_relax_block) and
+// every expansion inside them rounds identically; division by 16 is exact either way.
+#ifdef MSOM_STRICT
+#define BILINEAR(cn, cfx, cfy, cff) ((9. * (cn) + 3. * ((cfx) + (cfy)) + (cff)) / 16.)
+#else
+#define BILINEAR(cn, cfx, cfy, cff) (fma(9., (cn), fma(3., (cfx) + (cfy), (cff))) * 0.0625)
+#endif
+
 // writes the homogeneous-Dirichlet ghosts that mirror cell (i, j) (edges: -v, corners: +v)
 __device__ __forceinline__ void split_write_ghosts(double *f, const SplitGeom &g, int l, int j, int i, double v, int walls) {
   if (walls & WALL_PER) {  // periodic images of an edge cell

@@ -103,6 +103,7 @@ struct msom {
   int block_sweeps = 0;  // experimental temporally blocked smoother (2 sweeps per pass); measured not faster at nl = 6
   int march = 1;         // chained half-sweeps in register windows (kernels_march.hip) on wide single-GPU levels
   int march_k = 4;       // at most this many half-sweeps per pass (2..4)
+  int march_prolong = 0; // whole levels: prolongation folded into the first pass (4 + 4 half-sweeps); measured 3 % slower than (red + prolongation) + 4 + 3
   int mg_fused = 1;  // fused residual+restriction and correction+residual passes of the multigrid cycle
   double *psi_alt = nullptr;  // second psi buffer (the fused correction writes out of place)
   int rhs_variant = 6;  // 6: one layer per wavefront, register windows (kernels_lpw.hip, default); 1: LDS tiles, software-pipelined; 0: LDS tiles, phase by phase
@@ -605,6 +606,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "mg_fused")) m->mg_fused = (int)v;
   else if (!strcmp(key, "march")) m->march = (int)v;
   else if (!strcmp(key, "march_rows")) g_march_rows = (int)v;
+  else if (!strcmp(key, "march_prolong")) m->march_prolong = (int)v;
   else if (!strcmp(key, "march_xcd")) { extern int g_march_remap; g_march_remap = (int)v; }
   else if (!strcmp(key, "march_k")) m->march_k = (int)v < 2 ? 2 : ((int)v > 4 ? 4 : (int)v);
   else if (!strcmp(key, "block_sweeps")) { m->block_sweeps = (int)v; if (m->const_set) return build_coefs(m); }
@@ -1029,17 +1031,27 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
       mh.res_s = m->nb[DIR_S] >= 0 ? m->mh_res_s[k] : nullptr; mh.res_n = m->nb[DIR_N] >= 0 ? m->mh_res_n[k] : nullptr;
       STICKY(m, exch_split_deep(m, L.res, *L.sg, m->mh_res_s[k], m->mh_res_n[k], hg, nl));  // constant during the sweeps
     }
-    if (coarse && n > 0) {
+    const int kmax = nl >= 7 && m->march_k > 3 ? 3 : m->march_k;
+    if (coarse && n >= 3 && kmax >= 3 && !L.tiled && m->march_prolong) {
+      // whole levels: the prolongation rides in the first PASS (its input is interpolated from the coarse level on
+      // the fly), so the 2 nrelax half-sweeps are 4 + 4 instead of (red + prolongation) + 4 + 3
+      int K = n < kmax ? n : kmax;
+      if (n - K == 1 && K > 3) K--;
+      if (prof) prof_begin(m, m->prof_march[K]);
+      if (launch_relax_march(m->st, nullptr, *L.da_alt, L.res, *L.sg, nl, *L.rc, 0, K, L.walls, g_march_rows, nullptr, *coarse->da, coarse->sg)) m->sticky = MSOM_ERR_ARG;
+      if (prof) prof_end(m, m->prof_march[K]);
+      std::swap(*L.da, *L.da_alt);
+      n -= K; c = K & 1;
+    } else if (coarse && n > 0) {
       launch_relax_red_prolong(m->st, *L.da, *coarse->da, *coarse->sg, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, L.walls);
       n--; c = 1;
     }
     while (n >= 2) {
-      const int kmax = nl >= 7 && m->march_k > 3 ? 3 : m->march_k;
       int K = n < kmax ? n : kmax;
       if (n - K == 1 && K > 2) K--;
       if (L.tiled) STICKY(m, exch_split_deep(m, *L.da, *L.sg, m->mh_da_s[L.k], m->mh_da_n[L.k], hg, nl));
       if (prof) prof_begin(m, m->prof_march[K]);
-      launch_relax_march(m->st, *L.da, *L.da_alt, L.res, *L.sg, nl, *L.rc, c, K, L.walls, g_march_rows, L.tiled ? &mh : nullptr);
+      if (launch_relax_march(m->st, *L.da, *L.da_alt, L.res, *L.sg, nl, *L.rc, c, K, L.walls, g_march_rows, L.tiled ? &mh : nullptr)) m->sticky = MSOM_ERR_ARG;
       if (prof) prof_end(m, m->prof_march[K]);
       std::swap(*L.da, *L.da_alt);
       n -= K; c = (c + K) & 1;
