@@ -200,15 +200,20 @@ def main():
         plain_bytes = (3.0 + sigma) * w / 2.0
         marched = m4_n + m3_n > 0
         if marched:
-            # the smoother's finest-level pass: K chained half-sweeps per launch (kernels_march.hip).  Algorithmic bytes
-            # of ONE launch, whatever K: the other colour's da in (w/2), the residual of both colours (w), both colours
-            # of da out (w)
+            # the smoother's finest-level pass: K chained half-sweeps per launch (kernels_march.hip).
+            # Contract figure: SURVEY 8(d)'s per-unit bytes (one red+black sweep = (3 + sigma) w: R a, R b, W a) x the
+            # units one launch processes (K / 2 sweeps).  The pass itself needs less -- the other colour's da in (w/2),
+            # the residual of both colours (w), both colours of da out (w) = 2.5 w whatever K -- because the values
+            # between the chained half-sweeps never leave the registers; that figure and the measured HBM traffic are
+            # reported next to the contract one (so `frac` can exceed 1: it is an effective bandwidth)
             K, launch_ms, launches = (4, m4_ms, m4_n) if m4_n * m4_ms >= m3_n * m3_ms else (3, m3_ms, m3_n)
-            launch_bytes = 2.5 * w
-            kernel = f"k_relax_march<{nl}, {K}> (finest level: {K} chained red-black colour half-sweeps per pass, intermediate values in registers)"
+            launch_bytes = plain_bytes * K
+            pass_bytes = 2.5 * w
+            kernel = f"k_relax_march<{nl}, {K}> (finest level: {K} chained red-black colour half-sweeps = {K / 2:g} sweeps per pass, intermediate values in registers)"
             pmc_file = "r01_pmc_traffic_march.json"
         else:
             K, launch_bytes, launch_ms, launches = 1, plain_bytes, sweep_ms / 2.0, 2 * sweep_n
+            pass_bytes = plain_bytes
             kernel = f"k_relax_color_x2<{nl}, {'true' if uniform else 'false'}, true> (finest-level red-black colour half-sweep)"
             pmc_file = "r01_pmc_traffic_relax_fine.json"
         achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
@@ -253,6 +258,10 @@ def main():
                 "avg_launch_ms": launch_ms,
                 "launches_timed": launches,
                 "half_sweeps_per_launch": K,
+                "per_unit_bytes": 2.0 * plain_bytes, "units_per_launch": K / 2.0, "unit_name": "red+black sweep (SURVEY 8d: R a, R b, W a)",
+                "pass_compulsory_bytes": pass_bytes,
+                "achieved_vs_pass_bytes": pass_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0,
+                "frac_vs_pass_bytes": pass_bytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if launch_ms > 0 else 0.0,
                 "plain_half_sweep_kernel": {
                     "kernel": f"k_relax_color_x2<{nl}, {'true' if uniform else 'false'}, true> (one colour half-sweep per launch; used on tiles and small levels)",
                     "avg_launch_ms": plain_ms, "algorithmic_bytes_per_launch": plain_bytes,
