@@ -33,13 +33,18 @@ struct MarchArgs {
   // (mspg/elliptic.h:74-86), interpolated on the fly and never stored; `in` is not read
   const double *coarse;
   SplitGeom cg;
+  // CORR variant (last pass of the finest level): the correction a += da (mspg/elliptic.h:92-98) rides in the pass:
+  // psi_out = psi + (value after the last update of each colour), natural layout, wall ghosts included; da is not stored
+  const double *psi;
+  double *psi_out;
+  NatGeom ng;
   SplitGeom g;
   int c1;  // colour of the first half-sweep (0 red, 1 black)
   int walls, H, remap;
   RelaxCoef rc;
 };
 
-template <int NL, int K, bool PL>
+template <int NL, int K, bool PL, bool CORR>
 __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
   // halo lanes per side: K cells of cone; the prolongation variant needs one more coarse cell (DPP neighbour) beyond them
   constexpr int HL = PL ? (K + 2) / 2 : (K + 1) / 2, OW = 64 - 2 * HL;
@@ -157,6 +162,14 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
       }
       if (PL) prolong_row(t + 1, (t + 1 + c0) & 1, W[0][2]);
     }
+    // CORR: psi of the row the last half-sweep finishes in this step, requested before the chain of half-sweeps
+    double2 pa[CORR ? NL : 1];
+    if (CORR) {
+      const int rk = min(max(t - (K - 1), 0), ny - 1);
+      const double *ps = p.psi + nat_idx(p.ng, 0, rk, 2 * min(max(kx, 0), hk - 1));
+#pragma unroll
+      for (int l = 0; l < NL; l++) pa[l] = *reinterpret_cast<const double2 *>(ps + l * p.ng.ls);
+    }
 #pragma unroll
     for (int s = 1; s <= K; s++) {
       const int r = t - (s - 1);                 // row of half-sweep s
@@ -216,7 +229,7 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
 #pragma unroll
         for (int l = 0; l < NL; l++) W[s][2][l] = x[l];
       }
-      if (s >= K - 1 && r >= y0 && r < y1 && own_lane) {  // the last update of each colour is what the level keeps
+      if (!CORR && s >= K - 1 && r >= y0 && r < y1 && own_lane) {  // the last update of each colour is what the level keeps
         double *dst = p.out + off(px, r);
 #pragma unroll
         for (int l = 0; l < NL; l++) dst[l * ls] = x[l];
@@ -224,6 +237,23 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
         if (i == 0 || i == p.g.nx - 1 || r == 0 || r == ny - 1) {
 #pragma unroll
           for (int l = 0; l < NL; l++) split_write_ghosts(p.out, p.g, l, r, i, x[l], p.walls);
+        }
+      }
+      if (CORR && s == K && r >= y0 && r < y1 && own_lane) {
+        // both colours of row r are final now: this half-sweep's cell and the other one, which the previous half-sweep
+        // updated one step ago (the centre row of its window): one 16-byte load and store per lane and layer
+        const size_t c = nat_idx(p.ng, 0, r, 2 * kx);
+        const bool wallcell = kx == 0 || kx == hk - 1 || r == 0 || r == ny - 1;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+          const double2 a = pa[l];
+          const double de = px ? W[K - 1][1][l] : x[l], dd = px ? x[l] : W[K - 1][1][l];
+          const double ve = a.x + de, vo = a.y + dd;
+          *reinterpret_cast<double2 *>(p.psi_out + c + l * p.ng.ls) = make_double2(ve, vo);
+          if (wallcell) {
+            nat_write_ghosts(p.psi_out, p.ng, l, r, 2 * kx, ve, p.walls);
+            nat_write_ghosts(p.psi_out, p.ng, l, r, 2 * kx + 1, vo, p.walls);
+          }
         }
       }
     }
@@ -237,14 +267,19 @@ static int march_dispatch(hipStream_t st, const MarchArgs &a, int K) {
   const int hk = a.g.hk;
   auto grid = [&](int ow) { return dim3((hk + ow - 1) / ow, (a.g.ny + a.H - 1) / a.H); };
   switch (K) {
-    case 2: hipLaunchKernelGGL((k_relax_march<NL, 2, false>), grid(62), dim3(64), 0, st, a); return 0;
+    case 2:
+      if (a.psi_out) hipLaunchKernelGGL((k_relax_march<NL, 2, false, true>), grid(62), dim3(64), 0, st, a);
+      else hipLaunchKernelGGL((k_relax_march<NL, 2, false, false>), grid(62), dim3(64), 0, st, a);
+      return 0;
     case 3:
-      if (a.coarse) hipLaunchKernelGGL((k_relax_march<NL, 3, true>), grid(60), dim3(64), 0, st, a);
-      else hipLaunchKernelGGL((k_relax_march<NL, 3, false>), grid(60), dim3(64), 0, st, a);
+      if (a.coarse) hipLaunchKernelGGL((k_relax_march<NL, 3, true, false>), grid(60), dim3(64), 0, st, a);
+      else if (a.psi_out) hipLaunchKernelGGL((k_relax_march<NL, 3, false, true>), grid(60), dim3(64), 0, st, a);
+      else hipLaunchKernelGGL((k_relax_march<NL, 3, false, false>), grid(60), dim3(64), 0, st, a);
       return 0;
     case 4:
-      if (a.coarse) hipLaunchKernelGGL((k_relax_march<NL, 4, true>), grid(58), dim3(64), 0, st, a);
-      else hipLaunchKernelGGL((k_relax_march<NL, 4, false>), grid(60), dim3(64), 0, st, a);
+      if (a.coarse) hipLaunchKernelGGL((k_relax_march<NL, 4, true, false>), grid(58), dim3(64), 0, st, a);
+      else if (a.psi_out) hipLaunchKernelGGL((k_relax_march<NL, 4, false, true>), grid(60), dim3(64), 0, st, a);
+      else hipLaunchKernelGGL((k_relax_march<NL, 4, false, false>), grid(60), dim3(64), 0, st, a);
       return 0;
   }
   return -1;
@@ -252,8 +287,11 @@ static int march_dispatch(hipStream_t st, const MarchArgs &a, int K) {
 
 // K (2..4) half-sweeps starting with colour c1, in -> out; returns -1 if (nl, K) has no instantiation
 int launch_relax_march(hipStream_t st, const double *in, double *out, const double *res, const SplitGeom &sg, int nl, const RelaxCoef &rc, int c1,
-                       int K, int walls, int chunk_rows, const MarchHalo *h, const double *coarse, const SplitGeom *cg) {
+                       int K, int walls, int chunk_rows, const MarchHalo *h, const double *coarse, const SplitGeom *cg, const MarchCorrect *mc) {
   MarchArgs a;
+  a.psi = mc ? mc->psi : nullptr; a.psi_out = mc ? mc->psi_out : nullptr;
+  if (mc) a.ng = mc->g;
+  if (mc && coarse) return -1;
   a.coarse = coarse; a.cg = cg ? *cg : sg;
   if (coarse && (K < 3 || h)) return -1;  // the prolongation variant exists for K = 3, 4 on whole (untiled) levels
   a.in_s = h ? h->in_s : nullptr; a.in_n = h ? h->in_n : nullptr; a.res_s = h ? h->res_s : nullptr; a.res_n = h ? h->res_n : nullptr;

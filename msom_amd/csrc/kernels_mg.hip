@@ -44,33 +44,6 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-__device__ __forceinline__ void nat_write_ghosts(double *f, const NatGeom &g, int l, int j, int i, double v, int walls) {
-  if (walls & WALL_PER) {
-    const bool w = i == 0, e = i == g.nx - 1, s = j == 0, n = j == g.ny - 1;
-    if (!(w | e | s | n)) return;
-    if (w) f[nat_idx(g, l, j, g.nx)] = v;
-    if (e) f[nat_idx(g, l, j, -1)] = v;
-    if (s) f[nat_idx(g, l, g.ny, i)] = v;
-    if (n) f[nat_idx(g, l, -1, i)] = v;
-    if (w && s) f[nat_idx(g, l, g.ny, g.nx)] = v;
-    if (w && n) f[nat_idx(g, l, -1, g.nx)] = v;
-    if (e && s) f[nat_idx(g, l, g.ny, -1)] = v;
-    if (e && n) f[nat_idx(g, l, -1, -1)] = v;
-    return;
-  }
-  const bool w = i == 0 && (walls & WALL_W), e = i == g.nx - 1 && (walls & WALL_E);
-  const bool s = j == 0 && (walls & WALL_S), n = j == g.ny - 1 && (walls & WALL_N);
-  if (!(w | e | s | n)) return;
-  if (w) f[nat_idx(g, l, j, -1)] = -v;
-  if (e) f[nat_idx(g, l, j, g.nx)] = -v;
-  if (s) f[nat_idx(g, l, -1, i)] = -v;
-  if (n) f[nat_idx(g, l, g.ny, i)] = -v;
-  if (w && s) f[nat_idx(g, l, -1, -1)] = v;
-  if (w && n) f[nat_idx(g, l, g.ny, -1)] = v;
-  if (e && s) f[nat_idx(g, l, -1, g.nx)] = v;
-  if (e && n) f[nat_idx(g, l, g.ny, g.nx)] = v;
-}
-
 // ------------------------------------------------------------------ layout conversion
 
 __global__ void k_nat_to_split(const double *__restrict__ nat, NatGeom g, double *sp, SplitGeom sg, int nl) {
@@ -193,18 +166,20 @@ struct Res2Args {
   RelaxCoef rc;
 };
 
-template <bool CORRECT, bool WRITE, bool RESTRICT>
+// UMAX (without CORRECT): max |u| of a itself, for the pass that follows a correction done elsewhere (kernels_march.hip)
+template <bool CORRECT, bool WRITE, bool RESTRICT, bool UMAX = false>
 __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
   __shared__ double sr[RESTRICT ? MSOM_MAXNL : 1][BY][BX][2];
   __shared__ double smm[BY], sms[BY];
-  __shared__ double smu[CORRECT ? MSOM_MAXNL : 1][BY];
+  constexpr bool VEL = CORRECT || UMAX;
+  __shared__ double smu[VEL ? MSOM_MAXNL : 1][BY];
   const int kx = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
   const bool in = kx < p.sg.hk && j < p.g.ny;
   const int nl = p.nl;
   double m = 0., bs = 0.;
-  double um[CORRECT ? MSOM_MAXNL : 1];
+  double um[VEL ? MSOM_MAXNL : 1];
 #pragma unroll
-  for (int l = 0; l < (CORRECT ? MSOM_MAXNL : 1); l++) um[l] = 0.;
+  for (int l = 0; l < (VEL ? MSOM_MAXNL : 1); l++) um[l] = 0.;
   if (in) {
     const int pitch = p.g.pitch, i = 2 * kx;
     const double D = p.rc.D, rD = 1. / D;
@@ -270,12 +245,14 @@ __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
       }
       if (RESTRICT) { sr[l][threadIdx.y][threadIdx.x][0] = re; sr[l][threadIdx.y][threadIdx.x][1] = ro; }
       m = fmax(m, fmax(fabs(re), fabs(ro)));
-      if (CORRECT && !(p.dbg & 64)) {
+      if (VEL && !(p.dbg & 64)) {
         // face velocities of the corrected psi (comp_vel, msqg/qg.h:276-283): west and south face
         // of both cells; feeds the dt limiter so that dt is known before the tendency pass
-        const double *d = p.da + (size_t)l * p.sg.ls;
-        const double nw = p.a[c - 1 + pitch] + d[so - 1 + p.sg.rp], sw = p.a[c - 1 - pitch] + d[so - 1 - p.sg.rp];
-        const double se2 = p.a[c + 2 - pitch] + d[se + 1 - p.sg.rp];
+        double nw = p.a[c - 1 + pitch], sw = p.a[c - 1 - pitch], se2 = p.a[c + 2 - pitch];
+        if (CORRECT) {
+          const double *d = p.da + (size_t)l * p.sg.ls;
+          nw = nw + d[so - 1 + p.sg.rp]; sw = sw + d[so - 1 - p.sg.rp]; se2 = se2 + d[se + 1 - p.sg.rp];
+        }
         const double ue = fabs(DIVC(0.25 * (a1ne - a1se + nw - sw), D, rD)), ve = fabs(DIVC(0.25 * (a1o - a1w + a1so - sw), D, rD));
         const double uo = fabs(DIVC(0.25 * (a1no - a1so + a1ne - a1se), D, rD)), vo = fabs(DIVC(0.25 * (a1ee - a1e + se2 - a1se), D, rD));
         const double uu = fmax(fmax(ue, ve), fmax(uo, vo));
@@ -303,7 +280,7 @@ __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
   }
   m = wave_max(m);
   if (p.want_sum) bs = wave_sum(bs);
-  if (CORRECT) {
+  if (VEL) {
 #pragma unroll
     for (int l = 0; l < MSOM_MAXNL; l++)
       if (l < nl) {
@@ -319,7 +296,7 @@ __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
     atomicMax((unsigned long long *)p.maxres, (unsigned long long)__double_as_longlong(mm));
     if (p.want_sum) p.sum_partial[blockIdx.y * gridDim.x + blockIdx.x] = ss;
   }
-  if (CORRECT && threadIdx.y == 0 && threadIdx.x < nl) {
+  if (VEL && threadIdx.y == 0 && threadIdx.x < nl) {
     double v = smu[threadIdx.x][0];
     for (int k = 1; k < BY; k++) v = fmax(v, smu[threadIdx.x][k]);
     p.umax_partial[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * nl + threadIdx.x] = v;
@@ -336,7 +313,8 @@ __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
 #define CR_TR 16
 #define CR_TW 128
 #define CR_LP 132  // LDS row pitch (130 used)
-template <bool UNIFORM>
+// CORR = false: a is already the corrected field (kernels_march.hip applied a += da): only max |res|, max |u|
+template <bool UNIFORM, bool CORR = true>
 __global__ void __launch_bounds__(BX *BY, 4) k_correct_residual(Res2Args p) {
   __shared__ __align__(16) double T[2][CR_TR + 2][CR_LP];
   __shared__ double smm[BY];
@@ -362,8 +340,8 @@ __global__ void __launch_bounds__(BX *BY, 4) k_correct_residual(Res2Args p) {
       double e = 0., o = 0.;
       if (inx && y0 + ty + BY * k < ny) {
         const double2 v = *reinterpret_cast<const double2 *>(al + c0 + k * cstep);
-        e = v.x + dl[se0 + k * sstep];
-        o = v.y + dl[se0 + k * sstep + p.sg.hp];
+        e = v.x; o = v.y;
+        if (CORR) { e = e + dl[se0 + k * sstep]; o = o + dl[se0 + k * sstep + p.sg.hp]; }
       }
       xe[k] = e; xo[k] = o;
       *reinterpret_cast<double2 *>(&T[b][ty + BY * k + 1][2 * tx + 2]) = make_double2(e, o);
@@ -376,7 +354,10 @@ __global__ void __launch_bounds__(BX *BY, 4) k_correct_residual(Res2Args p) {
       else { r = h - 2 * (CR_TW + 2) - CR_TR; cc = CR_TW; }
       const int gx = x0 + cc, gy = y0 + r;
       double v = 0.;
-      if (gx <= nx && gy <= ny) v = al[nat_idx(p.g, 0, gy, gx)] + dl[split_idx(p.sg, 0, gy, gx)];
+      if (gx <= nx && gy <= ny) {
+        v = al[nat_idx(p.g, 0, gy, gx)];
+        if (CORR) v = v + dl[split_idx(p.sg, 0, gy, gx)];
+      }
       T[b][r + 1][cc + 2] = v;
     }
   };
@@ -427,9 +408,11 @@ __global__ void __launch_bounds__(BX *BY, 4) k_correct_residual(Res2Args p) {
         re += DIVC(DIVC(e1 - a1se, D, rD) - DIVC(a1ne - e1, D, rD), D, rD);
         ro += DIVC(DIVC(o1 - e1, D, rD) - DIVC(a1ee - o1, D, rD), D, rD);
         ro += DIVC(DIVC(o1 - a1so, D, rD) - DIVC(a1no - o1, D, rD), D, rD);
-        *reinterpret_cast<double2 *>(p.a_out + cl) = make_double2(e1, o1);
-        nat_write_ghosts(p.a_out, p.g, l, j, i, e1, p.walls);
-        nat_write_ghosts(p.a_out, p.g, l, j, i + 1, o1, p.walls);
+        if (CORR) {
+          *reinterpret_cast<double2 *>(p.a_out + cl) = make_double2(e1, o1);
+          nat_write_ghosts(p.a_out, p.g, l, j, i, e1, p.walls);
+          nat_write_ghosts(p.a_out, p.g, l, j, i + 1, o1, p.walls);
+        }
         m = fmax(m, fmax(fabs(re), fabs(ro)));
         // face velocities of the corrected psi (comp_vel, msqg/qg.h:276-283): west and south faces of both cells
         const double nw = T[b][r + 1][cx - 1], sw = T[b][r - 1][cx - 1], se2 = T[b][r - 1][cx + 2];
@@ -508,8 +491,8 @@ void launch_residual2(hipStream_t st, int mode, const double *a, const double *d
     case 1:
       if (g.nx % 2 == 0 && g.nx >= CR_TW && g.ny >= CR_TR && !(p.dbg & 128)) {
         gr = dim3((g.nx + CR_TW - 1) / CR_TW, (g.ny + CR_TR - 1) / CR_TR);
-        if (uniformS) hipLaunchKernelGGL(k_correct_residual<true>, gr, block2d(), 0, st, p);
-        else hipLaunchKernelGGL(k_correct_residual<false>, gr, block2d(), 0, st, p);
+        if (uniformS) hipLaunchKernelGGL((k_correct_residual<true, true>), gr, block2d(), 0, st, p);
+        else hipLaunchKernelGGL((k_correct_residual<false, true>), gr, block2d(), 0, st, p);
       } else
         hipLaunchKernelGGL((k_residual2<true, false, false>), gr, block2d(), 0, st, p);
       (void)hipMemsetAsync(umax_out, 0, nl * sizeof(double), st);
@@ -518,6 +501,16 @@ void launch_residual2(hipStream_t st, int mode, const double *a, const double *d
     case 2: hipLaunchKernelGGL((k_residual2<false, true, false>), gr, block2d(), 0, st, p); break;
     case 6: hipLaunchKernelGGL((k_residual2<false, true, true>), gr, block2d(), 0, st, p); break;
     case 0: hipLaunchKernelGGL((k_residual2<false, false, false>), gr, block2d(), 0, st, p); break;
+    case 8:  // max |res(a)| and max |u(a)| of an a that is already corrected
+      if (g.nx % 2 == 0 && g.nx >= CR_TW && g.ny >= CR_TR && !(p.dbg & 128)) {
+        gr = dim3((g.nx + CR_TW - 1) / CR_TW, (g.ny + CR_TR - 1) / CR_TR);
+        if (uniformS) hipLaunchKernelGGL((k_correct_residual<true, false>), gr, block2d(), 0, st, p);
+        else hipLaunchKernelGGL((k_correct_residual<false, false>), gr, block2d(), 0, st, p);
+      } else
+        hipLaunchKernelGGL((k_residual2<false, false, false, true>), gr, block2d(), 0, st, p);
+      (void)hipMemsetAsync(umax_out, 0, nl * sizeof(double), st);
+      hipLaunchKernelGGL(k_max_final_mg, dim3(64), dim3(256), 0, st, umax_partial, umax_out, (int)(gr.x * gr.y), nl);
+      break;
     default: break;
   }
 }

@@ -41,6 +41,34 @@ __device__ __forceinline__ void split_write_ghosts(double *f, const SplitGeom &g
   if (e && n) f[split_idx(g, l, g.ny, g.nx)] = v;
 }
 
+// the same for a field in the natural layout
+__device__ __forceinline__ void nat_write_ghosts(double *f, const NatGeom &g, int l, int j, int i, double v, int walls) {
+  if (walls & WALL_PER) {
+    const bool w = i == 0, e = i == g.nx - 1, s = j == 0, n = j == g.ny - 1;
+    if (!(w | e | s | n)) return;
+    if (w) f[nat_idx(g, l, j, g.nx)] = v;
+    if (e) f[nat_idx(g, l, j, -1)] = v;
+    if (s) f[nat_idx(g, l, g.ny, i)] = v;
+    if (n) f[nat_idx(g, l, -1, i)] = v;
+    if (w && s) f[nat_idx(g, l, g.ny, g.nx)] = v;
+    if (w && n) f[nat_idx(g, l, -1, g.nx)] = v;
+    if (e && s) f[nat_idx(g, l, g.ny, -1)] = v;
+    if (e && n) f[nat_idx(g, l, -1, -1)] = v;
+    return;
+  }
+  const bool w = i == 0 && (walls & WALL_W), e = i == g.nx - 1 && (walls & WALL_E);
+  const bool s = j == 0 && (walls & WALL_S), n = j == g.ny - 1 && (walls & WALL_N);
+  if (!(w | e | s | n)) return;
+  if (w) f[nat_idx(g, l, j, -1)] = -v;
+  if (e) f[nat_idx(g, l, j, g.nx)] = -v;
+  if (s) f[nat_idx(g, l, -1, i)] = -v;
+  if (n) f[nat_idx(g, l, g.ny, i)] = -v;
+  if (w && s) f[nat_idx(g, l, -1, -1)] = v;
+  if (w && n) f[nat_idx(g, l, g.ny, -1)] = v;
+  if (e && s) f[nat_idx(g, l, -1, g.nx)] = v;
+  if (e && n) f[nat_idx(g, l, g.ny, g.nx)] = v;
+}
+
 // XCD-aware block numbering.  Workgroups are dealt round-robin over the 8 XCDs (linear ids b and b + 8 share an L2), so
 // neighbouring strips of a row-major grid land on 8 different L2s and each of them fetches the cache lines the strips
 // share (halo columns, partial 128-B lines at unaligned strip edges).  This renumbering gives every XCD one contiguous

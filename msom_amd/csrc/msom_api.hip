@@ -103,6 +103,8 @@ struct msom {
   int block_sweeps = 0;  // experimental temporally blocked smoother (2 sweeps per pass); measured not faster at nl = 6
   int march = 1;         // chained half-sweeps in register windows (kernels_march.hip) on wide single-GPU levels
   int march_k = 4;       // at most this many half-sweeps per pass (2..4)
+  int march_correct = 0; // the last pass of the finest level writes psi + da instead of da; measured neutral (the pass runs at 4.3 TB/s, the post-cycle pass it relieves at 5.8): off
+  int corr_req = 0, corr_done = 0;  // set around mg_cycle_levels by mg_solve / by the pass that did it
   int march_prolong = 0; // whole levels: prolongation folded into the first pass (4 + 4 half-sweeps); measured 3 % slower than (red + prolongation) + 4 + 3
   int mg_fused = 1;  // fused residual+restriction and correction+residual passes of the multigrid cycle
   double *psi_alt = nullptr;  // second psi buffer (the fused correction writes out of place)
@@ -607,6 +609,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "march")) m->march = (int)v;
   else if (!strcmp(key, "march_rows")) g_march_rows = (int)v;
   else if (!strcmp(key, "march_prolong")) m->march_prolong = (int)v;
+  else if (!strcmp(key, "march_correct")) m->march_correct = (int)v;
   else if (!strcmp(key, "march_xcd")) { extern int g_march_remap; g_march_remap = (int)v; }
   else if (!strcmp(key, "march_k")) m->march_k = (int)v < 2 ? 2 : ((int)v > 4 ? 4 : (int)v);
   else if (!strcmp(key, "block_sweeps")) { m->block_sweeps = (int)v; if (m->const_set) return build_coefs(m); }
@@ -1050,11 +1053,17 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
       int K = n < kmax ? n : kmax;
       if (n - K == 1 && K > 2) K--;
       if (L.tiled) STICKY(m, exch_split_deep(m, *L.da, *L.sg, m->mh_da_s[L.k], m->mh_da_n[L.k], hg, nl));
+      // the very last pass of the finest level can apply the correction itself: psi_alt = psi + da (mg_solve swaps)
+      const bool corr = m->corr_req && L.fine && n == K;
+      MarchCorrect mc{m->f[MSOM_PSI], m->psi_alt, m->g};
       if (prof) prof_begin(m, m->prof_march[K]);
-      if (launch_relax_march(m->st, *L.da, *L.da_alt, L.res, *L.sg, nl, *L.rc, c, K, L.walls, g_march_rows, L.tiled ? &mh : nullptr)) m->sticky = MSOM_ERR_ARG;
+      if (launch_relax_march(m->st, *L.da, *L.da_alt, L.res, *L.sg, nl, *L.rc, c, K, L.walls, g_march_rows, L.tiled ? &mh : nullptr, nullptr, nullptr,
+                             corr ? &mc : nullptr))
+        m->sticky = MSOM_ERR_ARG;
       if (prof) prof_end(m, m->prof_march[K]);
-      std::swap(*L.da, *L.da_alt);
       n -= K; c = (c + K) & 1;
+      if (corr) { m->corr_done = 1; return; }  // da of this level was consumed in registers; nothing reads it any more
+      std::swap(*L.da, *L.da_alt);
     }
     if (n == 1) {
       if (L.tiled) STICKY(m, exch_split(m, *L.da, *L.sg, nl, 0));
@@ -1215,9 +1224,17 @@ static int mg_solve(msom *m, const double *b, msom_mgstats *s) {
     have_first = true;
   }
   for (s->i = 0; s->i < p.nitermax && (s->i < p.nitermin || s->resa > p.tolerance); s->i++) {
+    m->corr_req = fused && m->march_correct;
+    m->corr_done = 0;
     mg_cycle_levels(m, s->nrelax, fused ? 2 : 1);
+    m->corr_req = 0;
     HIPCHK(hipMemsetAsync(m->d_scal + SC_RES1, 0, sizeof(double), m->st));
-    if (fused) {
+    if (m->corr_done) {  // a_new = a + da already sits in psi_alt (last smoother pass): boundary(a), then max |res|, max |u|
+      std::swap(m->f[MSOM_PSI], m->psi_alt);
+      if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], m->nl, m->bc, 1));
+      residual2(m, 8, b, SC_RES1, 0);
+      m->umax_ready = 1;
+    } else if (fused) {
       residual2(m, 1, b, SC_RES1, 0);            // a_new = a + da -> psi_alt, max |res(a_new)|, max |u(a_new)|
       std::swap(m->f[MSOM_PSI], m->psi_alt);
       m->umax_ready = 1;
