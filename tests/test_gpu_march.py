@@ -48,14 +48,14 @@ def test_march_equals_half_sweep_per_launch(nx, ny, nl, strict):
 
 
 @pytest.mark.parametrize("k,rows", [(2, 0), (3, 0), (4, 0), (4, 32), (3, 48), (4, 16), (2, 80)])
-@pytest.mark.parametrize("prolong", [0, 1])
+@pytest.mark.parametrize("prolong", [0, 1, 2])
 def test_march_pass_lengths_and_chunk_heights(k, rows, prolong):
     """the result depends neither on how the 2 nrelax half-sweeps are cut into passes, nor on whether the prolongation
     rides in the first pass (march_prolong) or in a red half-sweep of its own, nor on the chunk height"""
     nx, ny, nl = 512, 128, 3
     txt = orc.double_gyre_params(nx, nl, extra=f"Ny = {ny}\n" + SLIP)
     a = run(txt, True, nl, ny, nx, march=0)
-    b = run(txt, True, nl, ny, nx, march=2, march_k=k, march_rows=rows, march_prolong=prolong)
+    b = run(txt, True, nl, ny, nx, march=2, march_k=k, march_rows=rows, march_prolong=prolong & 1, march_correct=prolong >> 1)   # 2: correction folded into the last pass
     assert np.array_equal(a[0], b[0]) and a[2] == b[2]
 
 
