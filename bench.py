@@ -209,7 +209,7 @@ def main():
             K, launch_ms, launches = (4, m4_ms, m4_n) if m4_n > 0 else (3, m3_ms, m3_n)   # the longer pass where both run
             launch_bytes = plain_bytes * K
             pass_bytes = 2.5 * w
-            kernel = f"k_relax_march<{nl}, {K}> (finest level: {K} chained red-black colour half-sweeps = {K / 2:g} sweeps per pass, intermediate values in registers)"
+            kernel = f"k_relax_march<{nl}, {K}, false, false> (finest level: {K} chained red-black colour half-sweeps = {K / 2:g} sweeps per pass, intermediate values in registers)"
             pmc_file = "r01_pmc_traffic_march.json"
         else:
             K, launch_bytes, launch_ms, launches = 1, plain_bytes, sweep_ms / 2.0, 2 * sweep_n
