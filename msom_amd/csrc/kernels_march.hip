@@ -299,13 +299,14 @@ int launch_relax_march(hipStream_t st, const double *in, double *out, const doub
   extern int g_march_remap;
   a.in = in; a.out = out; a.res = res; a.g = sg; a.c1 = c1; a.walls = walls; a.rc = rc; a.remap = g_march_remap;
   int H = chunk_rows;
-  if (H <= 0) {  // >= 2048 independent wavefronts where the level allows, chunks tall enough for the 2 K re-computed rows
-    // one round of at most 2048 independent wavefronts (8 per CU at <= 256 VGPRs), chunks tall enough for the 2 K
-    // re-computed rows
-    const int strips = (sg.hk + 59) / 60, want = 2048 / strips > 0 ? 2048 / strips : 1;
+  if (H <= 0) {
+    // about 6000 independent wavefronts (three rounds at 8 per CU) where the level allows, chunks of at least 24 rows
+    // (2 K re-computed rows each).  Measured at 4096^2 x 6 inside the step: 24-row chunks 7.81-7.93 ms/step, one round
+    // of 72-row chunks 7.95-8.04, 64-row chunks 8.5 (rounds of equal-length workgroups that march in step)
+    const int strips = (sg.hk + 59) / 60, want = 6144 / strips > 0 ? 6144 / strips : 1;
     H = (sg.ny + want - 1) / want;
     H = ((H + 7) / 8) * 8;
-    if (H < 16) H = 16;
+    if (H < 24) H = 24;
   }
   a.H = H;
   if (nl >= 7 && K > 3) return -1;  // 4 windows of 7 or 8 layers do not fit 256 VGPRs
