@@ -103,6 +103,7 @@ struct msom {
   int block_sweeps = 0;  // experimental temporally blocked smoother (2 sweeps per pass); measured not faster at nl = 6
   int march = 1;         // chained half-sweeps in register windows (kernels_march.hip) on wide single-GPU levels
   int march_k = 4;       // at most this many half-sweeps per pass (2..4)
+  int march_min = 24;    // log2 of the cell-layers a level needs for the chained pass
   int march_correct = 0; // the last pass of the finest level writes psi + da instead of da; measured neutral (the pass runs at 4.3 TB/s, the post-cycle pass it relieves at 5.8): off
   int corr_req = 0, corr_done = 0;  // set around mg_cycle_levels by mg_solve / by the pass that did it
   int march_prolong = 0; // whole levels: prolongation folded into the first pass (4 + 4 half-sweeps); measured 3 % slower than (red + prolongation) + 4 + 3
@@ -608,6 +609,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "mg_fused")) m->mg_fused = (int)v;
   else if (!strcmp(key, "march")) m->march = (int)v;
   else if (!strcmp(key, "march_rows")) g_march_rows = (int)v;
+  else if (!strcmp(key, "march_min")) m->march_min = (int)v;
   else if (!strcmp(key, "march_prolong")) m->march_prolong = (int)v;
   else if (!strcmp(key, "march_correct")) m->march_correct = (int)v;
   else if (!strcmp(key, "march_xcd")) { extern int g_march_remap; g_march_remap = (int)v; }
@@ -995,7 +997,7 @@ static bool march_ok(msom *m, const Lev &L) {
   if (!m->march || m->block_sweeps || !m->uniformS || m->nl < 2 || (m->walls & WALL_PER) || (!L.tiled && L.walls != WALL_ALL) || L.sg->nx < 512 ||
       L.sg->ny < 64)
     return false;
-  return m->march >= 2 || (size_t)L.sg->nx * L.sg->ny * m->nl >= ((size_t)1 << 24);
+  return m->march >= 2 || (size_t)L.sg->nx * L.sg->ny * m->nl >= ((size_t)1 << m->march_min);
 }
 // is the prolongation coarse -> L folded into the first smoothing pass of L?
 static bool fuse_prolong(msom *m, const Lev &L, int nrelax) {
