@@ -83,3 +83,41 @@ def test_march_off_where_it_does_not_apply():
     a = run(txt, True, nl, ny, nx, march=0, uniform_S=0)
     b = run(txt, True, nl, ny, nx, march=2, uniform_S=0)
     assert np.array_equal(a[0], b[0])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_product_build_vs_oracle(seed):
+    """differential test of the product build's default kernels (chained smoother forced on, one-layer-per-wavefront
+    tendency kernel) against the CPU oracle over random parameter combinations (layers, aspect ratio, partial slip, both
+    viscosities, drag, 3-D forcing): two RK2 steps at TOLERANCE 1e-11, <= 1e-9 relative on psi and q"""
+    rng = np.random.default_rng(4000 + seed)
+    nl = int(rng.choice([2, 3, 4, 6]))
+    nx, ny = [(512, 64), (512, 128), (1024, 64)][int(rng.integers(3))]
+    extra = f"Ny = {ny}\n"
+    if rng.random() < 0.5:
+        extra += f"sbc = {rng.choice([0.5, 2.0, 100.0])}\n"
+    if rng.random() < 0.5:
+        extra += f"Re = {rng.choice([200.0, 1500.0])}\n"
+    if rng.random() < 0.3:
+        extra += "Re4 = 0\n"
+    if rng.random() < 0.5:
+        extra += f"Eks = {rng.choice([0.001, 0.01])}\n"
+    txt = orc.double_gyre_params(nx, nl, extra=extra)
+    o = orc.Oracle(txt, smoother=orc.GS_RB, quiet=1)
+    g = QG(txt)
+    g.option("quiet", 1); g.option("march", 2)
+    for h in (o, g):
+        h.option("TOLERANCE", 1e-11)
+    p0 = orc.synthetic_psi(nl, ny, nx)
+    o.set(orc.PSI, p0); g.set(F["PSI"], p0)
+    if rng.random() < 0.5:
+        qf = 1e-6 * rng.standard_normal((nl, ny, nx))
+        o.set(orc.QFORC, qf); g.set(F["QFORC"], qf)
+    o.set_const(); g.set_const()
+    assert g.param("uniform_S") == 1.0
+    for _ in range(2):
+        o.step(); g.step()
+    desc = f"nl={nl} {nx}x{ny} {extra!r}"
+    assert g.t == pytest.approx(o.t, rel=1e-12), desc
+    assert rel(g.get(F["PSI"]), o.get(orc.PSI)) <= 1e-9, desc
+    assert rel(g.get(F["Q"]), o.get(orc.Q)) <= 1e-9, desc
