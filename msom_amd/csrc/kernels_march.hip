@@ -40,7 +40,7 @@ struct MarchArgs {
   NatGeom ng;
   SplitGeom g;
   int c1;  // colour of the first half-sweep (0 red, 1 black)
-  int walls, H, remap;
+  int walls, H, remap, flip;
   RelaxCoef rc;
 };
 
@@ -57,6 +57,12 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
   const int kx = (int)bx * OW - HL + lane;
   const int y0 = by * p.H, y1 = min(p.g.ny, y0 + p.H);
   const int hk = p.g.hk, ny = p.g.ny, hp = p.g.hp;
+  // Odd chunks march DOWN.  A colour half-sweep does not depend on the order of its cells, so the direction changes
+  // nothing in the result; but two vertically adjacent chunks now reach their common edge at the same time (both at
+  // their start or both at their end), so the 2 K rows they both read there are one HBM read and one L2 hit instead of
+  // two HBM reads 24 rows apart.  `ph` maps the marching coordinate t (chunk-local, as if marching up) to the row.
+  const bool down = p.flip && (by & 1);
+  auto ph = [&](int t) -> int { return down ? y0 + y1 - 1 - t : t; };
   const ptrdiff_t rp = p.g.rp;
   const size_t ls = p.g.ls;
   const int kxc = min(max(kx, -2), hk + 1);  // stays inside the padded half row
@@ -126,7 +132,7 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
   // rows y0 - K and y0 - K + 1 of the input fill the first window before half-sweep 1 starts at row y0 - K + 1
 #pragma unroll
   for (int q = 0; q < 2; q++) {
-    const int r = y0 - K + q;
+    const int r = ph(y0 - K + q);
     if (PL) prolong_row(r, (r + c0) & 1, W[0][q + 1]);
     else {
       size_t st;
@@ -149,38 +155,41 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
     }
     {
       size_t s0 = 0, s1, s2;
-      const double *src = PL ? p.res : rowsrc(p.in, p.in_s, p.in_n, (t + 1 + c0) & 1, t + 1, s0);
+      const int rn = ph(t + 1), ra = ph(t), rb = ph(t - 1);   // rows of the new input row and of half-sweeps 1 and 2
+      const double *src = PL ? p.res : rowsrc(p.in, p.in_s, p.in_n, (rn + c0) & 1, rn, s0);
       // residual rows: beyond a wall they are never used (clamped), beyond a tile edge they come from the halo arrays
-      const int t1 = (t < 0 && !p.res_s) ? 0 : ((t >= ny && !p.res_n) ? ny - 1 : t);
-      const int t2 = (t - 1 < 0 && !p.res_s) ? 0 : ((t - 1 >= ny && !p.res_n) ? ny - 1 : t - 1);
-      const double *r1 = rowsrc(p.res, p.res_s, p.res_n, (t + p.c1) & 1, t1, s1);           // colour c1, row t
-      const double *r2 = rowsrc(p.res, p.res_s, p.res_n, (t - 1 + c0) & 1, t2, s2);         // colour c0, row t - 1
+      const int t1 = (ra < 0 && !p.res_s) ? 0 : ((ra >= ny && !p.res_n) ? ny - 1 : ra);
+      const int t2 = (rb < 0 && !p.res_s) ? 0 : ((rb >= ny && !p.res_n) ? ny - 1 : rb);
+      const double *r1 = rowsrc(p.res, p.res_s, p.res_n, (ra + p.c1) & 1, t1, s1);           // colour c1, row of half-sweep 1
+      const double *r2 = rowsrc(p.res, p.res_s, p.res_n, (rb + c0) & 1, t2, s2);             // colour c0, row of half-sweep 2
 #pragma unroll
       for (int l = 0; l < NL; l++) {
         if (!PL) W[0][2][l] = src[l * s0];
         R1[0][l] = r1[l * s1]; R2[0][l] = r2[l * s2];
       }
-      if (PL) prolong_row(t + 1, (t + 1 + c0) & 1, W[0][2]);
+      if (PL) prolong_row(ph(t + 1), (ph(t + 1) + c0) & 1, W[0][2]);
     }
     // CORR: psi of the row the last half-sweep finishes in this step, requested before the chain of half-sweeps
     double2 pa[CORR ? NL : 1];
     if (CORR) {
-      const int rk = min(max(t - (K - 1), 0), ny - 1);
+      const int rk = min(max(ph(t - (K - 1)), 0), ny - 1);
       const double *ps = p.psi + nat_idx(p.ng, 0, rk, 2 * min(max(kx, 0), hk - 1));
 #pragma unroll
       for (int l = 0; l < NL; l++) pa[l] = *reinterpret_cast<const double2 *>(ps + l * p.ng.ls);
     }
 #pragma unroll
     for (int s = 1; s <= K; s++) {
-      const int r = t - (s - 1);                 // row of half-sweep s
+      const int r = ph(t - (s - 1));             // row of half-sweep s
       const int px = (r + p.c1 + s - 1) & 1;     // x parity (= half) of its cells in that row
       double x[NL];
-      if (wallS && r == -1) {                    // ghost row: -(wall row after the previous half-sweep)
+      // ghost row: -(wall row after the previous half-sweep); that row is the next one of the window when the chunk
+      // marches towards it, the previous one otherwise
+      if (wallS && r == -1) {
 #pragma unroll
-        for (int l = 0; l < NL; l++) x[l] = -W[s - 1][2][l];
+        for (int l = 0; l < NL; l++) x[l] = -W[s - 1][down ? 0 : 2][l];
       } else if (wallN && r == ny) {
 #pragma unroll
-        for (int l = 0; l < NL; l++) x[l] = -W[s - 1][0][l];
+        for (int l = 0; l < NL; l++) x[l] = -W[s - 1][down ? 2 : 0][l];
       } else {
         double rhs[NL], rs[NL];
 #pragma unroll
@@ -261,6 +270,7 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
 }
 
 int g_march_remap = 1;  // XCD-contiguous block numbering (option march_xcd)
+int g_march_flip = 1;   // odd chunks march down (option march_flip)
 
 template <int NL>
 static int march_dispatch(hipStream_t st, const MarchArgs &a, int K) {
@@ -297,7 +307,8 @@ int launch_relax_march(hipStream_t st, const double *in, double *out, const doub
   a.in_s = h ? h->in_s : nullptr; a.in_n = h ? h->in_n : nullptr; a.res_s = h ? h->res_s : nullptr; a.res_n = h ? h->res_n : nullptr;
   a.hls = h ? h->ls : 0; a.KR = h ? h->rows : 0;
   extern int g_march_remap;
-  a.in = in; a.out = out; a.res = res; a.g = sg; a.c1 = c1; a.walls = walls; a.rc = rc; a.remap = g_march_remap;
+  extern int g_march_flip;
+  a.in = in; a.out = out; a.res = res; a.g = sg; a.c1 = c1; a.walls = walls; a.rc = rc; a.remap = g_march_remap; a.flip = g_march_flip;
   int H = chunk_rows;
   if (H <= 0) {
     // about 6000 independent wavefronts (three rounds at 8 per CU) where the level allows, chunks of at least 24 rows

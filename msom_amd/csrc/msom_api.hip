@@ -613,6 +613,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "march_prolong")) m->march_prolong = (int)v;
   else if (!strcmp(key, "march_correct")) m->march_correct = (int)v;
   else if (!strcmp(key, "march_xcd")) { extern int g_march_remap; g_march_remap = (int)v; }
+  else if (!strcmp(key, "march_flip")) { extern int g_march_flip; g_march_flip = (int)v; }
   else if (!strcmp(key, "march_k")) m->march_k = (int)v < 2 ? 2 : ((int)v > 4 ? 4 : (int)v);
   else if (!strcmp(key, "block_sweeps")) { m->block_sweeps = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "mg_global_sum")) m->mg_global_sum = (int)v;
