@@ -97,7 +97,7 @@ int msom_destroy(msom_t *m);
  * residual/restriction and correction/residual passes, "prolong_fused" [1], "mg_coarse" [1] coarse levels
  * in one launch, "march" [1] chained half-sweep smoother on HBM-bound single-GPU levels (2: on every level that is
  * wide enough), "march_k" [4] half-sweeps per pass, "march_rows" [0 = auto] chunk height, "march_min" [24] log2 of the cell-layers a level needs, "march_prolong" [0] prolongation folded
- * into the first pass, "march_correct" [0] correction folded into the last pass, "march_xcd" [1] XCD-contiguous block numbering, "block_sweeps" [0] LDS-tiled blocked smoother, "agglomerate" [1] / "agg_size" [256]
+ * into the first pass, "march_correct" [0] correction folded into the last pass, "march_xcd" [1] XCD-contiguous block numbering, "march_flip" [1] odd chunks march downwards, "block_sweeps" [0] LDS-tiled blocked smoother, "agglomerate" [1] / "agg_size" [256]
  * gathered coarse levels of tiled runs, "mg_global_sum" [0]; "rhs_dbg", "block_variant": timing
  * experiments of tools/. */
 int msom_set_option(msom_t *m, const char *key, double value);
