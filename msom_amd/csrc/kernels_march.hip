@@ -272,24 +272,63 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
 int g_march_remap = 1;  // XCD-contiguous block numbering (option march_xcd)
 int g_march_flip = 1;   // odd chunks march down (option march_flip)
 
+// Chunk height.  All workgroups of a pass take the same time, so the pass ends with an idle tail unless their number
+// is close to a whole number of rounds (resident wavefronts per CU x CUs, from the occupancy calculator for the
+// instantiation at hand).  Measured at 4096^2 x 6, K = 4 (2048 resident): 24 rows = 2.92 rounds 0.440 ms, 36 rows = 1.95
+// rounds 0.453, 72 rows = 0.97 rounds 0.474, but 28 rows = 2.51 rounds 0.469, 44 rows = 1.6 rounds 0.485, 56 rows = 1.26
+// rounds 0.55.  Rule: the largest whole number of rounds (<= 3) whose chunks still have >= 20 rows (2 K of them are
+// re-computed), at least one round; never below 16 rows.
+template <typename Kern>
+static void march_launch(hipStream_t st, Kern kern, MarchArgs a, int ow, int chunk_rows) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  const int strips = (a.g.hk + ow - 1) / ow;
+  int H = chunk_rows;
+  if (H <= 0) {
+    static const void *seen[64];
+    static int seen_n[64], nseen = 0;  // occupancy per instantiation, asked once (host threads of tiled tests: benign race, same value)
+    int per_cu = 0;
+    for (int q = 0; q < nseen; q++)
+      if (seen[q] == (const void *)kern) per_cu = seen_n[q];
+    if (!per_cu) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+      if (nseen < 64) { seen[nseen] = (const void *)kern; seen_n[nseen] = per_cu; nseen++; }
+    }
+    const int slots = per_cu * ncu;
+    H = 0;
+    for (int m = 3; m >= 1 && !H; m--) {
+      const int chunks = m * slots / strips;
+      if (chunks < 1) continue;
+      const int h = (a.g.ny + chunks - 1) / chunks;
+      if (h >= 20 || m == 1) H = h;
+    }
+    if (H < 16) H = 16;
+  }
+  a.H = H;
+  hipLaunchKernelGGL(kern, dim3(strips, (a.g.ny + H - 1) / H), dim3(64), 0, st, a);
+}
+
 template <int NL>
-static int march_dispatch(hipStream_t st, const MarchArgs &a, int K) {
-  const int hk = a.g.hk;
-  auto grid = [&](int ow) { return dim3((hk + ow - 1) / ow, (a.g.ny + a.H - 1) / a.H); };
+static int march_dispatch(hipStream_t st, const MarchArgs &a, int K, int rows) {
   switch (K) {
     case 2:
-      if (a.psi_out) hipLaunchKernelGGL((k_relax_march<NL, 2, false, true>), grid(62), dim3(64), 0, st, a);
-      else hipLaunchKernelGGL((k_relax_march<NL, 2, false, false>), grid(62), dim3(64), 0, st, a);
+      if (a.psi_out) march_launch(st, k_relax_march<NL, 2, false, true>, a, 62, rows);
+      else march_launch(st, k_relax_march<NL, 2, false, false>, a, 62, rows);
       return 0;
     case 3:
-      if (a.coarse) hipLaunchKernelGGL((k_relax_march<NL, 3, true, false>), grid(60), dim3(64), 0, st, a);
-      else if (a.psi_out) hipLaunchKernelGGL((k_relax_march<NL, 3, false, true>), grid(60), dim3(64), 0, st, a);
-      else hipLaunchKernelGGL((k_relax_march<NL, 3, false, false>), grid(60), dim3(64), 0, st, a);
+      if (a.coarse) march_launch(st, k_relax_march<NL, 3, true, false>, a, 60, rows);
+      else if (a.psi_out) march_launch(st, k_relax_march<NL, 3, false, true>, a, 60, rows);
+      else march_launch(st, k_relax_march<NL, 3, false, false>, a, 60, rows);
       return 0;
     case 4:
-      if (a.coarse) hipLaunchKernelGGL((k_relax_march<NL, 4, true, false>), grid(58), dim3(64), 0, st, a);
-      else if (a.psi_out) hipLaunchKernelGGL((k_relax_march<NL, 4, false, true>), grid(60), dim3(64), 0, st, a);
-      else hipLaunchKernelGGL((k_relax_march<NL, 4, false, false>), grid(60), dim3(64), 0, st, a);
+      if (a.coarse) march_launch(st, k_relax_march<NL, 4, true, false>, a, 58, rows);
+      else if (a.psi_out) march_launch(st, k_relax_march<NL, 4, false, true>, a, 60, rows);
+      else march_launch(st, k_relax_march<NL, 4, false, false>, a, 60, rows);
       return 0;
   }
   return -1;
@@ -309,26 +348,15 @@ int launch_relax_march(hipStream_t st, const double *in, double *out, const doub
   extern int g_march_remap;
   extern int g_march_flip;
   a.in = in; a.out = out; a.res = res; a.g = sg; a.c1 = c1; a.walls = walls; a.rc = rc; a.remap = g_march_remap; a.flip = g_march_flip;
-  int H = chunk_rows;
-  if (H <= 0) {
-    // about 6000 independent wavefronts (three rounds at 8 per CU) where the level allows, chunks of at least 24 rows
-    // (2 K re-computed rows each).  Measured at 4096^2 x 6 inside the step: 24-row chunks 7.81-7.93 ms/step, one round
-    // of 72-row chunks 7.95-8.04, 64-row chunks 8.5 (rounds of equal-length workgroups that march in step)
-    const int strips = (sg.hk + 59) / 60, want = 6144 / strips > 0 ? 6144 / strips : 1;
-    H = (sg.ny + want - 1) / want;
-    H = ((H + 7) / 8) * 8;
-    if (H < 24) H = 24;
-  }
-  a.H = H;
   if (nl >= 7 && K > 3) return -1;  // 4 windows of 7 or 8 layers do not fit 256 VGPRs
   switch (nl) {
-    case 2: return march_dispatch<2>(st, a, K);
-    case 3: return march_dispatch<3>(st, a, K);
-    case 4: return march_dispatch<4>(st, a, K);
-    case 5: return march_dispatch<5>(st, a, K);
-    case 6: return march_dispatch<6>(st, a, K);
-    case 7: return march_dispatch<7>(st, a, K);
-    case 8: return march_dispatch<8>(st, a, K);
+    case 2: return march_dispatch<2>(st, a, K, chunk_rows);
+    case 3: return march_dispatch<3>(st, a, K, chunk_rows);
+    case 4: return march_dispatch<4>(st, a, K, chunk_rows);
+    case 5: return march_dispatch<5>(st, a, K, chunk_rows);
+    case 6: return march_dispatch<6>(st, a, K, chunk_rows);
+    case 7: return march_dispatch<7>(st, a, K, chunk_rows);
+    case 8: return march_dispatch<8>(st, a, K, chunk_rows);
   }
   return -1;
 }
