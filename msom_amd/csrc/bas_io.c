@@ -55,9 +55,14 @@ int msom_bas_read(const char *path, double *a, int nl, int n, double L0) {
     float width;
     if (fread(&width, sizeof(float), 1, fp) != 1) goto shortread;
     const int m = (int)width;
-    if (m <= 0) goto shortread;
+    if (m <= 0 || m > (1 << 16) || (float)m != width) goto shortread; /* the frame size comes from the file: bound it */
     const size_t m1 = (size_t)m + 1;
     float *frame = (float *)malloc(m1 * m1 * sizeof(float));
+    if (!frame) {
+      fclose(fp);
+      msom_set_error("out of memory reading %s (frame %d)", path, m);
+      return -2;
+    }
     /* rest of the first row, then m full rows */
     if (fread(frame + 1, sizeof(float), m1 * m1 - 1, fp) != m1 * m1 - 1) {
       free(frame);

@@ -282,21 +282,24 @@ int comm_exchange(Comm *c, const Xfer *x, int nx) {
   h->posted[c->rank] = x;
   h->posted_n[c->rank] = nx;
   h->barrier();
-  for (int k = 0; k < nx; k++) {
+  int err = MSOM_OK;  // an error must not skip the closing barrier: the other tile threads are waiting in it
+  for (int k = 0; k < nx && !err; k++) {
     const Xfer *px = h->posted[x[k].peer];
     const int pn = h->posted_n[x[k].peer];
     const Xfer *src = nullptr;
     for (int q = 0; q < pn; q++)
       if (px[q].peer == c->rank && px[q].tag == x[k].tag) src = &px[q];
-    if (!src || src->count != x[k].count) {
+    if (!src || src->count != x[k].count || x[k].count > c->bufcount) {
       msom_set_error("local exchange: no matching message from rank %d tag %d", x[k].peer, x[k].tag);
-      return MSOM_ERR_COMM;
+      err = MSOM_ERR_COMM;
+    } else if (hipMemcpyAsync(x[k].recv, src->send, x[k].count * sizeof(double), hipMemcpyDeviceToDevice, c->st) != hipSuccess) {
+      msom_set_error("local exchange: device copy failed");
+      err = MSOM_ERR_HIP;
     }
-    HIPCHKC(hipMemcpyAsync(x[k].recv, src->send, x[k].count * sizeof(double), hipMemcpyDeviceToDevice, c->st));
   }
-  HIPCHKC(hipStreamSynchronize(c->st));
+  if (hipStreamSynchronize(c->st) != hipSuccess && !err) err = MSOM_ERR_HIP;
   h->barrier();  // nobody re-packs a send buffer before every reader is done
-  return MSOM_OK;
+  return err;
 }
 
 // in-place all-reduce of n doubles in device memory; result also copied to host `hout`

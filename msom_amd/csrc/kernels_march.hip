@@ -18,6 +18,9 @@
 //  * out of place (in -> out): a chunk re-computes K rows of its neighbours (cone of dependence), which those
 //    neighbours overwrite; lanes: 2 x ceil(K/2) halo lanes of 64.
 // Used on one GPU (no halo exchange between half-sweeps), walls (not the periodic domain), uniform S, nl >= 2.
+#include <map>
+#include <mutex>
+#include <utility>
 #include "mg_inl.h"
 #include "rhs_inl.h"
 
@@ -280,24 +283,28 @@ int g_march_flip = 1;   // odd chunks march down (option march_flip)
 // re-computed), at least one round; never below 16 rows.
 template <typename Kern>
 static void march_launch(hipStream_t st, Kern kern, MarchArgs a, int ow, int chunk_rows) {
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-    if (ncu <= 0) ncu = 256;
-  }
   const int strips = (a.g.hk + ow - 1) / ow;
   int H = chunk_rows;
   if (H <= 0) {
-    static const void *seen[64];
-    static int seen_n[64], nseen = 0;  // occupancy per instantiation, asked once (host threads of tiled tests: benign race, same value)
-    int per_cu = 0;
-    for (int q = 0; q < nseen; q++)
-      if (seen[q] == (const void *)kern) per_cu = seen_n[q];
-    if (!per_cu) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
-      if (nseen < 64) { seen[nseen] = (const void *)kern; seen_n[nseen] = per_cu; nseen++; }
+    // occupancy per (device, instantiation), asked once; tiled tests drive this from several host threads
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, std::pair<int, int>> cache;  // -> (blocks per CU, CUs)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int per_cu = 0, ncu = 0;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = cache.find({dev, (const void *)kern});
+      if (it == cache.end()) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+        cache[{dev, (const void *)kern}] = {per_cu, ncu};
+      } else {
+        per_cu = it->second.first;
+        ncu = it->second.second;
+      }
     }
     const int slots = per_cu * ncu;
     H = 0;

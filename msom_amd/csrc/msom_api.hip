@@ -231,12 +231,20 @@ static int reduce_scal(msom *m, int slot, int n, int op) {
   return MSOM_OK;
 }
 
+// every message of an exchange must fit the per-direction staging buffers of the communicator
+static bool fits_comm(msom *m, size_t count) {
+  if (count <= comm_bufcount(m->comm)) return true;
+  msom_set_error("halo message of %zu doubles exceeds the communication buffers (%zu)", count, comm_bufcount(m->comm));
+  return false;
+}
+
 // halo exchange of a natural field, `depth` ghost columns/rows, corners included: two phases
 // (x, then y over the x-ghost columns) with the wall BCs applied in between, exactly the
 // order of Basilisk's boundary() (x direction first).
 static int exch_nat(msom *m, double *f, int nl, int bc, int depth) {
   const NatGeom &g = m->g;
   const int d = depth;
+  if (m->nranks > 1 && !fits_comm(m, (size_t)d * ((g.nx > g.ny ? g.nx : g.ny) + 2 * d) * nl)) return MSOM_ERR_ARG;
   hipStream_t cs = m->nranks > 1 ? m->st2 : m->st;  // packs, wall BCs and unpacks ride on the communication stream
   if (m->nranks > 1) comm_begin(m);
   if (m->nranks > 1) {
@@ -281,6 +289,7 @@ static int exch_nat(msom *m, double *f, int nl, int bc, int depth) {
 // everything on the communication stream; the caller orders it against the compute stream
 static int exch_split_raw(msom *m, double *f, const SplitGeom &sg, int nl, int corners) {
   hipStream_t cs = m->st2;
+  if (!fits_comm(m, (size_t)nl * ((sg.nx > sg.ny ? sg.nx : sg.ny) + 2))) return MSOM_ERR_ARG;
   Xfer x[4];
   int n = 0;
   if (!corners) {  // one pack launch, one message per neighbour, one unpack launch
@@ -335,6 +344,7 @@ static int exch_split_deep(msom *m, double *f, const SplitGeom &sg, double *fs, 
   const int H = MARCH_HALO;
   Xfer x[2];
   int n = 0;
+  if (!fits_comm(m, (size_t)H * ((sg.nx > sg.ny ? sg.nx : sg.ny) + 2 * H) * nl)) return MSOM_ERR_ARG;
   comm_begin(m);
   auto pack = [&](int dir, int i0, int j0, int w, int h) {
     launch_split_pack_strip(cs, f, sg, nl, i0, j0, w, h, comm_sendbuf(m->comm, dir));
@@ -518,7 +528,9 @@ static msom *create_common(const Params &p0, int px, int py, int rank, const voi
   }
   if (alloc_all(m) != MSOM_OK ||
       (m->nranks > 1 && comm_create(&m->comm, rank, m->nranks, id128, m->st2,
-                                    (size_t)MARCH_HALO * ((m->nx > m->ny ? m->nx : m->ny) + 16) * m->nl) != MSOM_OK) ||
+                                    // largest message: a MARCH_HALO-deep strip of the widest exchanged field
+                                    // (tracer fields carry nl * nptr layers, fill_bc exchanges them whole)
+                                    (size_t)MARCH_HALO * ((m->nx > m->ny ? m->nx : m->ny) + 16) * m->nl * (p.nptr > 1 ? p.nptr : 1)) != MSOM_OK) ||
       set_vars(m) != MSOM_OK) {
     msom_destroy(m);
     return nullptr;
@@ -670,10 +682,11 @@ extern "C" double msom_get_param(msom_t *m, const char *key) {
   if (!strcmp(key, "nlevels")) return m->nlev;
   if (!strcmp(key, "uniform_S")) return m->uniformS;
   if (!strcmp(key, "agg_level")) return m->agg_level;
-  if (!strncmp(key, "idh0_", 5)) return m->lc.idh0[atoi(key + 5) % MSOM_MAXNL];
-  if (!strncmp(key, "idh1_", 5)) return m->lc.idh1[atoi(key + 5) % MSOM_MAXNL];
-  if (!strncmp(key, "Fr_", 3)) return p.Frm[atoi(key + 3) % MSOM_MAXARR];
-  if (!strncmp(key, "dh_", 3)) return m->dhf[atoi(key + 3) % MSOM_MAXARR];
+  auto idx = [](const char *s, int n) { const int k = atoi(s); return k >= 0 && k < n ? k : -1; };
+  if (!strncmp(key, "idh0_", 5)) { const int k = idx(key + 5, MSOM_MAXNL); return k < 0 ? NAN : m->lc.idh0[k]; }
+  if (!strncmp(key, "idh1_", 5)) { const int k = idx(key + 5, MSOM_MAXNL); return k < 0 ? NAN : m->lc.idh1[k]; }
+  if (!strncmp(key, "Fr_", 3)) { const int k = idx(key + 3, MSOM_MAXARR); return k < 0 ? NAN : p.Frm[k]; }
+  if (!strncmp(key, "dh_", 3)) { const int k = idx(key + 3, MSOM_MAXARR); return k < 0 ? NAN : m->dhf[k]; }
   return NAN;
 }
 
@@ -730,7 +743,9 @@ extern "C" int msom_set_field(msom_t *m, int field, const double *a) {
   if (r) return r;
   if (field == MSOM_RD) m->wv_ready = 0;
   if (field == MSOM_FR || field == MSOM_RO || field == MSOM_S) { m->fr_uniform = 0; m->const_set = 0; }
-  if (field == MSOM_PSIPG) m->have_pg = 1;
+  // the background flow feeds values cached by msom_set_const (max |u_pg| of the dt limiter, zeta_pg when flsrv = 1;
+  // the reference recomputes them on every step, msqg/qg.h:383-391): a new psi_pg needs a new set_const
+  if (field == MSOM_PSIPG) { m->have_pg = 1; m->const_set = 0; }
   if (field == MSOM_ZETAPG) m->have_zpg = 1;
   if (field == MSOM_QFORC) m->have_qforc = 1;
   if (field == MSOM_TOPO) m->flag_topo = 1;

@@ -163,10 +163,12 @@ int msom_nc_read(const char *path, const char *name, int rec, int nl, int ny, in
   NEED(8);
   uint32_t tag = get32(h + p), cnt = get32(h + p + 4); p += 8;
   if (tag == NC_DIMENSION) {
-    for (uint32_t d = 0; d < cnt && d < 64; d++) {
+    for (uint32_t d = 0; d < cnt; d++) {  /* every entry is walked so that the header offset stays right */
       NEED(4); uint32_t n = get32(h + p); p += 4 + ((n + 3) & ~3u);
-      NEED(4); dimlen[ndims] = get32(h + p); p += 4;
-      if (dimlen[ndims] == 0) recdim = ndims;
+      NEED(4); const uint32_t len = get32(h + p); p += 4;
+      if (d >= 64) continue;            /* dimensions beyond the table are skipped, not misparsed */
+      dimlen[ndims] = len;
+      if (len == 0) recdim = ndims;
       ndims++;
     }
   }

@@ -566,7 +566,10 @@ def compare(got, exp, exact=True, rtol=0.0, sum_rtol=1e-12):
                     assert np.array_equal(gi[:, [0, 1, 2, 4]], ei[:, [0, 1, 2, 4]]), k
                 else:
                     assert np.array_equal(gi[:, [0, 4]], ei[:, [0, 4]]), k
-                    assert np.allclose(gi[:, 1:3], ei[:, 1:3], rtol=max(rtol, 1e-6), atol=0), k
+                    # product build: residual before to rounding; the residual after is cancellation noise once the
+                    # solve has converged far below resb, so it is compared relative to resb
+                    assert np.allclose(gi[:, 1], ei[:, 1], rtol=max(rtol, 1e-6), atol=1e-15), k
+                    assert np.all(np.abs(gi[:, 2] - ei[:, 2]) <= 1e-3 * np.abs(ei[:, 2]) + 1e-8 * np.abs(ei[:, 1]) + 1e-15), k
                 assert np.allclose(gi[:, 3], ei[:, 3], rtol=sum_rtol, atol=1e-16), k
             else:
                 tol = sum_rtol if exact else max(rtol, sum_rtol)

@@ -298,3 +298,36 @@ def test_chained_smoother_default_on_big_tiles(strict):
     else:
         assert np.abs(p - g.get(F["PSI"])).max() <= 1e-10 * np.abs(g.get(F["PSI"])).max()
     assert out[0]["st"].i == g.mgstats().i
+
+
+def test_tiled_passive_tracers_wide_halo_messages():
+    """nptr = 5 on 2 x 2 tiles of 64^2 x 3: tracer fields carry nl * nptr = 15 layers and are exchanged whole, the
+    largest halo message of the run (the staging buffers were sized for nl layers only).  Bit-identical to
+    the single tile, tracers included."""
+    px = py = 2
+    tile, nl, nptr = 64, 3, 5
+    gn = tile * px
+    ex = f"MGLEVELS = 6\nnptr = {nptr}\nptr_r = [10,0,3.5,1,0]\nPe = [200,50,0,100,20]\n"
+    params = orc.double_gyre_params(gn, nl, extra=ex)
+    psi = orc.synthetic_psi(nl, gn, gn)
+    rng = np.random.default_rng(5)
+    c0, rl = 1e-3 * rng.standard_normal((nl * nptr, gn, gn)), 1e-3 * rng.standard_normal((nl * nptr, gn, gn))
+
+    def sl(a, rank):
+        ix, iy = rank % px, rank // px
+        return a[:, iy * tile:(iy + 1) * tile, ix * tile:(ix + 1) * tile]
+
+    def pre(g, rank):
+        g.set(F["PTR"], sl(c0, rank)); g.set(F["PTR_RELAX"], sl(rl, rank))
+
+    out = run_tiled(params, px, py, psi, nsteps=3, strict=True, pre=pre, fn=lambda g, r: g.get(F["PTR"]))
+    g = QG(params, strict=True)
+    g.option("quiet", 1)
+    g.set(F["PSI"], psi); g.set_const()
+    g.set(F["PTR"], c0); g.set(F["PTR_RELAX"], rl)
+    g.set_tnext(float("inf"))
+    for _ in range(3):
+        g.step()
+    assert np.array_equal(assemble(out, "q", px, py), g.get(F["Q"]))
+    assert np.array_equal(assemble(out, "extra", px, py), g.get(F["PTR"]))
+    assert np.abs(g.get(F["PTR"]) - c0).max() > 0
