@@ -1,17 +1,26 @@
 #!/usr/bin/env python
 """bench.py -- timesteps/s and grid-point-updates/s of the multi-layer QG hot path.
 
-One "step" = one full predictor-corrector (RK2) time step of msqg: 2 elliptic inversions
-q -> psi (multigrid, TOLERANCE 1e-3 as msqg/qg.h:159), 2 PV-tendency evaluations, 2 advances
-(SURVEY 8d).  Workload at N = 1: BASELINE.json's metric configuration, 4096 x 4096 x 6 layers,
-fp64, Verron double-gyre parameters (msqg/test/params.double_gyre.in) with nl = 6, synthetic
-seed-free initial stream function.  N > 1: one process per GPU, weak scaling -- every rank
-owns one 4096 x 4096 x 6 tile of a (4096 px) x (4096 py) domain.
+One "step" = one full predictor-corrector (RK2) time step of msqg: 2 elliptic inversions q -> psi (multigrid,
+TOLERANCE 1e-3 as msqg/qg.h:159), 2 PV-tendency evaluations, 2 advances.
 
-Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the
-library's stream around the dominant kernel (finest-level red-black smoother colour sweep);
-`cpu_baseline` is the CPU oracle (oracle/, OpenMP) timed on the host cores on a bounded
-sample of the same workload.
+Workloads (BASELINE.json configs; Verron double-gyre parameters of msqg/test/params.double_gyre.in with N / nl
+overridden, synthetic seed-free initial stream function, fp64):
+  C4 (default)  4096 x 4096 x 6   -- the configuration the metric is quoted on; fits one MI355X (14 of 288 GB)
+  C3            2048 x 2048 x 3
+  C2             512 x  512 x 3
+  C5            2048 x 2048 x 3, stochastic variant (msqg/qg_stochastic.h; noise from the device Philox generator)
+N = 1: the whole grid on one GPU.  N > 1 (one process per GPU, RCCL): by default WEAK scaling -- every rank owns one
+tile of the configuration's N = 1 size (`--tile NXxNY` overrides it), the domain grows with the tile grid and the
+grid spacing stays fixed; `--split` instead splits the configuration's own grid over the ranks (BASELINE C4 as
+written: 4096^2 x 6 on 2 x 4 tiles of 2048 x 1024 at N = 8).  After the timed weak-scaling leg a multi-rank run also
+times that split layout and reports it as `split_global_grid` in the same line.
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel of the step (the finest-level smoother pass);
+its duration is the average of HIP-event pairs recorded on the library's own stream around every such launch INSIDE
+the timed steps (option "profile"), `frac` = the pass's own compulsory HBM bytes / that duration / 8 TB/s.  The other
+finest-level kernels (PV tendency, residual passes, red + prolongation) are timed the same way and listed under
+`roofline.kernels`.  `cpu_baseline` is the CPU oracle (oracle/, OpenMP) timed on the host cores on a bounded sample.
 """
 import argparse
 import json
@@ -23,15 +32,23 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 
+CONFIGS = {
+    "C2": dict(N=512, nl=3, stochastic=False),
+    "C3": dict(N=2048, nl=3, stochastic=False),
+    "C4": dict(N=4096, nl=6, stochastic=False),
+    "C5": dict(N=2048, nl=3, stochastic=True),
+}
+
 
 def cpu_baseline(nl, n_cpu=1024, steps=2):
-    """CPU oracle (plain C + OpenMP, red-black smoother) on a bounded sample: `steps` RK2 steps
-    of the same parameter set on an n_cpu^2 x nl grid; grid-point-updates/s is size-normalised."""
+    """CPU oracle (plain C + OpenMP, red-black smoother) on a bounded sample: `steps` RK2 steps of the same parameter
+    set on an n_cpu^2 x nl grid; grid-point-updates/s is size-normalised.  The only place bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
+    from msom_amd import workloads as wl
 
     try:
         cores = len(os.sched_getaffinity(0))
@@ -47,8 +64,8 @@ def cpu_baseline(nl, n_cpu=1024, steps=2):
     threads = max(1, min(cores, quota, 16))
     os.environ["OMP_NUM_THREADS"] = str(threads)
     os.environ.setdefault("OMP_PROC_BIND", "close")
-    o = orc.Oracle(orc.double_gyre_params(n_cpu, nl), smoother=orc.GS_RB, quiet=1)
-    o.set(orc.PSI, orc.synthetic_psi(nl, n_cpu, n_cpu))
+    o = orc.Oracle(wl.double_gyre_params(n_cpu, nl), smoother=orc.GS_RB, quiet=1)
+    o.set(orc.PSI, wl.synthetic_psi(nl, n_cpu, n_cpu))
     o.set_const()
     o.step()  # warm-up (first touch, limiter start)
     t0 = time.perf_counter()
@@ -61,18 +78,19 @@ def cpu_baseline(nl, n_cpu=1024, steps=2):
         "cores": orc.lib().orc_num_threads(),
         "kind": "port",
         "sample": f"{steps} RK2 steps at {n_cpu}x{n_cpu}x{nl} fp64 (same params, red-black smoother, 1 warm-up step), "
-                  f"{dt / steps * 1e3:.0f} ms/step",
+                  f"{dt / steps * 1e3:.0f} ms/step; a 4096^2 x 6 step of the oracle takes ~16x longer (BASELINE.md section 5)",
         "steps_per_s": steps / dt,
     }
 
 
 _VARIANT_SNIPPET = """
 import sys, time
-sys.path.insert(0, {tests!r})
+sys.path.insert(0, {tests!r}); sys.path.insert(0, {root!r})
 import orc
+from msom_amd import workloads as wl
 n, nl, steps, sm = {n}, {nl}, {steps}, {sm}
-o = orc.Oracle(orc.double_gyre_params(n, nl), smoother=sm, quiet=1)
-o.set(orc.PSI, orc.synthetic_psi(nl, n, n)); o.set_const(); o.step()
+o = orc.Oracle(wl.double_gyre_params(n, nl), smoother=sm, quiet=1)
+o.set(orc.PSI, wl.synthetic_psi(nl, n, n)); o.set_const(); o.step()
 t0 = time.perf_counter()
 for _ in range(steps): o.step()
 print(n * n * nl * steps / (time.perf_counter() - t0))
@@ -80,14 +98,14 @@ print(n * n * nl * steps / (time.perf_counter() - t0))
 
 
 def cpu_variants(nl, n=512, steps=2):
-    """SURVEY 8d asks for the lexicographic (reference order) and single-thread CPU timings next to the
-    OpenMP red-black one: each in its own process (OMP_NUM_THREADS is read once), on a smaller sample."""
+    """SURVEY 8d asks for the lexicographic (reference order) and single-thread CPU timings next to the OpenMP red-black
+    one: each in its own process (OMP_NUM_THREADS is read once), on a smaller sample."""
     import subprocess
 
     out = {}
     for name, sm, threads in (("red_black_1_thread", 1, 1), ("lexicographic_reference_order_1_thread", 0, 1)):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads))
-        code = _VARIANT_SNIPPET.format(tests=os.path.join(ROOT, "tests"), n=n, nl=nl, steps=steps, sm=sm)
+        code = _VARIANT_SNIPPET.format(tests=os.path.join(ROOT, "tests"), root=ROOT, n=n, nl=nl, steps=steps, sm=sm)
         try:
             r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
             out[name] = {"value": float(r.stdout.strip().splitlines()[-1]), "unit": "grid-point-updates/s", "cores": threads,
@@ -97,14 +115,166 @@ def cpu_variants(nl, n=512, steps=2):
     return out
 
 
+def psi_fn(l, y, x):
+    """synthetic seed-free IC: global sine modes sampled on a tile (same formula as workloads.synthetic_psi)"""
+    f = np.zeros((y.size, x.size))
+    for k in range(1, 5):
+        for m in range(1, 5):
+            f += np.sin(1.7 * k + 2.3 * m + 0.9 * l) / (k * m) * np.outer(np.sin(m * np.pi * y), np.sin(k * np.pi * x))
+    return 1e-3 * (1.0 - 0.15 * l) * f
+
+
+class Leg:
+    """one model instance on this rank's tile of a (tx px) x (ty py) domain + its timed loop"""
+
+    def __init__(self, tx, ty, nl, px, py, rank, dist, cfg_n, stochastic=False, local_rank=0):
+        from msom_amd import FIELDS as F
+        from msom_amd import QG, load_library, tiling
+        from msom_amd import workloads as wl
+
+        self.tx, self.ty, self.nl, self.px, self.py, self.dist = tx, ty, nl, px, py, dist
+        self.gnx, self.gny = tx * px, ty * py
+        # the grid spacing of the configuration (Delta = 80 / N_config) is the same on every leg: L0 follows the domain width
+        extra = (f"Ny = {self.gny}\n" if self.gny != self.gnx else "")
+        if stochastic:
+            extra += "tr_stoch = 50\namp_stoch = 1e-5\n"
+        params = wl.double_gyre_params(self.gnx, nl, extra=extra, L0=80.0 * self.gnx / cfg_n)
+        self.params = params
+        lib = load_library()
+        if lib.msom_set_device(local_rank) != 0:
+            raise SystemExit(lib.msom_last_error().decode())
+        if px * py > 1:
+            uid = tiling.broadcast_unique_id(dist, lambda: tiling.rccl_unique_id(lib), device="cuda")
+            g = QG(params, tiled=(px, py, rank, uid))
+        else:
+            g = QG(params)
+        g.option("quiet", 1)
+        if stochastic:
+            g.option("stochastic", 1)
+            g.option("noise_mode", 1)   # counter-based Philox on the device (the reference's serial rand() is a host loop)
+            g.option("seed", 7)
+        g.set(F["PSI"], tiling.synthetic_tile(psi_fn, rank, px, py, nl, tx, ty))
+        if stochastic:
+            g.set(F["SIGMA"], np.ones((nl, ty, tx)))
+        g.set_const()
+        g.set_tnext(float("inf"))
+        self.g = g
+
+    def barrier(self):
+        if self.dist is not None:
+            import torch
+
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def run(self, steps, warmup):
+        g = self.g
+        for _ in range(warmup):
+            g.step()
+        g.option("profile", 1)
+        g.profile_reset()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.step()   # msom_step synchronises the library's stream before returning
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        g.option("profile", 0)
+        if self.dist is not None:
+            import torch
+
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed
+
+    def summary(self, steps, elapsed):
+        st = self.g.mgstats()
+        return {
+            "grid": f"{self.gnx}x{self.gny}x{self.nl}", "tiles": f"{self.px}x{self.py} of {self.tx}x{self.ty}",
+            "value": self.gnx * self.gny * self.nl * steps / elapsed, "unit": "grid-point-updates/s",
+            "timesteps_per_s": steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "mg_cycles_per_solve": st.i, "mg_nrelax": st.nrelax, "mg_resa": st.resa, "ke_1": self.g.ke(),
+        }
+
+    def kernels(self):
+        """finest-level kernels timed with HIP events inside the timed steps; bytes = compulsory HBM bytes of the launch"""
+        g, nl = self.g, self.nl
+        w = 8.0 * self.tx * self.ty * nl
+        uniform = g.param("uniform_S") == 1.0
+        sigma = 0.0 if uniform else (nl - 1) / nl
+        plain_bytes = (3.0 + sigma) * w / 2.0
+        spec = [
+            ("march4", "k_relax_march<nl,4> (4 chained red-black half-sweeps per pass)", 2.5 * w, "other colour in w/2 + residual w + both colours out w"),
+            ("march3", "k_relax_march<nl,3> (3 chained half-sweeps per pass)", 2.5 * w, "as march4"),
+            ("march2", "k_relax_march<nl,2>", 2.5 * w, "as march4"),
+            ("sweep", "k_relax_color_x2 red + black (two launches)", 2.0 * plain_bytes, "per colour: other colour in, own residual in [, S], own colour out"),
+            ("red_prolong", "k_relax_red_prolong3 (first red half-sweep + bilinear prolongation)", 1.25 * w, "residual w/2 + coarse w/4 + red out w/2"),
+            ("resid_restrict", "k_residual2<write+restrict> (pre-cycle residual + first restriction)", 3.25 * w, "psi, q in, residual out, level-1 residual out w/4"),
+            ("resid_correct", "k_correct_residual (psi += da, residual max, max|u|)", 4.0 * w, "psi, da, q in, psi out"),
+            ("rhs", "k_rhs_lpw (Arakawa Jacobians + beta + dissipation + drag + forcing + advance)", 3.0 * w, "psi, q_in in, q_out out"),
+        ]
+        out = {}
+        for key, name, nbytes, what in spec:
+            ms, n = g.profile_read(key)
+            if n > 0 and ms > 0:
+                out[key] = {"kernel": name, "avg_launch_ms": ms, "launches_timed": n, "compulsory_bytes_per_launch": nbytes, "bytes_are": what,
+                            "achieved_GBs": nbytes / (ms * 1e-3) / 1e9, "frac_hbm": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if "rhs" in out:
+            out["rhs"]["fp64_flop_per_point_layer"] = 215
+            out["rhs"]["achieved_fp64_TFLOPs"] = 215.0 * self.tx * self.ty * nl / (out["rhs"]["avg_launch_ms"] * 1e-3) / 1e12
+        return out, w, plain_bytes, uniform
+
+
+def roofline(leg, world):
+    ks, w, plain_bytes, uniform = leg.kernels()
+    nl = leg.nl
+    dom = next((k for k in ("march4", "march3", "march2") if k in ks), "sweep" if "sweep" in ks else None)
+    if dom is None:
+        return {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None, "kernels": ks}
+    d = ks[dom]
+    K = int(dom[-1]) if dom.startswith("march") else 2
+    nbytes, ms = d["compulsory_bytes_per_launch"], d["avg_launch_ms"]
+    if dom == "sweep":      # two launches per timed pair: report one colour half-sweep launch
+        nbytes, ms, K = nbytes / 2.0, ms / 2.0, 1
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, collected with rocprofv3 --pmc in separate
+    # runs and stored under profiles/); only quoted for the exact configuration it was measured on
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_march.json")))
+        if (leg.tx, leg.ty, nl, world) == (4096, 4096, 6, 1) and uniform and dom.startswith("march"):
+            traffic = pmc.get(f"traffic_bytes_per_launch_K{K}")
+    except Exception:
+        pass
+    # SURVEY 8(d)'s accounting unit for the smoother is a red+black SWEEP = (3 + sigma) w [R a, R b, W a]; a pass of K
+    # chained half-sweeps does the work of K/2 such sweeps while moving only 2.5 w: effective bandwidth, NOT a fraction
+    eff = 2.0 * plain_bytes * (K / 2.0) / (ms * 1e-3) / 1e9
+    return {
+        "bound": "hbm",
+        "kernel": d["kernel"] if dom != "sweep" else f"k_relax_color_x2<{nl}> (one colour half-sweep per launch)",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms, "launches_timed": d["launches_timed"],
+        "half_sweeps_per_launch": K,
+        "traffic_over_algorithmic": (traffic / nbytes) if traffic else None,
+        "effective_bw_in_survey_sweep_units": {"GBs": eff, "per_unit_bytes": 2.0 * plain_bytes, "units_per_launch": K / 2.0,
+                                               "note": "K half-sweeps = K/2 sweeps of (3+sigma) w each if run one by one; values between chained half-sweeps stay in registers"},
+        "smoother_that_ran": dom,
+        "kernels": ks,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--N", type=int, default=4096, help="tile edge (cells)")
-    ap.add_argument("--nl", type=int, default=6)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C4")
+    ap.add_argument("--tile", default=None, help="NXxNY: tile per rank (weak scaling), overrides the configuration's grid")
+    ap.add_argument("--split", action="store_true", help="split the configuration's own grid over the ranks (strong)")
+    ap.add_argument("--nl", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (other configs at N = 1, split grid at N > 1)")
     ap.add_argument("--cpu-n", type=int, default=1024)
     args = ap.parse_args()
 
@@ -113,10 +283,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-
-    import orc
-    from msom_amd import FIELDS as F
-    from msom_amd import QG
 
     dist = None
     if world > 1:
@@ -127,168 +293,77 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from msom_amd import load_library, tiling
+    from msom_amd import tiling
 
+    cfg = CONFIGS[args.config]
+    nl = args.nl or cfg["nl"]
     px, py = tiling.tile_grid(world)
-    N, nl = args.N, args.nl
-    gnx, gny = N * px, N * py
-    # weak scaling: the tile (N x N x nl, Delta = 80/N) is fixed, the domain grows with the tile grid
-    params = orc.double_gyre_params(gnx, nl, extra=(f"Ny = {gny}\n" if gny != gnx else ""), L0=80.0 * px)
-    lib = load_library()
-    if lib.msom_set_device(local_rank) != 0:
-        raise SystemExit(lib.msom_last_error().decode())
-    if world > 1:
-        uid = tiling.broadcast_unique_id(dist, lambda: tiling.rccl_unique_id(lib), device="cuda")
-        g = QG(params, tiled=(px, py, rank, uid))
+    if args.tile:
+        tx, ty = (int(v) for v in args.tile.lower().split("x"))
+    elif args.split:
+        tx, ty = cfg["N"] // px, cfg["N"] // py
     else:
-        g = QG(params)
-    g.option("quiet", 1)
+        tx = ty = cfg["N"]
+    leg = Leg(tx, ty, nl, px, py, rank, dist, cfg["N"], stochastic=cfg["stochastic"], local_rank=local_rank)
+    elapsed = leg.run(args.steps, args.warmup)
+    main_sum = leg.summary(args.steps, elapsed)
+    roof = roofline(leg, world) if rank == 0 else None
+    uniform = leg.g.param("uniform_S") == 1.0
+    leg.g.close()
 
-    # synthetic seed-free IC: global sine modes sampled on this rank's tile
-    def psi_fn(l, y, x):
-        f = np.zeros((y.size, x.size))
-        for k in range(1, 5):
-            for m in range(1, 5):
-                f += np.sin(1.7 * k + 2.3 * m + 0.9 * l) / (k * m) * np.outer(np.sin(m * np.pi * y), np.sin(k * np.pi * x))
-        return 1e-3 * (1.0 - 0.15 * l) * f
-
-    g.set(F["PSI"], tiling.synthetic_tile(psi_fn, rank, px, py, nl, N, N))
-    g.set_const()
-    g.set_tnext(float("inf"))
-
-    def barrier():
-        if dist is not None:
-            import torch
-
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        g.step()
-    g.option("profile", 1)
-    g.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        g.step()   # msom_step synchronises the library's stream before returning
-    barrier()
-    elapsed = time.perf_counter() - t0
-    g.option("profile", 0)
-    if dist is not None:
-        import torch
-
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    sweep_ms, sweep_n = g.profile_read("sweep")      # one sweep = red + black launch (half-sweep-per-launch path)
-    m4_ms, m4_n = g.profile_read("march4")           # finest-level passes of 4 / 3 chained half-sweeps (one GPU)
-    m3_ms, m3_n = g.profile_read("march3")
-    resid_ms, resid_n = g.profile_read("residual")
-    st = g.mgstats()
-    ke = g.ke()
-    # second kernel of the step (the Jacobian / PV-tendency pass): a short back-to-back microbenchmark after the timed
-    # region (HIP events on the library's stream); every rank takes part (tiles exchange the psi halo)
-    rhs_ms = g.bench_kernel("rhs_adv", 5)
-    plain_ms = g.bench_kernel("sweep", 5) / 2.0     # one plain colour half-sweep launch, for comparison
+    extra = {}
+    if not args.no_extra:
+        if world == 1 and args.config == "C4" and not args.tile:
+            # the other BASELINE configurations on one GPU, short legs (their kernels are timed the same way)
+            for name in ("C2", "C3", "C5"):
+                c = CONFIGS[name]
+                lg = Leg(c["N"], c["N"], c["nl"], 1, 1, 0, None, c["N"], stochastic=c["stochastic"], local_rank=local_rank)
+                steps = 100 if c["N"] <= 512 else 40
+                el = lg.run(steps, 10)
+                s = lg.summary(steps, el)
+                ks, _, _, _ = lg.kernels()
+                s["kernels"] = {k: {"avg_launch_ms": v["avg_launch_ms"], "frac_hbm": v["frac_hbm"]} for k, v in ks.items()}
+                if c["stochastic"]:
+                    s["variant"] = "msqg/qg_stochastic.h, device Philox noise (noise_mode 1), tr_stoch 50, amp_stoch 1e-5, sigma = 1"
+                extra[name] = s
+                lg.g.close()
+        elif world > 1 and not args.split and not args.tile:
+            # BASELINE C4 as written: the configuration's own grid split over the ranks (2 x 4 tiles of 2048 x 1024 at N = 8)
+            lg = Leg(cfg["N"] // px, cfg["N"] // py, nl, px, py, rank, dist, cfg["N"], stochastic=cfg["stochastic"], local_rank=local_rank)
+            el = lg.run(args.steps, args.warmup)
+            extra["split_global_grid"] = lg.summary(args.steps, el)
+            if rank == 0:
+                ks, _, _, _ = lg.kernels()
+                extra["split_global_grid"]["smoother_that_ran"] = next((k for k in ("march4", "march3", "march2", "sweep") if k in ks), None)
+            lg.g.close()
 
     if rank == 0:
-        w = 8.0 * N * N * nl                       # bytes of one layered fp64 field of the tile
-        uniform = g.param("uniform_S") == 1.0
-        sigma = 0.0 if uniform else (nl - 1) / nl
-        # algorithmic bytes of ONE colour half-sweep launch: read the other colour's da (w/2),
-        # read own-colour res (w/2) [+ own-colour S], write own-colour da (w/2)
-        plain_bytes = (3.0 + sigma) * w / 2.0
-        marched = m4_n + m3_n > 0
-        if marched:
-            # the smoother's finest-level pass: K chained half-sweeps per launch (kernels_march.hip).
-            # Contract figure: SURVEY 8(d)'s per-unit bytes (one red+black sweep = (3 + sigma) w: R a, R b, W a) x the
-            # units one launch processes (K / 2 sweeps).  The pass itself needs less -- the other colour's da in (w/2),
-            # the residual of both colours (w), both colours of da out (w) = 2.5 w whatever K -- because the values
-            # between the chained half-sweeps never leave the registers; that figure and the measured HBM traffic are
-            # reported next to the contract one (so `frac` can exceed 1: it is an effective bandwidth)
-            K, launch_ms, launches = (4, m4_ms, m4_n) if m4_n > 0 else (3, m3_ms, m3_n)   # the longer pass where both run
-            launch_bytes = plain_bytes * K
-            pass_bytes = 2.5 * w
-            kernel = f"k_relax_march<{nl}, {K}, false, false> (finest level: {K} chained red-black colour half-sweeps = {K / 2:g} sweeps per pass, intermediate values in registers)"
-            pmc_file = "r01_pmc_traffic_march.json"
-        else:
-            K, launch_bytes, launch_ms, launches = 1, plain_bytes, sweep_ms / 2.0, 2 * sweep_n
-            pass_bytes = plain_bytes
-            kernel = f"k_relax_color_x2<{nl}, {'true' if uniform else 'false'}, true> (finest-level red-black colour half-sweep)"
-            pmc_file = "r01_pmc_traffic_relax_fine.json"
-        achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-        # collected separately with rocprofv3 --pmc and stored under profiles/
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-            if N == 4096 and nl == 6 and uniform and world == 1:
-                traffic = pmc["traffic_bytes_per_launch"] if K == 1 else pmc[f"traffic_bytes_per_launch_K{K}"]
-        except Exception:
-            pass
         out = {
-            "metric": "grid-point-updates/s (timesteps/s x N^2 x nl), multi-layer QG RK2 step at 4096^2 x 6L per GPU",
-            "value": gnx * gny * nl * args.steps / elapsed,
+            "metric": f"grid-point-updates/s (timesteps/s x N^2 x nl), multi-layer QG RK2 step at {tx}x{ty}x{nl} per GPU",
+            "value": main_sum["value"],
             "unit": "grid-point-updates/s",
-            "timesteps_per_s": args.steps / elapsed,
+            "timesteps_per_s": main_sum["timesteps_per_s"],
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": main_sum["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.split else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"msqg double gyre (Verron 1992 params), {gnx}x{gny}x{nl} fp64, tiles {px}x{py} of {N}x{N}, "
+                "workload": f"{args.config}: msqg double gyre (Verron 1992 params){' + stochastic forcing' if cfg['stochastic'] else ''}, "
+                            f"{leg.gnx}x{leg.gny}x{nl} fp64, tiles {px}x{py} of {tx}x{ty}, "
                             f"TOLERANCE 1e-3, RK2 step = 2 inversions + 2 tendencies + 2 advances",
-                "mg_cycles_per_solve": st.i, "mg_nrelax": st.nrelax, "mg_resa": st.resa, "ke_1": ke,
-                "uniform_S_fast_path": bool(uniform),
+                "mg_cycles_per_solve": main_sum["mg_cycles_per_solve"], "mg_nrelax": main_sum["mg_nrelax"], "mg_resa": main_sum["mg_resa"],
+                "ke_1": main_sum["ke_1"], "uniform_S_fast_path": bool(uniform),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kernel,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": launch_bytes,
-                "avg_launch_ms": launch_ms,
-                "launches_timed": launches,
-                "half_sweeps_per_launch": K,
-                "other_pass": ({"half_sweeps_per_launch": 3, "avg_launch_ms": m3_ms, "launches_timed": m3_n} if marched and K == 4 and m3_n > 0 else None),
-                "per_unit_bytes": 2.0 * plain_bytes, "units_per_launch": K / 2.0, "unit_name": "red+black sweep (SURVEY 8d: R a, R b, W a)",
-                "pass_compulsory_bytes": pass_bytes,
-                "achieved_vs_pass_bytes": pass_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0,
-                "frac_vs_pass_bytes": pass_bytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if launch_ms > 0 else 0.0,
-                "plain_half_sweep_kernel": {
-                    "kernel": f"k_relax_color_x2<{nl}, {'true' if uniform else 'false'}, true> (one colour half-sweep per launch; used on tiles and small levels)",
-                    "avg_launch_ms": plain_ms, "algorithmic_bytes_per_launch": plain_bytes,
-                    "achieved_GBs": plain_bytes / (plain_ms * 1e-3) / 1e9 if plain_ms > 0 else 0.0,
-                    "note": "K of these move 1.5 K w; the chained pass moves 2.5 w for the same K half-sweeps",
-                },
-                "tendency_kernel": {
-                    "kernel": "k_rhs_lpw<4, true, false, true> (Arakawa Jacobians + beta + dissipation + drag + forcing + advance, one pass over psi)",
-                    "avg_launch_ms": rhs_ms,
-                    "algorithmic_bytes_per_launch": 3.0 * w,
-                    "achieved_GBs": 3.0 * w / (rhs_ms * 1e-3) / 1e9 if rhs_ms > 0 else 0.0,
-                    "frac_hbm": 3.0 * w / (rhs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rhs_ms > 0 else 0.0,
-                    "fp64_flop_per_point_layer": 215,
-                    "achieved_fp64_TFLOPs": 215.0 * N * N * nl / (rhs_ms * 1e-3) / 1e12 if rhs_ms > 0 else 0.0,
-                    "note": "fused: reads psi and q_in once, writes q_out once (the reference's loop chain moves ~25 w); "
-                            "one layer per wavefront, stencils from register windows + whole-wave DPP shifts; fp64-issue / wait bound (3 waves per SIMD), not HBM bound",
-                },
-                "residual_kernels": {
-                    "avg_launch_ms": resid_ms, "launches_timed": resid_n,
-                    "note": "k_residual2<write+restrict> (3.25 w) and k_residual2<correct> (4 w) alternate",
-                    "achieved_GBs": (3.625 * w / (resid_ms * 1e-3) / 1e9) if resid_ms > 0 else 0.0,
-                },
-            },
+            "roofline": roof,
         }
+        if extra:
+            out["other_legs"] = extra
         if not args.no_cpu and world == 1:   # CPU baseline: rank 0 at N = 1 only
-            g.close()
             out["cpu_baseline"] = cpu_baseline(nl, n_cpu=args.cpu_n)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             out["cpu_baseline"]["variants"] = cpu_variants(nl)

@@ -212,8 +212,13 @@ int msom_dbg_restrict(msom_t *m, int lev_fine, const double *fine, double *coars
 int msom_dbg_prolong(msom_t *m, int lev_coarse, const double *coarse, double *fine);
 int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, double add, double fac);
 
-/* ---- measurement: average HIP-event duration of the finest-level smoother sweep
- * (both colours) recorded while "profile" is on, and a direct kernel microbenchmark */
+/* ---- measurement: average HIP-event duration (events recorded on the library's own stream while the option
+ * "profile" is on, i.e. inside the timed steps) of the finest-level launches named
+ *   "sweep" (red + black half-sweep pair), "march2" / "march3" / "march4" (passes of K chained half-sweeps),
+ *   "red_prolong" (first red half-sweep + prolongation), "resid_restrict" (pre-cycle residual + restriction),
+ *   "resid_correct" (correction + residual + max|u|), "residual" (both of the former), "rhs" (fused PV tendency
+ *   [+ advance] pass), "block2";
+ * and a back-to-back kernel microbenchmark outside any step */
 int msom_profile_read(msom_t *m, const char *kernel, double *avg_ms, long *launches);
 int msom_profile_reset(msom_t *m);
 int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double *avg_ms);

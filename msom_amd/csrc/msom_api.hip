@@ -133,6 +133,7 @@ struct msom {
   // profiling of the finest-level smoother sweep
   int profile = 0;
   ProfSlot prof_sweep, prof_resid, prof_block, prof_march[5];  // prof_march[K]: passes of K chained half-sweeps
+  ProfSlot prof_rhs, prof_redprol, prof_rescorr, prof_respre;   // tendency pass, finest red+prolongation, post- / pre-cycle residual passes
 };
 
 static void free_agglomeration(msom *m);
@@ -590,7 +591,7 @@ extern "C" int msom_destroy(msom_t *m) {
   if (m->d_scal) hipFree(m->d_scal);
   if (m->h_scal) hipHostFree(m->h_scal);
   if (m->d_wind) hipFree(m->d_wind);
-  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4]})
+  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4], &m->prof_rhs, &m->prof_redprol, &m->prof_rescorr, &m->prof_respre})
     for (auto e : ps->ev) hipEventDestroy(e);
   if (m->comm) comm_destroy(m->comm);
   if (m->ev_c2x) hipEventDestroy(m->ev_c2x);
@@ -1064,7 +1065,9 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
       std::swap(*L.da, *L.da_alt);
       n -= K; c = K & 1;
     } else if (coarse && n > 0) {
+      if (prof) prof_begin(m, m->prof_redprol);
       launch_relax_red_prolong(m->st, *L.da, *coarse->da, *coarse->sg, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, L.walls);
+      if (prof) prof_end(m, m->prof_redprol);
       n--; c = 1;
     }
     while (n >= 2) {
@@ -1115,9 +1118,11 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
         comm_end(m);
         continue;
       }
-      if (pl && c == 0)
+      if (pl && c == 0) {
+        if (prof) prof_begin(m, m->prof_redprol);
         launch_relax_red_prolong(m->st, *L.da, *coarse->da, *coarse->sg, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, L.walls);
-      else
+        if (prof) prof_end(m, m->prof_redprol);
+      } else
         launch_relax_color(m->st, *L.da, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, c, L.walls, L.fine);
       // boundary_level(da, l): the last exchange of the level also carries the corner ghosts
       // that the bilinear prolongation to the next finer level reads
@@ -1186,11 +1191,12 @@ static void residual(msom *m, const double *a, const double *b, int slot, int wa
 }
 // fused variants (kernels_mg.hip k_residual2); mode bits 1 = CORRECT, 2 = WRITE, 4 = RESTRICT
 static void residual2(msom *m, int mode, const double *b, int slot, int want_sum) {
-  if (m->profile) prof_begin(m, m->prof_resid);
+  ProfSlot &which = (mode & 1) ? m->prof_rescorr : m->prof_respre;
+  if (m->profile) { prof_begin(m, m->prof_resid); prof_begin(m, which); }
   launch_residual2(m->st, mode, m->f[MSOM_PSI], m->da[0], m->psi_alt, b, m->f[MSOM_S], m->g, m->res[0], m->sg[0],
                    m->nlev > 1 ? m->res[1] : nullptr, m->sg[m->nlev > 1 ? 1 : 0], m->nl, m->rc[0], m->uniformS, m->walls, m->d_scal + slot,
                    m->partial, want_sum, m->partial_umax, m->d_scal + SC_UMAX);
-  if (m->profile) prof_end(m, m->prof_resid);
+  if (m->profile) { prof_end(m, m->prof_resid); prof_end(m, which); }
 }
 
 // max-residual slots (RES0, RES1) and the rhs sum (BSUM) -> host, reduced over the tiles
@@ -1346,11 +1352,13 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
       rr.sg = m->sg[0]; rr.cg = m->sg[1];
     }
     // one pass over psi: zeta, Jacobians, beta, dissipation, drag, forcing, max|u| (kernels_fused.hip)
+    prof_begin(m, m->prof_rhs);
     launch_rhs_fused(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, m->f[dqfield], nullptr,
                      nullptr, m->g, nl, m->walls & WALL_ALL, m->uniformS, m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe,
                      iRe4, Eks / (p.Rom * 2 * m->dhf[0]), Ekb / (p.Rom * 2 * m->dhf[nl - 1]),
                      p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, variant, adv_out >= 0 ? m->f[adv_in] : nullptr,
                      adv_out >= 0 ? m->f[adv_out] : nullptr, adv_dt, use_rr ? &rr : nullptr);
+    prof_end(m, m->prof_rhs);
     if (use_rr) m->res_ready = adv_out;
     if (advanced && adv_out >= 0) *advanced = 1;
     return MSOM_OK;
@@ -2291,13 +2299,15 @@ extern "C" int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, doubl
 
 extern "C" int msom_profile_reset(msom_t *m) {
   if (!m) return MSOM_ERR_ARG;
-  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4]}) { ps->used = 0; ps->total_ms = 0; ps->launches = 0; }
+  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4], &m->prof_rhs, &m->prof_redprol, &m->prof_rescorr, &m->prof_respre}) { ps->used = 0; ps->total_ms = 0; ps->launches = 0; }
   return MSOM_OK;
 }
 extern "C" int msom_profile_read(msom_t *m, const char *kernel, double *avg_ms, long *launches) {
   if (!m || !kernel) return MSOM_ERR_ARG;
   ProfSlot *ps = !strcmp(kernel, "sweep") ? &m->prof_sweep : !strcmp(kernel, "residual") ? &m->prof_resid : !strcmp(kernel, "block2") ? &m->prof_block :
-                 !strcmp(kernel, "march2") ? &m->prof_march[2] : !strcmp(kernel, "march3") ? &m->prof_march[3] : !strcmp(kernel, "march4") ? &m->prof_march[4] : nullptr;
+                 !strcmp(kernel, "march2") ? &m->prof_march[2] : !strcmp(kernel, "march3") ? &m->prof_march[3] : !strcmp(kernel, "march4") ? &m->prof_march[4] :
+                 !strcmp(kernel, "rhs") ? &m->prof_rhs : !strcmp(kernel, "red_prolong") ? &m->prof_redprol : !strcmp(kernel, "resid_correct") ? &m->prof_rescorr :
+                 !strcmp(kernel, "resid_restrict") ? &m->prof_respre : nullptr;
   if (!ps) { msom_set_error("unknown kernel %s", kernel); return MSOM_ERR_ARG; }
   prof_collect(m, *ps);
   if (avg_ms) *avg_ms = ps->launches ? ps->total_ms / ps->launches : 0.;
