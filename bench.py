@@ -205,7 +205,9 @@ class Leg:
         sigma = 0.0 if uniform else (nl - 1) / nl
         plain_bytes = (3.0 + sigma) * w / 2.0
         spec = [
-            ("march4", "k_relax_march<nl,4> (4 chained red-black half-sweeps per pass)", 2.5 * w, "other colour in w/2 + residual w + both colours out w"),
+            ("march4", "k_relax_march_dma<nl,4> (4 chained red-black half-sweeps per pass, rows by LDS-DMA)", 2.5 * w, "other colour in w/2 + residual w + both colours out w"),
+            ("march_pl", "k_relax_march_dma<nl,4,PL> (bilinear prolongation + 4 chained half-sweeps: first pass of a level visit)", 2.25 * w,
+             "coarse correction w/4 + residual w + both colours out w"),
             ("march3", "k_relax_march<nl,3> (3 chained half-sweeps per pass)", 2.5 * w, "as march4"),
             ("march2", "k_relax_march<nl,2>", 2.5 * w, "as march4"),
             ("sweep", "k_relax_color_x2 red + black (two launches)", 2.0 * plain_bytes, "per colour: other colour in, own residual in [, S], own colour out"),
@@ -276,6 +278,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (other configs at N = 1, split grid at N > 1)")
     ap.add_argument("--cpu-n", type=int, default=1024)
+    ap.add_argument("--opt", action="append", default=[], help="key=value library option (tuning A/B), repeatable")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -305,6 +308,9 @@ def main():
     else:
         tx = ty = cfg["N"]
     leg = Leg(tx, ty, nl, px, py, rank, dist, cfg["N"], stochastic=cfg["stochastic"], local_rank=local_rank)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        leg.g.option(k, float(v))
     elapsed = leg.run(args.steps, args.warmup)
     main_sum = leg.summary(args.steps, elapsed)
     roof = roofline(leg, world) if rank == 0 else None
@@ -358,6 +364,7 @@ def main():
                             f"TOLERANCE 1e-3, RK2 step = 2 inversions + 2 tendencies + 2 advances",
                 "mg_cycles_per_solve": main_sum["mg_cycles_per_solve"], "mg_nrelax": main_sum["mg_nrelax"], "mg_resa": main_sum["mg_resa"],
                 "ke_1": main_sum["ke_1"], "uniform_S_fast_path": bool(uniform),
+                **({"options": args.opt} if args.opt else {}),
             },
             "roofline": roof,
         }

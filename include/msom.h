@@ -96,8 +96,10 @@ int msom_destroy(msom_t *m);
  * "rhs_resid" [0] first residual of the next inversion as its by-product, "mg_fused" [1] fused
  * residual/restriction and correction/residual passes, "prolong_fused" [1], "mg_coarse" [1] coarse levels
  * in one launch, "march" [1] chained half-sweep smoother on HBM-bound single-GPU levels (2: on every level that is
- * wide enough), "march_k" [4] half-sweeps per pass, "march_rows" [0 = auto] chunk height, "march_min" [24] log2 of the cell-layers a level needs, "march_prolong" [0] prolongation folded
- * into the first pass, "march_correct" [0] correction folded into the last pass, "march_xcd" [1] XCD-contiguous block numbering, "march_flip" [1] odd chunks march downwards, "block_sweeps" [0] LDS-tiled blocked smoother, "agglomerate" [1] / "agg_size" [256]
+ * wide enough), "march_k" [4] half-sweeps per pass, "march_rows" [0 = auto] chunk height, "march_min" [24] log2 of the cell-layers a level needs, "march_prolong" [1] prolongation folded
+ * into the first pass, "march_dma" [2] memory side of the pass (0: register-window loads, 1: LDS-DMA prefetch with one strip per
+ * workgroup, 2: four strips per workgroup marching in step; PROCESS-WIDE tuning knob like march_rows / march_xcd / march_flip /
+ * march_dbg / rhs_dbg / block_variant, which are globals of the library rather than fields of the handle), "march_correct" [0] correction folded into the last pass, "march_xcd" [1] XCD-contiguous block numbering, "march_flip" [1] odd chunks march downwards, "block_sweeps" [0] LDS-tiled blocked smoother, "agglomerate" [1] / "agg_size" [256]
  * gathered coarse levels of tiled runs, "mg_global_sum" [0]; "rhs_dbg", "block_variant": timing
  * experiments of tools/. */
 int msom_set_option(msom_t *m, const char *key, double value);
@@ -215,6 +217,7 @@ int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, double add, doub
 /* ---- measurement: average HIP-event duration (events recorded on the library's own stream while the option
  * "profile" is on, i.e. inside the timed steps) of the finest-level launches named
  *   "sweep" (red + black half-sweep pair), "march2" / "march3" / "march4" (passes of K chained half-sweeps),
+ *   "march_pl" (first pass of a level visit: prolongation + K half-sweeps),
  *   "red_prolong" (first red half-sweep + prolongation), "resid_restrict" (pre-cycle residual + restriction),
  *   "resid_correct" (correction + residual + max|u|), "residual" (both of the former), "rhs" (fused PV tendency
  *   [+ advance] pass), "block2";

@@ -44,6 +44,7 @@ struct MarchArgs {
   SplitGeom g;
   int c1;  // colour of the first half-sweep (0 red, 1 black)
   int walls, H, remap, flip;
+  int dbg;  // timing experiments only (results wrong): 1 = no stores, 2 = no loads after the first step
   RelaxCoef rc;
 };
 
@@ -272,6 +273,303 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_relax_march_dma: the same pass with the memory side rebuilt (round 2).
+//
+// Measured on the register-window kernel above (tools/ab_march_dbg.py, 4096^2 x 6, K = 4): arithmetic alone 0.17 ms, with
+// its loads 0.27 ms, with its stores 0.29 ms, everything 0.53 ms -- the time does not depend on K (K = 2: 0.51 ms) and
+// loads and stores ADD instead of overlapping: every wavefront is an independent 60-lane strip whose 480-byte row pieces
+// (18 read + 12 written per step, 8 bytes per lane, consumed in the step that requests them) reach the memory system
+// one strip at a time.  Changes:
+//  * the rows of step t + 1 are requested by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, 32 lanes per 512-byte
+//    layer-row, two layer-rows per wave instruction, no VGPR destination) right after step t has moved its own rows
+//    from LDS into registers, so a request has a whole step to land; one counted wait per step;
+//  * WPB = 4 wavefronts per workgroup take 4 adjacent strips and march IN STEP (one s_barrier per row, no data
+//    exchanged): the pieces they request and write at the same moment are 1.9 KB of one row instead of 4 unrelated
+//    480-byte pieces (-5 % at K = 4, -14 % at K = 2 on the same box);
+//  * PL: the prolongation rides in the pass (input of the first half-sweep interpolated on the fly from two coarse rows
+//    per step, which arrive by LDS-DMA as well: the L2-latency loads at the head of every step that made the register
+//    version of this variant lose are gone) -- a level visit is (PL + 4) + 4 half-sweeps in two passes instead of
+//    (red + prolongation) + 4 + 3 in three.
+// Arithmetic, windows, ghost rules and stores are the ones above (same expression order => bit-identical,
+// tests/test_gpu_march.py).  LDS per wavefront: 3 NL (PL: 4 NL) layer-rows of 512 B = 9 (12) KB at NL = 6.
+template <int NL, int K, int HL, int WPB, bool PL>
+__global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
+  static_assert(HL % 2 == 0 && (!PL || HL % 4 == 0), "16-byte pieces: strips start at even kx (PL: at kx = 0 mod 4)");
+  constexpr int OW = 64 - 2 * HL;
+  constexpr int D1 = K >= 3 ? 3 : 1, D2 = K >= 4 ? 3 : 1;
+  // ring rows: [0, NL) residual of colour c1 (row t), [NL, 2 NL) residual of colour c0 (row t - 1), then either the input
+  // row t + 1 (NL rows) or, PL, a ring of 4 coarse rows (slot = J & 3; NL rows each: [even half | odd half] x 32 cells):
+  // a coarse row serves 4 fine rows and is fetched ONCE, one new row every second step
+  constexpr int NLE = (NL + 1) & ~1;                       // two layer-rows per DMA instruction
+  constexpr int CB = 2 * NLE;                              // first coarse ring row
+  constexpr int LROWS = PL ? CB + 4 * NLE : 2 * ((3 * NL + 1) / 2);
+  __shared__ __align__(16) double ring_all[WPB][LROWS][64];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  double(*ring)[64] = ring_all[wv];
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if (p.remap) xcd_remap(bx, by);
+  const int kx0 = ((int)bx * WPB + wv) * OW - HL;
+  const int kx = kx0 + lane;
+  const int y0 = by * p.H, y1 = min(p.g.ny, y0 + p.H);
+  const int hk = p.g.hk, ny = p.g.ny, hp = p.g.hp;
+  const bool down = p.flip && (by & 1);
+  auto ph = [&](int t) -> int { return down ? y0 + y1 - 1 - t : t; };
+  const ptrdiff_t rp = p.g.rp;
+  const size_t ls = p.g.ls;
+  const int kxc = min(max(kx, -2), hk + 1);
+  const bool own_lane = lane >= HL && lane < 64 - HL && kx < hk;
+  const bool wallW = (p.walls & WALL_W) && kx0 < 0, wallE = (p.walls & WALL_E) && kx0 + 63 >= hk;  // wave-uniform
+  const bool wallS = (p.walls & WALL_S) != 0, wallN = (p.walls & WALL_N) != 0;
+  const double sqD = p.rc.sqD;
+  auto off = [&](int half, int r) -> ptrdiff_t { return (ptrdiff_t)(min(max(r, -1), ny) + 1) * rp + half * hp + MSOM_SP + kxc; };
+  // DMA side: lane j fetches the 16-byte piece (cells e, e + 1 of the half row) of layer-row 2 d + (j >> 5)
+  const int sub = lane >> 5;
+  const int epc = MSOM_SP + min(max(kx0 + 2 * (lane & 31), -2), hk);  // piece start inside the padded half row (doubles)
+  // wave-uniform row base of a field whose rows beyond the tile live in halo arrays; lstride = doubles per layer
+  auto rowbase = [&](const double *f, const double *fs, const double *fn, int half, int r, size_t &lstride) -> const double * {
+    if (r < 0 && fs) { lstride = p.hls; return fs + (ptrdiff_t)(max(r, -p.KR) + p.KR + 1) * rp + half * hp; }
+    if (r >= ny && fn) { lstride = p.hls; return fn + (ptrdiff_t)(min(r - ny, p.KR - 1) + 1) * rp + half * hp; }
+    lstride = ls;
+    return f + (ptrdiff_t)(min(max(r, -1), ny) + 1) * rp + half * hp;
+  };
+  auto dma16 = [&](const double *gsrc, int ldsrow) {
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)(&ring[ldsrow][0]));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+  };
+  const int c0 = 1 - p.c1;  // colour of the input values
+  // PL: coarse cell of this lane = column kx of the coarse level; the lane's 16-byte coarse piece: quarter q = lane >> 4
+  // = {row J, row J + cy} x {even half, odd half}, cells (kx0 >> 1) + 2 (lane & 15) (+1) of that half row
+  const int chp = p.cg.hp;
+  const ptrdiff_t crp = p.cg.rp;
+  const size_t cls = p.cg.ls;
+  // lanes 0-31 fetch layer 2 d, lanes 32-63 layer 2 d + 1; within each, lanes 0-15 the even half, 16-31 the odd half
+  const int cpc = ((lane >> 4) & 1) * chp + MSOM_SP + min((kx0 >> 1) + 2 * (lane & 15), (p.cg.nx >> 1) + MSOM_SP - 2);
+  const int cld = (lane & 1) * 32 + (lane >> 1);   // where the lane's own coarse cell sits in a 64-double coarse ring row
+  int cjA = -1000, cjB = -1000;                    // the two newest coarse rows in the ring (wave-uniform)
+  auto coarse_rows = [&](int r, bool &neg, int &J, int &cy) {
+    neg = false;
+    int rr = r;
+    if (r < 0) { rr = 0; neg = wallS; }
+    if (r >= ny) { rr = ny - 1; neg = wallN; }
+    J = rr >> 1;
+    cy = (rr & 1) ? 1 : -1;
+  };
+  // requests the rows of marching step t
+  auto request = [&](int t) {
+    size_t st[3];
+    const double *bp[3];
+    const int rn = ph(t + 1), ra = ph(t), rb = ph(t - 1);
+    const int t1 = (ra < 0 && !p.res_s) ? 0 : ((ra >= ny && !p.res_n) ? ny - 1 : ra);
+    const int t2 = (rb < 0 && !p.res_s) ? 0 : ((rb >= ny && !p.res_n) ? ny - 1 : rb);
+    bp[0] = rowbase(p.res, p.res_s, p.res_n, (ra + p.c1) & 1, t1, st[0]);
+    bp[1] = rowbase(p.res, p.res_s, p.res_n, (rb + c0) & 1, t2, st[1]);
+    if (!PL) bp[2] = rowbase(p.in, p.in_s, p.in_n, (rn + c0) & 1, rn, st[2]);
+    else { bp[2] = bp[1]; st[2] = st[1]; }
+    constexpr int NPLAIN = PL ? 2 * NL : 3 * NL;
+#pragma unroll
+    for (int d = 0; d < (NPLAIN + 1) / 2; d++) {
+      const int ra0 = 2 * d, ra1 = (2 * d + 1 < NPLAIN) ? 2 * d + 1 : NPLAIN - 1;   // an odd row count repeats the last row
+      const double *g0 = bp[ra0 / NL] + (size_t)(ra0 % NL) * st[ra0 / NL];
+      const double *g1 = bp[ra1 / NL] + (size_t)(ra1 % NL) * st[ra1 / NL];
+      dma16((sub ? g1 : g0) + epc, 2 * d);
+    }
+    static_assert(!PL || 2 * ((2 * NL + 1) / 2) <= CB, "residual rows end before the coarse ring");
+    if constexpr (PL) {
+      bool neg;
+      int J, cy;
+      coarse_rows(rn, neg, J, cy);
+      // the rows J and J + cy must be in the ring when step t reads it; in steady state one of them is new every second step
+      const int first = down ? max(J, J + cy) : min(J, J + cy), second = down ? min(J, J + cy) : max(J, J + cy);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int Jn = q ? second : first;
+        if (Jn == cjA || Jn == cjB) continue;
+        cjB = cjA; cjA = Jn;
+        const double *cb = p.coarse + (ptrdiff_t)(Jn + 1) * crp + cpc;
+        const int slot = (Jn + 4) & 3;
+#pragma unroll
+        for (int d = 0; d < NLE / 2; d++) {
+          const int la = min(2 * d + sub, NL - 1);
+          dma16(cb + (size_t)la * cls, CB + slot * NLE + 2 * d);
+        }
+      }
+    }
+  };
+  // PL: colour-c0 cells of fine row r, interpolated from the two coarse rows (prolong_pt, kernels_mg.hip); a0 / a1 = the
+  // lane's coarse cell in rows J / J + cy.  Ghost rows / columns of the prolongated field are -P(wall cell).
+  auto prolong_vals = [&](int r, int half, const double (&A0)[NL], const double (&A1)[NL], double (&dst)[NL]) {
+    const bool neg = (r < 0 && wallS) || (r >= ny && wallN);
+    const bool gw = !neg && wallW && half == 1, ge = !neg && wallE && half == 0;
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      const double a0 = A0[l], a1 = A1[l];
+      const double b0 = half ? lane_above(a0) : lane_below(a0), b1 = half ? lane_above(a1) : lane_below(a1);
+      double v = BILINEAR(a0, b0, a1, b1);
+      if (neg) v = -v;
+      if (gw | ge) {
+        const double o0 = half ? lane_below(a0) : lane_above(a0), o1 = half ? lane_below(a1) : lane_above(a1);
+        const double po = BILINEAR(a0, o0, a1, o1);
+        const double gv = gw ? -lane_above(po) : -lane_below(po);
+        if (gw ? kx == -1 : kx == hk) v = gv;
+      }
+      dst[l] = v;
+    }
+  };
+
+  double W[K][3][NL];
+#pragma unroll
+  for (int s = 0; s < K; s++)
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int l = 0; l < NL; l++) W[s][q][l] = 0.;
+  double R1[D1][NL], R2[D2][NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+#pragma unroll
+    for (int d = 0; d < D1; d++) R1[d][l] = 0.;
+#pragma unroll
+    for (int d = 0; d < D2; d++) R2[d][l] = 0.;
+  }
+  const int tA = y0 - K + 1, tB = y1 + K - 2;
+  request(tA);
+  // rows y0 - K and y0 - K + 1 of the input fill the first window (plain loads, once per chunk)
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int r = ph(y0 - K + q);
+    if constexpr (PL) {
+      bool neg;
+      int J, cy;
+      coarse_rows(r, neg, J, cy);
+      const int Ic = min(max(kx, -1), p.cg.nx);
+      const ptrdiff_t coff = (Ic & 1) * chp + MSOM_SP + (Ic >> 1);
+      const double *c0p = p.coarse + (ptrdiff_t)(J + 1) * crp + coff, *c1p = p.coarse + (ptrdiff_t)(J + cy + 1) * crp + coff;
+      double A0[NL], A1[NL];
+#pragma unroll
+      for (int l = 0; l < NL; l++) { A0[l] = c0p[l * cls]; A1[l] = c1p[l * cls]; }
+      prolong_vals(r, (r + c0) & 1, A0, A1, W[0][q + 1]);
+    } else {
+      size_t st;
+      const double *src = rowbase(p.in, p.in_s, p.in_n, (r + c0) & 1, r, st) + MSOM_SP + kxc;
+#pragma unroll
+      for (int l = 0; l < NL; l++) W[0][q + 1][l] = src[l * st];
+    }
+  }
+  for (int t = tA; t <= tB; t++) {
+    if (WPB > 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the rows requested one step ago (and the stores issued since)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < K; s++)
+#pragma unroll
+      for (int l = 0; l < NL; l++) { W[s][0][l] = W[s][1][l]; W[s][1][l] = W[s][2][l]; }
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+#pragma unroll
+      for (int d = D1 - 1; d > 0; d--) R1[d][l] = R1[d - 1][l];
+#pragma unroll
+      for (int d = D2 - 1; d > 0; d--) R2[d][l] = R2[d - 1][l];
+    }
+    double A0[PL ? NL : 1], A1[PL ? NL : 1];
+    int sJ0 = 0, sJ1 = 0;
+    if constexpr (PL) {
+      bool neg;
+      int J, cy;
+      coarse_rows(ph(t + 1), neg, J, cy);
+      sJ0 = (J + 4) & 3; sJ1 = (J + cy + 4) & 3;
+    }
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      R1[0][l] = ring[l][lane];
+      R2[0][l] = ring[NL + l][lane];
+      if constexpr (!PL) W[0][2][l] = ring[2 * NL + l][lane];
+      else { A0[l] = ring[CB + sJ0 * NLE + l][cld]; A1[l] = ring[CB + sJ1 * NLE + l][cld]; }
+    }
+    // the ring is free again once these reads have returned: the next step's rows have this whole step to arrive
+    if (t < tB && !(p.dbg & 2)) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+      asm volatile("" ::: "memory");
+      request(t + 1);
+    }
+    if constexpr (PL) prolong_vals(ph(t + 1), (ph(t + 1) + c0) & 1, A0, A1, W[0][2]);
+#pragma unroll
+    for (int s = 1; s <= K; s++) {
+      const int r = ph(t - (s - 1));             // row of half-sweep s
+      const int px = (r + p.c1 + s - 1) & 1;     // x parity (= half) of its cells in that row
+      double x[NL];
+      if (wallS && r == -1) {
+#pragma unroll
+        for (int l = 0; l < NL; l++) x[l] = -W[s - 1][down ? 0 : 2][l];
+      } else if (wallN && r == ny) {
+#pragma unroll
+        for (int l = 0; l < NL; l++) x[l] = -W[s - 1][down ? 2 : 0][l];
+      } else {
+        double rhs[NL], rs[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) rs[l] = (s & 1) ? R1[(s - 1) < D1 ? (s - 1) : 0][l] : R2[(s - 2) >= 0 && (s - 2) < D2 ? (s - 2) : 0][l];
+        if (px) {
+#pragma unroll
+          for (int l = 0; l < NL; l++) {
+            const double a = W[s - 1][1][l];
+            double v = -sqD * rs[l];
+            v += lane_above(a) + a;
+            v += W[s - 1][2][l] + W[s - 1][0][l];
+            rhs[l] = v;
+          }
+        } else {
+#pragma unroll
+          for (int l = 0; l < NL; l++) {
+            const double a = W[s - 1][1][l];
+            double v = -sqD * rs[l];
+            v += a + lane_below(a);
+            v += W[s - 1][2][l] + W[s - 1][0][l];
+            rhs[l] = v;
+          }
+        }
+#pragma unroll
+        for (int l = 1; l < NL; l++) rhs[l] -= p.rc.w[l] * rhs[l - 1];
+        x[NL - 1] = rhs[NL - 1] * p.rc.it1[NL - 1];
+#pragma unroll
+        for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - p.rc.t2[l] * x[l + 1]) * p.rc.it1[l];
+        if (wallW && px == 1) {
+#pragma unroll
+          for (int l = 0; l < NL; l++) {
+            const double gv = -lane_above(W[s - 1][1][l]);
+            if (kx == -1) x[l] = gv;
+          }
+        }
+        if (wallE && px == 0) {
+#pragma unroll
+          for (int l = 0; l < NL; l++) {
+            const double gv = -lane_below(W[s - 1][1][l]);
+            if (kx == hk) x[l] = gv;
+          }
+        }
+      }
+      if (s < K) {
+#pragma unroll
+        for (int l = 0; l < NL; l++) W[s][2][l] = x[l];
+      }
+      if (s >= K - 1 && r >= y0 && r < y1 && own_lane && !(p.dbg & 1)) {  // the last update of each colour is what the level keeps
+        double *dst = p.out + off(px, r);
+#pragma unroll
+        for (int l = 0; l < NL; l++) dst[l * ls] = x[l];
+        const int i = 2 * kx + px;
+        if (i == 0 || i == p.g.nx - 1 || r == 0 || r == ny - 1) {
+#pragma unroll
+          for (int l = 0; l < NL; l++) split_write_ghosts(p.out, p.g, l, r, i, x[l], p.walls);
+        }
+      }
+    }
+  }
+}
+
 int g_march_remap = 1;  // XCD-contiguous block numbering (option march_xcd)
 int g_march_flip = 1;   // odd chunks march down (option march_flip)
 
@@ -282,7 +580,7 @@ int g_march_flip = 1;   // odd chunks march down (option march_flip)
 // rounds 0.55.  Rule: the largest whole number of rounds (<= 3) whose chunks still have >= 20 rows (2 K of them are
 // re-computed), at least one round; never below 16 rows.
 template <typename Kern>
-static void march_launch(hipStream_t st, Kern kern, MarchArgs a, int ow, int chunk_rows) {
+static void march_launch(hipStream_t st, Kern kern, MarchArgs a, int ow, int chunk_rows, int nthreads = 64) {
   const int strips = (a.g.hk + ow - 1) / ow;
   int H = chunk_rows;
   if (H <= 0) {
@@ -299,7 +597,7 @@ static void march_launch(hipStream_t st, Kern kern, MarchArgs a, int ow, int chu
         hipDeviceProp_t pr;
         if (hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
         if (ncu <= 0) ncu = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, nthreads, 0) != hipSuccess || per_cu <= 0) per_cu = 512 / nthreads;
         cache[{dev, (const void *)kern}] = {per_cu, ncu};
       } else {
         per_cu = it->second.first;
@@ -317,11 +615,40 @@ static void march_launch(hipStream_t st, Kern kern, MarchArgs a, int ow, int chu
     if (H < 16) H = 16;
   }
   a.H = H;
-  hipLaunchKernelGGL(kern, dim3(strips, (a.g.ny + H - 1) / H), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(kern, dim3(strips, (a.g.ny + H - 1) / H), dim3(nthreads), 0, st, a);
 }
+
+int g_march_dbg = 0;    // timing experiments (option march_dbg)
+int g_march_dma = 2;    // LDS-DMA version of the pass (option march_dma: 0 register-window kernel, 1 one strip, 2 four strips per workgroup)
 
 template <int NL>
 static int march_dispatch(hipStream_t st, const MarchArgs &a, int K, int rows) {
+  if (g_march_dma && !a.psi_out && !(K == 4 && NL > 6) && !(a.coarse && NL > 6)) {
+    // 1: one strip per workgroup; 2 (default): four adjacent strips per workgroup, marching in step, for the plain pass
+    // (the pass with the prolongation measured faster with one: 7.09 vs 7.25 ms per RK2 step); 3: four for both
+    constexpr int NLS = NL;
+    const bool four = a.coarse ? g_march_dma >= 3 : g_march_dma >= 2;
+#define MARCH_DMA_K(KK)                                                                                                      \
+    if (a.coarse) {                                                                                                          \
+      if (four) march_launch(st, k_relax_march_dma<NLS, KK, 4, 4, true>, a, 56 * 4, rows, 256);                                \
+      else march_launch(st, k_relax_march_dma<NLS, KK, 4, 1, true>, a, 56, rows, 64);                                          \
+    } else if (four) march_launch(st, k_relax_march_dma<NLS, KK, 2, 4, false>, a, 60 * 4, rows, 256);                          \
+    else march_launch(st, k_relax_march_dma<NLS, KK, 2, 1, false>, a, 60, rows, 64);                                           \
+    return 0;
+    if constexpr (NL <= 6) {
+      switch (K) {
+        case 2: if (!a.coarse) { MARCH_DMA_K(2) } break;
+        case 3: { MARCH_DMA_K(3) }
+        case 4: { MARCH_DMA_K(4) }
+      }
+    } else {
+      switch (K) {
+        case 2: { MARCH_DMA_K(2) }
+        case 3: { MARCH_DMA_K(3) }
+      }
+    }
+#undef MARCH_DMA_K
+  }
   switch (K) {
     case 2:
       if (a.psi_out) march_launch(st, k_relax_march<NL, 2, false, true>, a, 62, rows);
@@ -354,7 +681,8 @@ int launch_relax_march(hipStream_t st, const double *in, double *out, const doub
   a.hls = h ? h->ls : 0; a.KR = h ? h->rows : 0;
   extern int g_march_remap;
   extern int g_march_flip;
-  a.in = in; a.out = out; a.res = res; a.g = sg; a.c1 = c1; a.walls = walls; a.rc = rc; a.remap = g_march_remap; a.flip = g_march_flip;
+  extern int g_march_dbg;
+  a.in = in; a.out = out; a.res = res; a.g = sg; a.c1 = c1; a.walls = walls; a.rc = rc; a.remap = g_march_remap; a.flip = g_march_flip; a.dbg = g_march_dbg;
   if (nl >= 7 && K > 3) return -1;  // 4 windows of 7 or 8 layers do not fit 256 VGPRs
   switch (nl) {
     case 2: return march_dispatch<2>(st, a, K, chunk_rows);

@@ -106,7 +106,7 @@ struct msom {
   int march_min = 24;    // log2 of the cell-layers a level needs for the chained pass
   int march_correct = 0; // the last pass of the finest level writes psi + da instead of da; measured neutral (the pass runs at 4.3 TB/s, the post-cycle pass it relieves at 5.8): off
   int corr_req = 0, corr_done = 0;  // set around mg_cycle_levels by mg_solve / by the pass that did it
-  int march_prolong = 0; // whole levels: prolongation folded into the first pass (4 + 4 half-sweeps); measured 3 % slower than (red + prolongation) + 4 + 3
+  int march_prolong = 1; // whole levels: prolongation folded into the first pass ((PL + 4) + 4 half-sweeps; coarse rows by LDS-DMA, kernels_march.hip): 7.63 -> 7.09 ms per step at 4096^2 x 6
   int mg_fused = 1;  // fused residual+restriction and correction+residual passes of the multigrid cycle
   double *psi_alt = nullptr;  // second psi buffer (the fused correction writes out of place)
   int rhs_variant = 6;  // 6: one layer per wavefront, register windows (kernels_lpw.hip, default); 1: LDS tiles, software-pipelined; 0: LDS tiles, phase by phase
@@ -133,6 +133,7 @@ struct msom {
   // profiling of the finest-level smoother sweep
   int profile = 0;
   ProfSlot prof_sweep, prof_resid, prof_block, prof_march[5];  // prof_march[K]: passes of K chained half-sweeps
+  ProfSlot prof_march_pl;  // first pass of a level with the prolongation folded in
   ProfSlot prof_rhs, prof_redprol, prof_rescorr, prof_respre;   // tendency pass, finest red+prolongation, post- / pre-cycle residual passes
 };
 
@@ -591,7 +592,7 @@ extern "C" int msom_destroy(msom_t *m) {
   if (m->d_scal) hipFree(m->d_scal);
   if (m->h_scal) hipHostFree(m->h_scal);
   if (m->d_wind) hipFree(m->d_wind);
-  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4], &m->prof_rhs, &m->prof_redprol, &m->prof_rescorr, &m->prof_respre})
+  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4], &m->prof_rhs, &m->prof_redprol, &m->prof_rescorr, &m->prof_respre, &m->prof_march_pl})
     for (auto e : ps->ev) hipEventDestroy(e);
   if (m->comm) comm_destroy(m->comm);
   if (m->ev_c2x) hipEventDestroy(m->ev_c2x);
@@ -627,6 +628,8 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "march_correct")) m->march_correct = (int)v;
   else if (!strcmp(key, "march_xcd")) { extern int g_march_remap; g_march_remap = (int)v; }
   else if (!strcmp(key, "march_flip")) { extern int g_march_flip; g_march_flip = (int)v; }
+  else if (!strcmp(key, "march_dma")) { extern int g_march_dma; g_march_dma = (int)v; }
+  else if (!strcmp(key, "march_dbg")) { extern int g_march_dbg; g_march_dbg = (int)v; }
   else if (!strcmp(key, "march_k")) m->march_k = (int)v < 2 ? 2 : ((int)v > 4 ? 4 : (int)v);
   else if (!strcmp(key, "block_sweeps")) { m->block_sweeps = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "mg_global_sum")) m->mg_global_sum = (int)v;
@@ -1059,9 +1062,9 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
       // the fly), so the 2 nrelax half-sweeps are 4 + 4 instead of (red + prolongation) + 4 + 3
       int K = n < kmax ? n : kmax;
       if (n - K == 1 && K > 3) K--;
-      if (prof) prof_begin(m, m->prof_march[K]);
+      if (prof) prof_begin(m, m->prof_march_pl);
       if (launch_relax_march(m->st, nullptr, *L.da_alt, L.res, *L.sg, nl, *L.rc, 0, K, L.walls, g_march_rows, nullptr, *coarse->da, coarse->sg)) m->sticky = MSOM_ERR_ARG;
-      if (prof) prof_end(m, m->prof_march[K]);
+      if (prof) prof_end(m, m->prof_march_pl);
       std::swap(*L.da, *L.da_alt);
       n -= K; c = K & 1;
     } else if (coarse && n > 0) {
@@ -2299,14 +2302,14 @@ extern "C" int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, doubl
 
 extern "C" int msom_profile_reset(msom_t *m) {
   if (!m) return MSOM_ERR_ARG;
-  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4], &m->prof_rhs, &m->prof_redprol, &m->prof_rescorr, &m->prof_respre}) { ps->used = 0; ps->total_ms = 0; ps->launches = 0; }
+  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4], &m->prof_rhs, &m->prof_redprol, &m->prof_rescorr, &m->prof_respre, &m->prof_march_pl}) { ps->used = 0; ps->total_ms = 0; ps->launches = 0; }
   return MSOM_OK;
 }
 extern "C" int msom_profile_read(msom_t *m, const char *kernel, double *avg_ms, long *launches) {
   if (!m || !kernel) return MSOM_ERR_ARG;
   ProfSlot *ps = !strcmp(kernel, "sweep") ? &m->prof_sweep : !strcmp(kernel, "residual") ? &m->prof_resid : !strcmp(kernel, "block2") ? &m->prof_block :
                  !strcmp(kernel, "march2") ? &m->prof_march[2] : !strcmp(kernel, "march3") ? &m->prof_march[3] : !strcmp(kernel, "march4") ? &m->prof_march[4] :
-                 !strcmp(kernel, "rhs") ? &m->prof_rhs : !strcmp(kernel, "red_prolong") ? &m->prof_redprol : !strcmp(kernel, "resid_correct") ? &m->prof_rescorr :
+                 !strcmp(kernel, "march_pl") ? &m->prof_march_pl : !strcmp(kernel, "rhs") ? &m->prof_rhs : !strcmp(kernel, "red_prolong") ? &m->prof_redprol : !strcmp(kernel, "resid_correct") ? &m->prof_rescorr :
                  !strcmp(kernel, "resid_restrict") ? &m->prof_respre : nullptr;
   if (!ps) { msom_set_error("unknown kernel %s", kernel); return MSOM_ERR_ARG; }
   prof_collect(m, *ps);
