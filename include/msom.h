@@ -248,7 +248,14 @@ enum {
   MSOMN_DQ = 9,    /* updates                                                              */
   MSOMN_QPRED = 10,/* predictor                                                            */
   MSOMN_QFORC3D = 11, /* q_forcing_3d (-DFORCING_3D, qg_baroclinic_ms.h:25,179-185): added to every layer once set */
-  MSOMN_NFIELDS = 12
+  /* surface-QG variant (params key sqg = 1): the finished parts of qg-node/sqg_baroclinic_ms.h -- comp_stretch with the
+   * surface buoyancy :77-98, idh0[0] = 1/dh[0] :502, S2 of the surface = f/N2[0] :545, tmp boundary rule :64-67,
+   * laplacian(bs) in both dissipation operators :160-201.  That file stops at "TODO: STOPPED HERE" (:222) and does not
+   * compile; bs is therefore a prescribed field (its tendency rhs_bs is unfinished there), comp_q / invert_q are completed
+   * consistently with comp_stretch */
+  MSOMN_BS = 12,   /* bs        surface buoyancy, 1 layer                                  */
+  MSOMN_S2S = 13,  /* S2 of the surface: N2[0] before, f/N2[0] after set_const, 1 layer    */
+  MSOMN_NFIELDS = 14
 };
 typedef struct msomn msomn_t;
 

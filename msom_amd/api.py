@@ -456,7 +456,7 @@ def trash_vars_bfn():
     return None
 
 
-NODE_FIELDS = dict(PSI=0, Q=1, ZETA=2, TMP=3, PSIPG=4, S2=5, TOPO=6, QFORC=7, MASK=8, DQ=9, QPRED=10, QFORC3D=11)
+NODE_FIELDS = dict(PSI=0, Q=1, ZETA=2, TMP=3, PSIPG=4, S2=5, TOPO=6, QFORC=7, MASK=8, DQ=9, QPRED=10, QFORC3D=11, BS=12, S2S=13)
 
 
 class NodeQG:

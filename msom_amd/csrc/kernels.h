@@ -139,6 +139,10 @@ void launch_n_mul_mask(hipStream_t st, double *a, double *b, const double *mk, c
 void launch_n_del2(hipStream_t st, const double *in, double *out, const NatGeom &g, int nl, double add, double fac, double D);
 void launch_n_stretch(hipStream_t st, const double *in, double *out, const double *S2, const NatGeom &g, int nl, double add, double fac,
                       const LayerCoef &lc);
+void launch_n_stretch_sqg(hipStream_t st, const double *in, const double *bs, const double *S2S, double *out, const double *S2, const NatGeom &g, int nl,
+                          double add, double fac, const LayerCoef &lc);
+void launch_n_lap_bs(hipStream_t st, const double *bs, double *out, const NatGeom &g, double D);
+void launch_n_sqg_rhs(hipStream_t st, const double *q, const double *S2S, const double *bs, double *qeff, const NatGeom &g, int nl, double idh00);
 void launch_n_rhs_main(hipStream_t st, const double *psi, const double *zeta, const double *pg, const double *S2, const double *topo, double *dq,
                        const NatGeom &g, int nl, int have_pg, int have_topo, double D, double beta, double drag, double f0, double dhb, const LayerCoef &lc);
 void launch_n_axpy(hipStream_t st, double *dq, const double *x, const NatGeom &g, int nl, double c);

@@ -130,6 +130,53 @@ void launch_n_stretch(hipStream_t st, const double *in, double *out, const doubl
   hipLaunchKernelGGL(k_n_stretch, grid2d(g.nx, g.ny), block2d(), 0, st, in, out, S2, g, nl, add, fac, lc);
 }
 
+// comp_stretch(psi, bs, stretch, add, fac) of the surface-QG variant, sqg_baroclinic_ms.h:77-98.  S2 there has nl layers
+// with layer 0 at the surface: its S2[] / S2[0,0,1] of layer l are S2S / S2[0] for l = 0 and S2[l-1] / S2[l] below.
+__global__ void k_n_stretch_sqg(const double *__restrict__ in, const double *__restrict__ bs, const double *__restrict__ S2S, double *out,
+                                const double *__restrict__ S2, NatGeom g, int nl, double add, double fac, LayerCoef lc) {
+  VTX(g, i, j);
+  const size_t c0 = nat_idx(g, 0, j, i);
+  double pm = 0., pc = in[c0], pp = 0., s0 = 0., s1 = 0.;
+  for (int l = 0; l < nl; l++) {
+    const size_t c = c0 + (size_t)l * g.ls;
+    if (l < nl - 1) { pp = in[c + g.ls]; s1 = S2[c]; }
+    double v;
+    if (l == 0) v = fac * (S2S[c0] * bs[c0] * lc.idh0[0] - s1 * (pc - pp) * lc.idh1[l]);
+    else if (l < nl - 1) v = fac * (s0 * (pm - pc) * lc.idh0[l] - s1 * (pc - pp) * lc.idh1[l]);
+    else v = fac * (-s0 * (pc - pm)) * lc.idh0[l];
+    out[c] = add == 0. ? v : add * out[c] + v;
+    pm = pc; pc = pp; s0 = s1;
+  }
+}
+void launch_n_stretch_sqg(hipStream_t st, const double *in, const double *bs, const double *S2S, double *out, const double *S2, const NatGeom &g, int nl,
+                          double add, double fac, const LayerCoef &lc) {
+  hipLaunchKernelGGL(k_n_stretch_sqg, grid2d(g.nx, g.ny), block2d(), 0, st, in, bs, S2S, out, S2, g, nl, add, fac, lc);
+}
+// del2_bs of sqg_baroclinic_ms.h:160-168: laplacian(bs) on the inner vertices, neumann(0) on the four sides (the boundary
+// vertex takes the first interior value, x sides first, so a corner takes the diagonal neighbour)
+__global__ void k_n_lap_bs(const double *__restrict__ bs, double *out, NatGeom g, double D) {
+  VTX(g, i, j);
+  const int n = g.nx - 1;
+  const int ii = i == 0 ? 1 : (i == n ? n - 1 : i), jj = j == 0 ? 1 : (j == n ? n - 1 : j);
+  const size_t c = nat_idx(g, 0, jj, ii);
+  const double D2 = D * D;
+  out[nat_idx(g, 0, j, i)] = DIVC(LAPN(bs, c, g.pitch), D2, 1. / D2);
+}
+void launch_n_lap_bs(hipStream_t st, const double *bs, double *out, const NatGeom &g, double D) {
+  hipLaunchKernelGGL(k_n_lap_bs, grid2d(g.nx, g.ny), block2d(), 0, st, bs, out, g, D);
+}
+// right-hand side of the surface-QG inversion: q with the known surface term of the top layer removed
+__global__ void k_n_sqg_rhs(const double *__restrict__ q, const double *__restrict__ S2S, const double *__restrict__ bs, double *qeff, NatGeom g, int nl,
+                            double idh00) {
+  VTX(g, i, j);
+  size_t k = nat_idx(g, 0, j, i);
+  qeff[k] = q[k] - S2S[k] * bs[k] * idh00;
+  for (int l = 1; l < nl; l++) { k += g.ls; qeff[k] = q[k]; }
+}
+void launch_n_sqg_rhs(hipStream_t st, const double *q, const double *S2S, const double *bs, double *qeff, const NatGeom &g, int nl, double idh00) {
+  hipLaunchKernelGGL(k_n_sqg_rhs, grid2d(g.nx, g.ny), block2d(), 0, st, q, S2S, bs, qeff, g, nl, idh00);
+}
+
 // advective part of rhs_pv_baroclinic, qg_baroclinic_ms.h:116-155
 struct NRhsArgs {
   const double *psi, *zeta, *pg, *S2, *topo;

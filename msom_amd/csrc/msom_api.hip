@@ -101,6 +101,7 @@ struct msom {
   int stochastic = 0, corrector_step = 0, noise_mode = 0;
   int prolong_fused = 1;  // first red half-sweep of a level interpolates its neighbours from the coarser level
   int block_sweeps = 0;  // experimental temporally blocked smoother (2 sweeps per pass); measured not faster at nl = 6
+  int block_small = 0;   // the same kernel on the launch-bound levels only (not marched, <= block_small cells wide): 2 launches per level visit instead of 8
   int march = 1;         // chained half-sweeps in register windows (kernels_march.hip) on wide single-GPU levels
   int march_k = 4;       // at most this many half-sweeps per pass (2..4)
   int march_min = 24;    // log2 of the cell-layers a level needs for the chained pass
@@ -631,6 +632,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "march_dma")) { extern int g_march_dma; g_march_dma = (int)v; }
   else if (!strcmp(key, "march_dbg")) { extern int g_march_dbg; g_march_dbg = (int)v; }
   else if (!strcmp(key, "march_k")) m->march_k = (int)v < 2 ? 2 : ((int)v > 4 ? 4 : (int)v);
+  else if (!strcmp(key, "block_small")) m->block_small = (int)v;
   else if (!strcmp(key, "block_sweeps")) { m->block_sweeps = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "mg_global_sum")) m->mg_global_sum = (int)v;
   else if (!strcmp(key, "agglomerate")) { m->agglomerate = (int)v; if (m->const_set) return build_coefs(m); }
@@ -1007,7 +1009,8 @@ static Lev glob_lev(msom *m, int k) {
 
 // can the level use the temporally blocked smoother (k_relax_block: 2 sweeps per pass)?
 static bool block_ok(msom *m, const Lev &L) {
-  return m->block_sweeps && m->uniformS && !L.tiled && !(m->walls & WALL_PER) && L.sg->nx >= 64 && L.sg->ny >= 16;
+  const bool want = m->block_sweeps || (m->block_small && L.sg->nx <= m->block_small);
+  return want && m->uniformS && !L.tiled && !(m->walls & WALL_PER) && L.sg->nx >= 64 && L.sg->ny >= 16;
 }
 // can the level chain its half-sweeps in registers (k_relax_march)?  One GPU (no halo exchange between half-sweeps),
 // walls, uniform S, and a level big enough to be HBM-bound: a marching wavefront pays one memory latency per row, which

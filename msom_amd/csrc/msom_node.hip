@@ -45,6 +45,8 @@ struct msomn {
   // stochastic forcing (-D_STOCHASTIC of the reference): cell-scalar noise n_stoch, wavelet-filtered (qg-node/qg_stochastic.h)
   int stochastic = 0, corrector_step = 0, cnlev = 0;
   int forcing_3d = 0;  // -DFORCING_3D: switched on by setting MSOMN_QFORC3D
+  int sqg = 0;         // surface-QG variant (params key sqg): sqg_baroclinic_ms.h:77-98,502,545-547
+  double *qeff = nullptr, *d2bs = nullptr;  // sqg scratch: rhs of the inversion, laplacian(bs)
   std::vector<NatGeom> cg;
   std::vector<double *> cs, cr, csig;  // cs[0] = n_stoch
   int tiled_relax = 0;  // option: LDS-tiled smoother passes (1-2 sweeps per pass) on the wide levels; measured 3 % faster at 4097^2 x 3, 7 % slower at 2049^2 x 3
@@ -76,7 +78,7 @@ static int dalloc(double **p, size_t n) {
   return MSOM_OK;
 }
 static int field_layers(const msomn *m, int f) {
-  return f == MSOMN_S2 ? m->nlm : (f == MSOMN_TOPO || f == MSOMN_QFORC || f == MSOMN_MASK) ? 1 : m->nl;
+  return f == MSOMN_S2 ? m->nlm : (f == MSOMN_TOPO || f == MSOMN_QFORC || f == MSOMN_MASK || f == MSOMN_BS || f == MSOMN_S2S) ? 1 : m->nl;
 }
 
 // [layers][n+1][n+1] contiguous (host or device) <-> padded natural layout
@@ -112,6 +114,8 @@ extern "C" void msomn_destroy(msomn_t *m) {
     if (m->cr[k]) (void)hipFree(m->cr[k]);
     if (m->csig[k]) (void)hipFree(m->csig[k]);
   }
+  if (m->qeff) (void)hipFree(m->qeff);
+  if (m->d2bs) (void)hipFree(m->d2bs);
   if (m->d_scal) (void)hipFree(m->d_scal);
   if (m->partial) (void)hipFree(m->partial);
   if (m->d_row) (void)hipFree(m->d_row);
@@ -154,8 +158,13 @@ static int node_alloc(msomn *m) {
   for (size_t j = 0; j < n1; j++) for (size_t i = 0; i < n1; i++) h[j * n1 + i] = (i == 0 || j == 0 || i == n1 - 1 || j == n1 - 1) ? 0. : 1.;
   if ((r = upload_g(m, m->f[MSOMN_MASK], m->g, 1, h.data()))) return r;
   if (m->nl > 1) {
-    for (int l = 0; l < m->nlm; l++) for (size_t k = 0; k < n1 * n1; k++) h[l * n1 * n1 + k] = m->p.N2[l];
+    // sqg: N2 = [surface, interfaces ...]; S2 layers 1..nl-1 of sqg_baroclinic_ms.h are the interfaces below layers 0..nl-2
+    for (int l = 0; l < m->nlm; l++) for (size_t k = 0; k < n1 * n1; k++) h[l * n1 * n1 + k] = m->p.N2[l + (m->sqg ? 1 : 0)];
     if ((r = upload_g(m, m->f[MSOMN_S2], m->g, m->nlm, h.data()))) return r;
+    if (m->sqg) {
+      for (size_t k = 0; k < n1 * n1; k++) h[k] = m->p.N2[0];
+      if ((r = upload_g(m, m->f[MSOMN_S2S], m->g, 1, h.data())) || (r = dalloc(&m->qeff, m->g.ls * m->nl)) || (r = dalloc(&m->d2bs, m->g.ls))) return r;
+    }
   }
   return MSOM_OK;
 }
@@ -164,6 +173,7 @@ static msomn *node_create(const NodeParams &p, const char *text) {
   if (p.nl < 1 || p.nl > MSOM_MAXNL) { msom_set_error("nl = %d outside the supported range 1..%d", p.nl, MSOM_MAXNL); return nullptr; }
   if (p.N < 2 || (p.N & (p.N - 1))) { msom_set_error("N = %d must be a power of two >= 2", p.N); return nullptr; }
   if (p.bc_fac == -1) { msom_set_error("bc_fac = -1 (periodic vertex grid) is not supported"); return nullptr; }
+  if (p.sqg && p.nl < 2) { msom_set_error("sqg = 1 needs nl >= 2 (qg-node/sqg_baroclinic_ms.h is the multi-layer model)"); return nullptr; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
     msom_set_error("no HIP device available: libmsomhip has no CPU fallback");
@@ -173,6 +183,7 @@ static msomn *node_create(const NodeParams &p, const char *text) {
   m->p = p;
   if (text) m->params_text = text;
   m->N = p.N; m->nl = p.nl; m->nlm = p.nl > 1 ? p.nl - 1 : 1;
+  m->sqg = p.sqg != 0;
   m->D = p.L0 / p.N;
   m->tolerance = p.TOLERANCE;
   m->g = node_geom(p.N);
@@ -229,6 +240,7 @@ extern "C" double msomn_get_param(msomn_t *m, const char *k) {
   if (!strcmp(k, "nlevels")) return m->nlev;
   if (!strcmp(k, "iRd2_low")) return m->iRd2_low;
   if (!strcmp(k, "bc_fac")) return m->p.bc_fac;
+  if (!strcmp(k, "sqg")) return m->sqg;
   if (!strncmp(k, "idh0_", 5)) { int l = atoi(k + 5); return l >= 0 && l < MSOM_MAXNL ? m->lc.idh0[l] : NAN; }
   if (!strncmp(k, "idh1_", 5)) { int l = atoi(k + 5); return l >= 0 && l < MSOM_MAXNL ? m->lc.idh1[l] : NAN; }
   return NAN;
@@ -253,7 +265,8 @@ extern "C" int msomn_get_field(msomn_t *m, int f, double *a) {
 static double bcc(const msomn *m) { return 2 * m->p.bc_fac / (m->D * m->D); }
 static void bnd_psi(msomn *m) { launch_n_bnd_const(m->st, m->f[MSOMN_PSI], m->g, m->nl, m->psi_bc); }
 static void bnd_q(msomn *m, double *q) { launch_n_bnd_from(m->st, q, m->f[MSOMN_PSI], m->g, m->nl, bcc(m), 0, m->psi_bc); }
-static void bnd_tmp(msomn *m) { launch_n_bnd_from(m->st, m->f[MSOMN_TMP], m->f[MSOMN_ZETA], m->g, m->nl, bcc(m), 1, 0.); }
+// sqg_baroclinic_ms.h:64-67: the tmp rule subtracts psi_bc instead of the boundary value of zeta
+static void bnd_tmp(msomn *m) { launch_n_bnd_from(m->st, m->f[MSOMN_TMP], m->f[MSOMN_ZETA], m->g, m->nl, bcc(m), m->sqg ? 0 : 1, m->sqg ? m->psi_bc : 0.); }
 
 static int read_scalar(msomn *m, int slot, double *out) {
   HIPCHK(hipMemcpyAsync(m->h_scal + slot, m->d_scal + slot, sizeof(double), hipMemcpyDeviceToHost, m->st));
@@ -267,7 +280,9 @@ static int comp_q(msomn *m, const double *psi, double *q) {
   if (m->nl == 1) launch_n_helm(m->st, psi, q, m->g, m->D, m->iRd2_low);
   else {
     launch_n_del2(m->st, psi, q, m->g, m->nl, 0., 1., m->D);
-    launch_n_stretch(m->st, psi, q, m->f[MSOMN_S2], m->g, m->nl, 1., 1., m->lc);
+    // sqg: the reference's comp_q_baroclinic (:232-243) still calls the 4-argument comp_stretch; completed with bs
+    if (m->sqg) launch_n_stretch_sqg(m->st, psi, m->f[MSOMN_BS], m->f[MSOMN_S2S], q, m->f[MSOMN_S2], m->g, m->nl, 1., 1., m->lc);
+    else launch_n_stretch(m->st, psi, q, m->f[MSOMN_S2], m->g, m->nl, 1., 1., m->lc);
   }
   bnd_q(m, q);
   HIPCHK(hipGetLastError());
@@ -289,12 +304,16 @@ static int rhs_pv(msomn *m, double *q, double *dq) {
   launch_n_del2(m->st, psi, zeta, m->g, nl, 0., 1., m->D);                      // comp_del2(psi, zeta, 0, 1)
   bnd_q(m, zeta);
   launch_n_rhs_main(m->st, psi, zeta, m->f[MSOMN_PSIPG], S2, m->f[MSOMN_TOPO], dq, m->g, nl, 1, 1, m->D, p.beta, drag, p.f0, p.dh[nl - 1], m->lc);
-  launch_n_stretch(m->st, zeta, dq, S2, m->g, nl, 1., p.nu, m->lc);            // :160
+  if (m->sqg) {                                                                 // sqg_baroclinic_ms.h:160-174: del2_bs = laplacian(bs)
+    launch_n_lap_bs(m->st, m->f[MSOMN_BS], m->d2bs, m->g, m->D);
+    launch_n_stretch_sqg(m->st, zeta, m->d2bs, m->f[MSOMN_S2S], dq, S2, m->g, nl, 1., p.nu, m->lc);
+  } else launch_n_stretch(m->st, zeta, dq, S2, m->g, nl, 1., p.nu, m->lc);      // :160
   launch_n_del2(m->st, zeta, tmp, m->g, nl, 0., 1.0, m->D);                     // :162 + boundary(tmp)
   bnd_tmp(m);
   launch_n_axpy(m->st, dq, tmp, m->g, nl, p.nu);                               // :164-167
   const double minus_nu4 = -p.nu4;
-  launch_n_stretch(m->st, tmp, dq, S2, m->g, nl, 1., minus_nu4, m->lc);        // :172
+  if (m->sqg) launch_n_stretch_sqg(m->st, tmp, m->d2bs, m->f[MSOMN_S2S], dq, S2, m->g, nl, 1., minus_nu4, m->lc);   // del4_bs is laplacian(bs) again, :187-201
+  else launch_n_stretch(m->st, tmp, dq, S2, m->g, nl, 1., minus_nu4, m->lc);   // :172
   launch_n_del2(m->st, tmp, dq, m->g, nl, 1., minus_nu4, m->D);                 // :173
   launch_n_add2d(m->st, dq, m->f[MSOMN_QFORC], m->g);                           // :176-180 surface forcing
   if (m->forcing_3d) launch_n_axpy(m->st, dq, m->f[MSOMN_QFORC3D], m->g, nl, 1.);   // :179-185 (FORCING_3D)
@@ -365,7 +384,12 @@ static int vpoisson(msomn *m, double *a, const double *b) {
   return MSOM_OK;
 }
 static int invert_q(msomn *m, double *q) {
-  int r = vpoisson(m, m->f[MSOMN_PSI], q);
+  const double *b = q;
+  if (m->sqg) {  // the known surface term of the top layer moves to the right-hand side (completion, see include/msom.h)
+    launch_n_sqg_rhs(m->st, q, m->f[MSOMN_S2S], m->f[MSOMN_BS], m->qeff, m->g, m->nl, m->lc.idh0[0]);
+    b = m->qeff;
+  }
+  int r = vpoisson(m, m->f[MSOMN_PSI], b);
   if (r) return r;
   bnd_psi(m);
   bnd_q(m, q);
@@ -512,7 +536,8 @@ extern "C" int msomn_set_const(msomn_t *m) {
     for (int l = 0; l < nl; l++) if (p.dh[l] == 0.) { msom_set_error("thickness = 0: check the definition of dh in params.in"); return MSOM_ERR_CONFIG; }
     double dhc[MSOM_MAXNL];
     for (int l = 0; l < nl - 1; l++) dhc[l] = 0.5 * (p.dh[l] + p.dh[l + 1]);
-    m->lc.idh0[0] = 0.; m->lc.idh1[0] = 1. / (dhc[0] * p.dh[0]);
+    m->lc.idh0[0] = m->sqg ? 1. / p.dh[0] : 0.;  // sqg_baroclinic_ms.h:502 "surface layer: 1/h"
+    m->lc.idh1[0] = 1. / (dhc[0] * p.dh[0]);
     for (int l = 1; l < nl - 1; l++) { m->lc.idh0[l] = 1. / (dhc[l - 1] * p.dh[l]); m->lc.idh1[l] = 1. / (dhc[l] * p.dh[l]); }
     m->lc.idh0[nl - 1] = 1. / (dhc[nl - 2] * p.dh[nl - 1]); m->lc.idh1[nl - 1] = 0.;
     // S2: N^2 -> f^2 / N^2 with f = f0 + flag_ms beta (y - L0/2)  (qg_baroclinic_ms.h:501-505); init-time host pass
@@ -523,6 +548,15 @@ extern "C" int msomn_set_const(msomn_t *m) {
       for (size_t i = 0; i < n1; i++) { double &s = h[(l * n1 + j) * n1 + i]; s = f * f / s; }
     }
     if ((r = upload_g(m, m->f[MSOMN_S2], m->g, m->nlm, h.data()))) return r;
+    if (m->sqg) {  // :545 surface layer: f / N^2 (f, not f^2)
+      std::vector<double> hs(n1 * n1);
+      if ((r = download_g(m, m->f[MSOMN_S2S], m->g, 1, hs.data()))) return r;
+      for (size_t j = 0; j < n1; j++) {
+        const double f = p.f0 + p.flag_ms * p.beta * (j * m->D - 0.5 * p.L0);
+        for (size_t i = 0; i < n1; i++) hs[j * n1 + i] = f / hs[j * n1 + i];
+      }
+      if ((r = upload_g(m, m->f[MSOMN_S2S], m->g, 1, hs.data()))) return r;
+    }
     if (p.scale_topo != 1.) {
       std::vector<double> tp(n1 * n1);
       if ((r = download_g(m, m->f[MSOMN_TOPO], m->g, 1, tp.data()))) return r;

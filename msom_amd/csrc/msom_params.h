@@ -43,6 +43,7 @@ void msom_set_error(const char *fmt, ...);
  * qg-node/qg.h:104-127,164 and qg.c:61-66 */
 struct NodeParams {
   int N, nl, flag_ms;
+  int sqg; /* 1: surface-QG variant, the finished parts of qg-node/sqg_baroclinic_ms.h (N2 then has nl entries, N2[0] = surface) */
   double L0, f0, beta, nu, nu4, hEkb, gp_low, scale_topo, tau0, tau1, tf1, tf2, dy_ws, forc_mode, noise_init;
   double Lfmax, Lfmin, fac_filt_Rd, dtflt, bc_fac, DT, tend, dtout, CFL, TOLERANCE, dtdiag;
   double amp_stoch, L_filt; /* -D_STOCHASTIC keys, qg-node/qg.c:104-107 */

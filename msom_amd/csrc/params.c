@@ -133,7 +133,7 @@ void msom_params_derive(struct Params *p) {
  * line rules as above: blanks removed, split at '=', atoi/atof, arrays [a,b,c]) */
 #define KN(name, type, member) { name, type, offsetof(struct NodeParams, member) }
 static const keydef NODE_KEYS[] = {
-  KN("N", T_INT, N), KN("nl", T_INT, nl), KN("flag_ms", T_INT, flag_ms), KN("L0", T_DBL, L0), KN("f0", T_DBL, f0),
+  KN("N", T_INT, N), KN("nl", T_INT, nl), KN("flag_ms", T_INT, flag_ms), KN("sqg", T_INT, sqg), KN("L0", T_DBL, L0), KN("f0", T_DBL, f0),
   KN("beta", T_DBL, beta), KN("nu", T_DBL, nu), KN("nu4", T_DBL, nu4), KN("hEkb", T_DBL, hEkb), KN("gp_low", T_DBL, gp_low),
   KN("scale_topo", T_DBL, scale_topo), KN("tau0", T_DBL, tau0), KN("tau1", T_DBL, tau1), KN("tf1", T_DBL, tf1), KN("tf2", T_DBL, tf2),
   KN("dy_ws", T_DBL, dy_ws), KN("forc_mode", T_DBL, forc_mode), KN("noise_init", T_DBL, noise_init), KN("Lfmax", T_DBL, Lfmax),

@@ -25,7 +25,12 @@
 #define ORN_MAXNL 16
 
 enum { ORN_PSI = 0, ORN_Q, ORN_ZETA, ORN_TMP, ORN_PSIPG, ORN_S2 /* nl-1 */, ORN_TOPO /* 1 */, ORN_QFORC /* 1 */, ORN_MASK /* 1 */, ORN_DQ,
-       ORN_QPRED, ORN_QFORC3D /* q_forcing_3d, -DFORCING_3D, qg_baroclinic_ms.h:25,179-185 */, ORN_NFIELDS };
+       ORN_QPRED, ORN_QFORC3D /* q_forcing_3d, -DFORCING_3D, qg_baroclinic_ms.h:25,179-185 */,
+       /* surface-QG variant (params key sqg = 1), the finished parts of qg-node/sqg_baroclinic_ms.h */
+       ORN_BS /* bs: surface buoyancy, 1 layer (:77-86, argument `bs` of comp_stretch) */,
+       ORN_S2S /* S2 of the surface "layer": N2[0] before, f/N2[0] after set_const (:545), 1 layer */,
+       ORN_QEFF /* scratch: rhs of the elliptic problem = q minus the surface term */, ORN_D2BS /* scratch: laplacian(bs), :160-168 */,
+       ORN_NFIELDS };
 
 typedef struct { int n, nl; double *d; } vf; /* (n+3)^2 per layer: vertices -1..n+1 */
 #define VI(f, l, i, j) ((((size_t)(l) * ((f)->n + 3)) + (size_t)((j) + 1)) * ((f)->n + 3) + (size_t)((i) + 1))
@@ -34,7 +39,7 @@ typedef struct { int n, nl; double *d; } vf; /* (n+3)^2 per layer: vertices -1..
 typedef struct { int i; double resb, resa, sum; int nrelax; } orn_mgstats;
 
 typedef struct {
-  int N, nl, flag_ms;
+  int N, nl, flag_ms, sqg;
   double L0, f0, beta, hEkb, tau0, tau1, tf1, tf2, dy_ws, forc_mode, nu, nu4, gp_low, iRd2_low, scale_topo, bc_fac, psi_bc;
   double DT, tend, dtout, CFL, TOLERANCE, noise_init;
   double dh[ORN_MAXNL], N2[ORN_MAXNL], idh0[ORN_MAXNL], idh1[ORN_MAXNL];
@@ -73,7 +78,7 @@ orn_t *orn_create_str(const char *text) {
 #define KD(name, field) else if (!strcmp(k, name)) o->field = atof(v)
 #define KI(name, field) else if (!strcmp(k, name)) o->field = atoi(v)
     if (0) {}
-    KI("N", N); KI("nl", nl); KI("flag_ms", flag_ms); KD("L0", L0); KD("f0", f0); KD("beta", beta); KD("nu", nu); KD("nu4", nu4);
+    KI("N", N); KI("nl", nl); KI("flag_ms", flag_ms); KI("sqg", sqg); KD("L0", L0); KD("f0", f0); KD("beta", beta); KD("nu", nu); KD("nu4", nu4);
     KD("hEkb", hEkb); KD("gp_low", gp_low); KD("scale_topo", scale_topo); KD("tau0", tau0); KD("tau1", tau1); KD("tf1", tf1);
     KD("tf2", tf2); KD("dy_ws", dy_ws); KD("forc_mode", forc_mode); KD("noise_init", noise_init); KD("bc_fac", bc_fac); KD("DT", DT);
     KD("tend", tend); KD("dtout", dtout); KD("CFL", CFL); KD("TOLERANCE", TOLERANCE); KD("amp_stoch", amp_stoch); KD("L_filt", L_filt);
@@ -83,7 +88,9 @@ orn_t *orn_create_str(const char *text) {
   free(copy);
   if (o->nl < 1 || o->nl > ORN_MAXNL || o->N < 2 || (o->N & (o->N - 1))) { free(o); return NULL; }
   const int N = o->N, nl = o->nl, nlm = nl > 1 ? nl - 1 : 1;
-  for (int k = 0; k < ORN_NFIELDS; k++) vf_alloc(&o->f[k], N, (k == ORN_S2) ? nlm : (k == ORN_TOPO || k == ORN_QFORC || k == ORN_MASK) ? 1 : nl);
+  if (o->sqg && nl < 2) { free(o); return NULL; }
+  for (int k = 0; k < ORN_NFIELDS; k++)
+    vf_alloc(&o->f[k], N, (k == ORN_S2) ? nlm : (k == ORN_TOPO || k == ORN_QFORC || k == ORN_MASK || k == ORN_BS || k == ORN_S2S || k == ORN_D2BS) ? 1 : nl);
   int n = 0; while ((N >> n) >= 2) n++;
   o->nlev = n;
   o->da = (vf *)calloc(n, sizeof(vf)); o->res = (vf *)calloc(n, sizeof(vf)); o->mask = (vf *)calloc(n, sizeof(vf)); o->S2 = (vf *)calloc(n, sizeof(vf));
@@ -92,7 +99,10 @@ orn_t *orn_create_str(const char *text) {
   vf *mk = &o->f[ORN_MASK];
   for (int j = 0; j <= N; j++) for (int i = 0; i <= N; i++) W(mk, 0, i, j) = (i == 0 || i == N || j == 0 || j == N) ? 0. : 1.;
   /* S2[] = N2[l] (qg_baroclinic_ms.h:471-476) */
-  for (int l = 0; l < nl - 1; l++) for (int j = 0; j <= N; j++) for (int i = 0; i <= N; i++) W(&o->f[ORN_S2], l, i, j) = o->N2[l];
+  /* sqg: S2 has nl layers there, layer 0 = the surface (sqg_baroclinic_ms.h:519-523); its layers 1..nl-1 are the
+   * interfaces below layers 0..nl-2, i.e. exactly S2[0..nl-2] of the baroclinic model: N2 = [surface, interfaces...] */
+  for (int l = 0; l < nl - 1; l++) for (int j = 0; j <= N; j++) for (int i = 0; i <= N; i++) W(&o->f[ORN_S2], l, i, j) = o->N2[l + (o->sqg ? 1 : 0)];
+  if (o->sqg) for (int j = 0; j <= N; j++) for (int i = 0; i <= N; i++) W(&o->f[ORN_S2S], 0, i, j) = o->N2[0];
   { int c = 1; while ((N >> c) >= 1) c++; o->cnlev = c; /* Basilisk levels depth() ... 0 */
     o->cs = (double **)calloc(c, sizeof(double *)); o->cw = (double **)calloc(c, sizeof(double *)); o->csig = (double **)calloc(c, sizeof(double *));
     for (int k = 0; k < c; k++) { size_t sz = (size_t)((N >> k) + 2) * ((N >> k) + 2);
@@ -123,6 +133,7 @@ double orn_get_param(orn_t *o, const char *k) {
   if (!strcmp(k, "nlevels")) return o->nlev;
   if (!strcmp(k, "iRd2_low")) return o->iRd2_low;
   if (!strcmp(k, "bc_fac")) return o->bc_fac;
+  if (!strcmp(k, "sqg")) return o->sqg;
   if (!strcmp(k, "tend")) return o->tend;
   if (!strcmp(k, "dtout")) return o->dtout;
   if (!strncmp(k, "idh0_", 5)) return o->idh0[atoi(k + 5)];
@@ -166,7 +177,8 @@ static double bcc(const orn_t *o, int lev) { double D = o->L0 / (o->N >> lev); r
 /* boundary({psi}), boundary({q}), boundary({zeta}), boundary({tmp}) with set_bc_ms() in force */
 static void bnd_psi(orn_t *o) { bnd_const(&o->f[ORN_PSI], o->psi_bc); }
 static void bnd_q(orn_t *o, vf *q) { bnd_from(q, &o->f[ORN_PSI], bcc(o, 0), 0, o->psi_bc); }
-static void bnd_tmp(orn_t *o) { bnd_from(&o->f[ORN_TMP], &o->f[ORN_ZETA], bcc(o, 0), 1, 0.); }
+/* sqg_baroclinic_ms.h:64-67: the tmp rule subtracts psi_bc instead of the boundary value of zeta */
+static void bnd_tmp(orn_t *o) { bnd_from(&o->f[ORN_TMP], &o->f[ORN_ZETA], bcc(o, 0), o->sqg ? 0 : 1, o->sqg ? o->psi_bc : 0.); }
 
 /* ---------------------------------------------------------------- operators (qg-node/qg.h:176-190) */
 #define LAPN(p, l, i, j, D2) ((W(p, l, (i) + 1, j) + W(p, l, (i) - 1, j) + W(p, l, i, (j) + 1) + W(p, l, i, (j) - 1) - 4 * W(p, l, i, j)) / (D2))
@@ -203,6 +215,28 @@ static void comp_stretch(orn_t *o, vf *in, vf *out, double add, double fac) {
   }
 }
 
+/* comp_stretch(psi, bs, stretch, add, fac) of sqg_baroclinic_ms.h:77-98: S2 there has nl layers with layer 0 at the
+ * surface, so its S2[] / S2[0,0,1] of layer l are S2S / S2[0] for l = 0 and S2[l-1] / S2[l] below; idh0[0] = 1/dh[0] (:502) */
+static void comp_stretch_sqg(orn_t *o, vf *in, vf *bs, vf *out, double add, double fac) {
+  const int n = o->N, nl = o->nl; vf *S2 = &o->f[ORN_S2], *S2S = &o->f[ORN_S2S];
+  for (int j = 0; j <= n; j++) for (int i = 0; i <= n; i++) {
+    int l = 0;
+    W(out, l, i, j) = add * W(out, l, i, j) + fac * (W(S2S, 0, i, j) * W(bs, 0, i, j) * o->idh0[0] - W(S2, l, i, j) * (W(in, l, i, j) - W(in, l + 1, i, j)) * o->idh1[l]);
+    for (l = 1; l < nl - 1; l++)
+      W(out, l, i, j) = add * W(out, l, i, j) + fac * (W(S2, l - 1, i, j) * (W(in, l - 1, i, j) - W(in, l, i, j)) * o->idh0[l] - W(S2, l, i, j) * (W(in, l, i, j) - W(in, l + 1, i, j)) * o->idh1[l]);
+    l = nl - 1;
+    W(out, l, i, j) = add * W(out, l, i, j) + fac * (-W(S2, l - 1, i, j) * (W(in, l, i, j) - W(in, l - 1, i, j))) * o->idh0[l];
+  }
+}
+/* del2_bs / del4_bs of sqg_baroclinic_ms.h:160-168, 187-195: laplacian(bs) on every vertex, then neumann(0) on the four
+ * sides ([BASILISK RULE] a vertex-scalar BC writes the boundary vertex: it takes the first interior value; x sides first) */
+static void lap_bs(orn_t *o) {
+  const int n = o->N; const double D = o->L0 / n, D2 = D * D; vf *bs = &o->f[ORN_BS], *d = &o->f[ORN_D2BS];
+  for (int j = 0; j <= n; j++) for (int i = 0; i <= n; i++) W(d, 0, i, j) = LAPN(bs, 0, i, j, D2);
+  for (int j = 0; j <= n; j++) { W(d, 0, 0, j) = W(d, 0, 1, j); W(d, 0, n, j) = W(d, 0, n - 1, j); }
+  for (int i = 0; i <= n; i++) { W(d, 0, i, 0) = W(d, 0, i, 1); W(d, 0, i, n) = W(d, 0, i, n - 1); }
+}
+
 /* rhs_pv_baroclinic qg_baroclinic_ms.h:104-196 / rhs_pv_barotropic qg_barotropic.h:16-29 */
 static void rhs_pv(orn_t *o, vf *q, vf *dq) {
   const int n = o->N, nl = o->nl; const double D = o->L0 / n, D2 = D * D;
@@ -228,11 +262,13 @@ static void rhs_pv(orn_t *o, vf *q, vf *dq) {
     W(dq, l, i, j) = -jac(psi, l, zeta, l, i, j, D) - jac(pg, l, zeta, l, i, j, D) - W(S2, l - 1, i, j) * ju * o->idh0[l] - BETAV(psi, l, i, j);
     W(dq, l, i, j) += -o->hEkb * o->f0 / (2 * o->dh[nl - 1]) * W(zeta, l, i, j) - jac(psi, l, topo, 0, i, j, D) * o->f0 / o->dh[nl - 1];
   }
-  comp_stretch(o, zeta, dq, 1., o->nu);
+  if (o->sqg) { lap_bs(o); comp_stretch_sqg(o, zeta, &o->f[ORN_D2BS], dq, 1., o->nu); }   /* sqg_baroclinic_ms.h:160-174 */
+  else comp_stretch(o, zeta, dq, 1., o->nu);
   comp_del2(o, zeta, tmp, 0., 1.0, OUT_TMP);
   for (int l = 0; l < nl; l++) for (int j = 0; j <= n; j++) for (int i = 0; i <= n; i++) W(dq, l, i, j) += o->nu * W(tmp, l, i, j);
   const double minus_nu4 = -o->nu4;
-  comp_stretch(o, tmp, dq, 1., minus_nu4);
+  if (o->sqg) comp_stretch_sqg(o, tmp, &o->f[ORN_D2BS], dq, 1., minus_nu4);   /* del4_bs is laplacian(bs) again, :187-201 */
+  else comp_stretch(o, tmp, dq, 1., minus_nu4);
   comp_del2(o, tmp, dq, 1., minus_nu4, OUT_NONE);
   for (int j = 0; j <= n; j++) for (int i = 0; i <= n; i++) W(dq, 0, i, j) += W(qf, 0, i, j);
   if (o->forcing_3d) for (int l = 0; l < nl; l++) for (int j = 0; j <= n; j++) for (int i = 0; i <= n; i++) W(dq, l, i, j) += W(&o->f[ORN_QFORC3D], l, i, j);
@@ -246,7 +282,10 @@ static void comp_q(orn_t *o, vf *psi, vf *q) {
     for (int j = 0; j <= n; j++) for (int i = 0; i <= n; i++) W(q, 0, i, j) = LAPN(psi, 0, i, j, D2) - o->iRd2_low * W(psi, 0, i, j);
   } else {
     for (int l = 0; l < o->nl; l++) for (int j = 0; j <= n; j++) for (int i = 0; i <= n; i++) W(q, l, i, j) = LAPN(psi, l, i, j, D2);
-    comp_stretch(o, psi, q, 1., 1.);
+    /* sqg: the reference's comp_q_baroclinic (:232-243) still calls the 4-argument comp_stretch and does not compile;
+     * completed here with the surface buoyancy bs as the `bs` argument */
+    if (o->sqg) comp_stretch_sqg(o, psi, &o->f[ORN_BS], q, 1., 1.);
+    else comp_stretch(o, psi, q, 1., 1.);
   }
   bnd_q(o, q);
 }
@@ -361,6 +400,18 @@ static orn_mgstats vpoisson(orn_t *o, vf *a, vf *b) {
 }
 /* invert_q_baroclinic :217-225 / invert_q_barotropic qg_barotropic.h:45-54 */
 static void invert_q(orn_t *o, vf *q) {
+  if (o->sqg) {
+    /* the elliptic operator of relax_ / residual_baroclinic (sqg_baroclinic_ms.h:248-400) is the baroclinic one with the
+     * shifted S2 index and has no bs term; the reference passes q itself (:250, unfinished file).  Completed so that
+     * invert_q inverts comp_q: the known surface term S2S*bs*idh0[0] of the top layer moves to the right-hand side */
+    const int n = o->N; vf *e = &o->f[ORN_QEFF];
+    memcpy(e->d, q->d, (size_t)q->nl * (n + 3) * (n + 3) * sizeof(double));
+    for (int j = 0; j <= n; j++) for (int i = 0; i <= n; i++) W(e, 0, i, j) = W(q, 0, i, j) - W(&o->f[ORN_S2S], 0, i, j) * W(&o->f[ORN_BS], 0, i, j) * o->idh0[0];
+    o->mg = vpoisson(o, &o->f[ORN_PSI], e);
+    bnd_psi(o);
+    bnd_q(o, q);
+    return;
+  }
   o->mg = vpoisson(o, &o->f[ORN_PSI], q);
   bnd_psi(o);
   bnd_q(o, q);
@@ -442,13 +493,18 @@ void orn_set_const(orn_t *o) { /* qg-node/qg.h:465-524 + qg_baroclinic_ms.h:449-
   if (nl > 1) {
     double dhc[ORN_MAXNL];
     for (int l = 0; l < nl - 1; l++) dhc[l] = 0.5 * (o->dh[l] + o->dh[l + 1]);
-    o->idh0[0] = 0.; o->idh1[0] = 1. / (dhc[0] * o->dh[0]);
+    o->idh0[0] = o->sqg ? 1. / o->dh[0] : 0.; /* sqg_baroclinic_ms.h:502 "surface layer: 1/h" */
+    o->idh1[0] = 1. / (dhc[0] * o->dh[0]);
     for (int l = 1; l < nl - 1; l++) { o->idh0[l] = 1. / (dhc[l - 1] * o->dh[l]); o->idh1[l] = 1. / (dhc[l] * o->dh[l]); }
     o->idh0[nl - 1] = 1. / (dhc[nl - 2] * o->dh[nl - 1]); o->idh1[nl - 1] = 0.;
     /* S2: N^2 -> f^2/N^2 with f = f0 + flag_ms*beta*(y - L0/2), :501-505 (input: the field holds N^2) */
     for (int l = 0; l < nl - 1; l++) for (int j = 0; j <= N; j++) for (int i = 0; i <= N; i++) {
       const double f = o->f0 + o->flag_ms * o->beta * (j * D - 0.5 * o->L0);
       W(&o->f[ORN_S2], l, i, j) = f * f / W(&o->f[ORN_S2], l, i, j);
+    }
+    if (o->sqg) for (int j = 0; j <= N; j++) for (int i = 0; i <= N; i++) { /* :545 surface layer f/N^2 (f, not f^2) */
+      const double f = o->f0 + o->flag_ms * o->beta * (j * D - 0.5 * o->L0);
+      W(&o->f[ORN_S2S], 0, i, j) = f / W(&o->f[ORN_S2S], 0, i, j);
     }
     for (int j = 0; j <= N; j++) for (int i = 0; i <= N; i++) W(&o->f[ORN_TOPO], 0, i, j) *= o->scale_topo;
   } else if (o->gp_low != 0.) o->iRd2_low = o->f0 * o->f0 / (o->gp_low * o->dh[nl - 1]);

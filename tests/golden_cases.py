@@ -488,6 +488,28 @@ def case_node(make, inp, N, nl, bc_fac):
     return out
 
 
+def case_node_sqg(make, inp, N, nl):
+    """surface-QG option of the vertex model (params key sqg = 1): the finished parts of qg-node/sqg_baroclinic_ms.h
+    (:64-67, 77-98, 160-201, 502, 545) with a prescribed surface buoyancy"""
+    dh, N2 = NODE_LAYERS[nl]
+    txt = NODE_PARAMS.format(N=N, nl=nl, bc_fac=1.0, dh=dh, N2="[300.," + N2[1:]) + "sqg = 1\ntau1 = 5e-4\ntf1 = 0.3\ntf2 = 0.7\n"
+    m = make(txt, TOLERANCE=1e-9)
+    m.set("MASK", inp["in_mask"])
+    m.set("BS", inp["in_bs"])
+    m.set("PSI", inp["in_psi"])
+    m.set_const()
+    out = {"q_0": m.get("Q"), "S2S": m.get("S2S")}
+    out["invert_stats"] = m.invert_q()
+    out["psi_inverted"] = m.get("PSI")
+    m.rhs_pv()
+    out["rhs_dq"] = m.get("DQ")
+    m.set_tnext(0.11)
+    out["dt"] = np.array([m.step() for _ in range(5)])
+    out["psi_end"], out["q_end"] = m.get("PSI"), m.get("Q")
+    m.close()
+    return out
+
+
 def case_node_stochastic(make, inp, N):
     """-D_STOCHASTIC of the vertex model (qg-node/qg_stochastic.h:15-65, qg.h:306-320), serial rand() stream, srand(11)"""
     txt = NODE_PARAMS.format(N=N, nl=1, bc_fac=1.0, dh=NODE_LAYERS[1][0], N2=NODE_LAYERS[1][1]) + "amp_stoch = 0.3\nL_filt = 8.0\n"
@@ -502,7 +524,14 @@ def case_node_stochastic(make, inp, N):
     return out
 
 
+def sqg_inputs(N, nl, seed):
+    d = node_inputs(N, nl, seed)
+    x = np.arange(N + 1) / N
+    return {"in_mask": d["in_mask"], "in_psi": d["in_psi"], "in_bs": 0.3 * np.outer(np.sin(np.pi * x), np.sin(2 * np.pi * x))[None] + 0.05}
+
+
 NODE_CASES = {
+    "node_sqg_32x3": (case_node_sqg, dict(N=32, nl=3), lambda: sqg_inputs(32, 3, 204)),
     "node_island_32x3": (case_node, dict(N=32, nl=3, bc_fac=1.0), lambda: node_inputs(32, 3, 201)),
     "node_island_64x1": (case_node, dict(N=64, nl=1, bc_fac=0.5), lambda: node_inputs(64, 1, 202)),
     "node_stochastic_32x1": (case_node_stochastic, dict(N=32), lambda: {"in_psi": node_inputs(32, 1, 203)["in_psi"]}),

@@ -5,7 +5,7 @@ import numpy as np
 
 import orc
 
-PSI, Q, ZETA, TMP, PSIPG, S2, TOPO, QFORC, MASK, DQ, QPRED, QFORC3D = range(12)
+PSI, Q, ZETA, TMP, PSIPG, S2, TOPO, QFORC, MASK, DQ, QPRED, QFORC3D, BS, S2S = range(14)
 GS_LEX, GS_RB = 0, 1
 
 
