@@ -255,7 +255,8 @@ enum {
    * consistently with comp_stretch */
   MSOMN_BS = 12,   /* bs        surface buoyancy, 1 layer                                  */
   MSOMN_S2S = 13,  /* S2 of the surface: N2[0] before, f/N2[0] after set_const, 1 layer    */
-  MSOMN_NFIELDS = 14
+  MSOMN_PSIF = 14, /* psi_f     running mean of the part the wavelet filter removes (qg_baroclinic_ms.h:30,384) */
+  MSOMN_NFIELDS = 15
 };
 typedef struct msomn msomn_t;
 
@@ -302,6 +303,12 @@ int msomn_read_nc(msomn_t *m, int field, const char *path, const char *varname, 
  * <workdir>/outdir_%04d/, one stdout line per iteration; nsteps_max < 0: run to tend.
  * Returns the iteration count or < 0. */
 int msomn_run(msomn_t *m, const char *workdir, long nsteps_max);
+/* wavelet_filter of the vertex model, qg_baroclinic_ms.h:346-400 (event filter :405-408, driven by msomn_run when dtflt > 0):
+ * invert q, masked wavelet transform (qg-node/wavelet_vertex.h:10-46) of the cell average of psi scaled by sig_lev
+ * (:525-552; keys Lfmax, Lfmin, fac_filt_Rd), psi_f running mean, psi -= filtered part, q = comp_q(psi) */
+int msomn_wavelet_filter(msomn_t *m, double dtflt);
+int msomn_dbg_wv_get(msomn_t *m, int what /* 0 sig_lev, 1 mask_c */, int level, double *out /* [n][n], n = N >> level */);
+int msomn_dbg_wv_apply(msomn_t *m, const double *in, double *out /* cell fields [nl][N][N] */);
 /* multigrid pieces on level arrays [layer][n_k+1][n_k+1] (level 0 = finest), for the parity tests */
 int msomn_dbg_relax(msomn_t *m, int level, double *da, const double *res, int nsweeps);
 int msomn_dbg_residual(msomn_t *m, const double *a, const double *b, double *res, double *maxres);

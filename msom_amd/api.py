@@ -131,6 +131,9 @@ def load_library(strict=False):
         "msomn_dbg_del2_zeta": (ci, [vp]),
         "msomn_dbg_noise": (ci, [vp, vp, ci, vp]),
         "msomn_dbg_csig": (ci, [vp, ci, vp]),
+        "msomn_wavelet_filter": (ci, [vp, cd]),
+        "msomn_dbg_wv_get": (ci, [vp, ci, ci, vp]),
+        "msomn_dbg_wv_apply": (ci, [vp, vp, vp]),
     }
     for fn, (res, args) in sig.items():
         f = getattr(L, fn)  # AttributeError if the library does not export a declared symbol
@@ -456,7 +459,7 @@ def trash_vars_bfn():
     return None
 
 
-NODE_FIELDS = dict(PSI=0, Q=1, ZETA=2, TMP=3, PSIPG=4, S2=5, TOPO=6, QFORC=7, MASK=8, DQ=9, QPRED=10, QFORC3D=11, BS=12, S2S=13)
+NODE_FIELDS = dict(PSI=0, Q=1, ZETA=2, TMP=3, PSIPG=4, S2=5, TOPO=6, QFORC=7, MASK=8, DQ=9, QPRED=10, QFORC3D=11, BS=12, S2S=13, PSIF=14)
 
 
 class NodeQG:
@@ -629,4 +632,20 @@ class NodeQG:
         n = self.N >> k
         out = np.empty((n, n))
         self._chk(self.L.msomn_dbg_csig(self.h, k, _ptr(out)))
+        return out
+
+    # wavelet filter of the vertex model (qg_baroclinic_ms.h:346-400)
+    def wavelet_filter(self, dtflt):
+        self._chk(self.L.msomn_wavelet_filter(self.h, dtflt))
+
+    def wv_get(self, what, k):
+        n = self.N >> k
+        out = np.empty((n, n))
+        self._chk(self.L.msomn_dbg_wv_get(self.h, what, k, _ptr(out)))
+        return out
+
+    def wv_apply(self, cells):
+        cells = _f64(cells, (self.nl, self.N, self.N))
+        out = np.empty_like(cells)
+        self._chk(self.L.msomn_dbg_wv_apply(self.h, _ptr(cells), _ptr(out)))
         return out

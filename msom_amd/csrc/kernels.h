@@ -130,6 +130,12 @@ void launch_wv_restrict(hipStream_t st, const double *f, const NatGeom &fg, doub
 void launch_wv_recon(hipStream_t st, const double *s, const double *sc, const double *rc, const double *sig, double *out, const NatGeom &fg,
                      const NatGeom &cg, int nl);
 void launch_wv_root(hipStream_t st, const double *s, const double *sig, double *r, const NatGeom &g, int nl);
+void launch_wv_recon_m(hipStream_t st, const double *s, const double *sc, const double *rc, const double *sig, const double *mc, double *out,
+                       const NatGeom &fg, const NatGeom &cg, int nl);
+void launch_wv_root_m(hipStream_t st, const double *s, const double *sig, const double *mc, double *r, const NatGeom &g, int nl);
+void launch_wv_vert2cell(hipStream_t st, const double *v, const NatGeom &vg, double *c, const NatGeom &cg, int nl);
+void launch_wv_vertex_update(hipStream_t st, double *psi, double *psif, const double *c, const double *mask, const NatGeom &vg, const NatGeom &cg, int nl,
+                             double dtflt, int nbar, int update_mean);
 void launch_wv_qof(hipStream_t st, double *qof, double *q, const double *tmp, const NatGeom &g, int nl, double dtflt, int nbar, int restore);
 
 // ---- kernels_node.hip (vertex-grid variant, qg-node/)

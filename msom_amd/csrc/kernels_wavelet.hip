@@ -76,3 +76,71 @@ __global__ void k_wv_qof(double *qof, double *q, const double *__restrict__ tmp,
 void launch_wv_qof(hipStream_t st, double *qof, double *q, const double *tmp, const NatGeom &g, int nl, double dtflt, int nbar, int restore) {
   hipLaunchKernelGGL(k_wv_qof, grid2d(g.nx, g.ny), dim3(BX, BY), 0, st, qof, q, tmp, g, nl, dtflt, nbar, restore);
 }
+
+// ---- masked transform pair of the vertex model: wavelet_mask / inverse_wavelet_mask, qg-node/wavelet_vertex.h:10-46, with the
+// scaling by sig_lev in between (qg_baroclinic_ms.h:373-376):
+//   w_k = ((s_k - bilinear(s_{k+1})) * mask_c_k) * sig_k,   r_k = (bilinear(r_{k+1}) + w_k) * mask_c_k
+//   root: r = ((s * mask_c) * sig) * mask_c
+__global__ void k_wv_recon_m(const double *s, const double *__restrict__ sc, const double *__restrict__ rc, const double *__restrict__ sig,
+                             const double *__restrict__ mc, double *out, NatGeom fg, NatGeom cg, int nl) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= fg.nx || j >= fg.ny) return;
+  const int cx = (i & 1) ? 1 : -1, cyp = (j & 1) ? cg.pitch : -cg.pitch;
+  const double sg = sig[nat_idx(fg, 0, j, i)], mk = mc[nat_idx(fg, 0, j, i)];
+  for (int l = 0; l < nl; l++) {
+    const size_t k = nat_idx(fg, l, j, i), kc = nat_idx(cg, l, j >> 1, i >> 1);
+    double d = s[k];
+    d -= bilin(sc, kc, cx, cyp);
+    d = d * mk;
+    const double w = d * sg;
+    double r = bilin(rc, kc, cx, cyp);
+    r += w;
+    out[k] = r * mk;
+  }
+}
+void launch_wv_recon_m(hipStream_t st, const double *s, const double *sc, const double *rc, const double *sig, const double *mc, double *out,
+                       const NatGeom &fg, const NatGeom &cg, int nl) {
+  hipLaunchKernelGGL(k_wv_recon_m, grid2d(fg.nx, fg.ny), dim3(BX, BY), 0, st, s, sc, rc, sig, mc, out, fg, cg, nl);
+}
+__global__ void k_wv_root_m(const double *__restrict__ s, const double *__restrict__ sig, const double *__restrict__ mc, double *r, NatGeom g, int nl) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  const double sg = sig[nat_idx(g, 0, j, i)], mk = mc[nat_idx(g, 0, j, i)];
+  for (int l = 0; l < nl; l++) {
+    double w = s[nat_idx(g, l, j, i)] * mk;
+    w = w * sg;
+    r[nat_idx(g, l, j, i)] = w * mk;
+  }
+}
+void launch_wv_root_m(hipStream_t st, const double *s, const double *sig, const double *mc, double *r, const NatGeom &g, int nl) {
+  hipLaunchKernelGGL(k_wv_root_m, grid2d(g.nx, g.ny), dim3(BX, BY), 0, st, s, sig, mc, r, g, nl);
+}
+// cell average of a vertex field (qg_baroclinic_ms.h:369-370): cell (i, j) <- vertices (i, j), (i+1, j), (i, j+1), (i+1, j+1)
+__global__ void k_wv_vert2cell(const double *__restrict__ v, NatGeom vg, double *c, NatGeom cg, int nl) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= cg.nx || j >= cg.ny) return;
+  for (int l = 0; l < nl; l++) {
+    const size_t k = nat_idx(vg, l, j, i);
+    c[nat_idx(cg, l, j, i)] = 0.25 * (v[k] + v[k + 1] + v[k + vg.pitch] + v[k + 1 + vg.pitch]);
+  }
+}
+void launch_wv_vert2cell(hipStream_t st, const double *v, const NatGeom &vg, double *c, const NatGeom &cg, int nl) {
+  hipLaunchKernelGGL(k_wv_vert2cell, grid2d(cg.nx, cg.ny), dim3(BX, BY), 0, st, v, vg, c, cg, nl);
+}
+// :381-386: psi_loc = vertex average of the filtered cell field (ghost cells: dirichlet), psi_f running mean, psi = (psi - psi_loc) mask
+__global__ void k_wv_vertex_update(double *psi, double *psif, const double *__restrict__ c, const double *__restrict__ mask, NatGeom vg, NatGeom cg, int nl,
+                                   double dtflt, int nbar, int update_mean) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  if (i >= vg.nx || j >= vg.ny) return;
+  const double mk = mask[nat_idx(vg, 0, j, i)];
+  for (int l = 0; l < nl; l++) {
+    const size_t kc = nat_idx(cg, l, j, i), k = nat_idx(vg, l, j, i);
+    const double psi_loc = 0.25 * (c[kc] + c[kc - 1] + c[kc - cg.pitch] + c[kc - 1 - cg.pitch]);
+    if (update_mean) psif[k] = (psif[k] * nbar + psi_loc / dtflt) / (nbar + 1);
+    psi[k] = (psi[k] - psi_loc) * mk;
+  }
+}
+void launch_wv_vertex_update(hipStream_t st, double *psi, double *psif, const double *c, const double *mask, const NatGeom &vg, const NatGeom &cg, int nl,
+                             double dtflt, int nbar, int update_mean) {
+  hipLaunchKernelGGL(k_wv_vertex_update, grid2d(vg.nx, vg.ny), dim3(BX, BY), 0, st, psi, psif, c, mask, vg, cg, nl, dtflt, nbar, update_mean);
+}

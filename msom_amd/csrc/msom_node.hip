@@ -47,6 +47,10 @@ struct msomn {
   int forcing_3d = 0;  // -DFORCING_3D: switched on by setting MSOMN_QFORC3D
   int sqg = 0;         // surface-QG variant (params key sqg): sqg_baroclinic_ms.h:77-98,502,545-547
   double *qeff = nullptr, *d2bs = nullptr;  // sqg scratch: rhs of the inversion, laplacian(bs)
+  // wavelet filter of the vertex model (qg_baroclinic_ms.h:346-400): cell pyramids of s, r (nl layers), sig_lev, mask_c
+  std::vector<NatGeom> wg;
+  std::vector<double *> ws, wr, wsig, wmc;
+  int wv_ready = 0, nbar = 0;
   std::vector<NatGeom> cg;
   std::vector<double *> cs, cr, csig;  // cs[0] = n_stoch
   int tiled_relax = 0;  // option: LDS-tiled smoother passes (1-2 sweeps per pass) on the wide levels; measured 3 % faster at 4097^2 x 3, 7 % slower at 2049^2 x 3
@@ -78,6 +82,7 @@ static int dalloc(double **p, size_t n) {
   return MSOM_OK;
 }
 static int field_layers(const msomn *m, int f) {
+  if (f == MSOMN_PSIF) return m->nl;
   return f == MSOMN_S2 ? m->nlm : (f == MSOMN_TOPO || f == MSOMN_QFORC || f == MSOMN_MASK || f == MSOMN_BS || f == MSOMN_S2S) ? 1 : m->nl;
 }
 
@@ -114,6 +119,8 @@ extern "C" void msomn_destroy(msomn_t *m) {
     if (m->cr[k]) (void)hipFree(m->cr[k]);
     if (m->csig[k]) (void)hipFree(m->csig[k]);
   }
+  for (auto *v : {&m->ws, &m->wr, &m->wsig, &m->wmc})
+    for (double *q : *v) if (q) (void)hipFree(q);
   if (m->qeff) (void)hipFree(m->qeff);
   if (m->d2bs) (void)hipFree(m->d2bs);
   if (m->d_scal) (void)hipFree(m->d_scal);
@@ -526,6 +533,136 @@ extern "C" int msomn_dbg_csig(msomn_t *m, int level, double *out) {
   return MSOM_OK;
 }
 
+// ---- wavelet filter of the vertex model: wavelet_filter qg_baroclinic_ms.h:346-400, sig_lev / mask_c :525-578,
+// wavelet_mask / inverse_wavelet_mask qg-node/wavelet_vertex.h:10-46 (the transform runs on the CELL average of psi)
+static int wv_setup(msomn *m) {
+  const NodeParams &p = m->p;
+  int r;
+  if (m->wg.empty()) {
+    int c = 1;
+    while ((m->N >> c) >= 1) c++;
+    m->wg.resize(c); m->ws.assign(c, nullptr); m->wr.assign(c, nullptr); m->wsig.assign(c, nullptr); m->wmc.assign(c, nullptr);
+    for (int k = 0; k < c; k++) {
+      m->wg[k] = cell_geom(m->N >> k);
+      if ((r = dalloc(&m->ws[k], m->wg[k].ls * m->nl)) || (r = dalloc(&m->wr[k], m->wg[k].ls * m->nl)) || (r = dalloc(&m->wsig[k], m->wg[k].ls)) ||
+          (r = dalloc(&m->wmc[k], m->wg[k].ls)))
+        return r;
+    }
+  }
+  const int K = (int)m->wg.size(), N = m->N;
+  const size_t n1 = N + 1;
+  // sig_lev :527-552 (low pass only): a vertex scalar read at the cell with the same index
+  std::vector<double> s2;
+  if (p.fac_filt_Rd > 0) {
+    if (m->nl < 2) { msom_set_error("fac_filt_Rd > 0 needs the stratification S2 (nl >= 2)"); return MSOM_ERR_CONFIG; }
+    s2.resize(n1 * n1 * m->nlm);
+    if ((r = download_g(m, m->f[MSOMN_S2], m->g, m->nlm, s2.data()))) return r;
+  }
+  std::vector<std::vector<double>> sl(K);
+  for (int k = 0; k < K; k++) {
+    const int n = N >> k, fx = 2 * n;
+    const double Delta = p.L0 / n;
+    sl[k].resize((size_t)n * n);
+    for (int j = 0; j < n; j++)
+      for (int i = 0; i < n; i++) {
+        double ref_flag = 0;
+        if (k > 0) {
+          ref_flag += sl[k - 1][(size_t)(2 * j) * fx + 2 * i]; ref_flag += sl[k - 1][(size_t)(2 * j + 1) * fx + 2 * i];
+          ref_flag += sl[k - 1][(size_t)(2 * j) * fx + 2 * i + 1]; ref_flag += sl[k - 1][(size_t)(2 * j + 1) * fx + 2 * i + 1];
+        }
+        double v;
+        if (ref_flag > 0) v = 1;
+        else {
+          double L2;
+          if (p.fac_filt_Rd > 0) L2 = fmin(p.fac_filt_Rd * p.dh[0] / sqrt(s2[((size_t)j << k) * n1 + ((size_t)i << k)]), p.Lfmax);
+          else L2 = p.Lfmax + (j * Delta / p.L0) * (p.Lfmin - p.Lfmax);
+          if (L2 > 2 * Delta) v = 0;
+          else if (L2 <= 2 * Delta && L2 > Delta) v = 1 - (L2 - Delta) / Delta;
+          else v = 1;
+        }
+        sl[k][(size_t)j * n + i] = v;
+      }
+    const NatGeom &g = m->wg[k];
+    HIPCHK(hipMemcpy2DAsync(m->wsig[k] + nat_idx(g, 0, 0, 0), g.pitch * sizeof(double), sl[k].data(), g.nx * sizeof(double), g.nx * sizeof(double), g.ny,
+                            hipMemcpyHostToDevice, m->st));
+  }
+  HIPCHK(hipStreamSynchronize(m->st));
+  // mask_c :567-575: cell average of the vertex mask, restricted to every level
+  launch_wv_vert2cell(m->st, m->f[MSOMN_MASK], m->g, m->wmc[0], m->wg[0], 1);
+  for (int k = 1; k < K; k++) launch_wv_restrict(m->st, m->wmc[k - 1], m->wg[k - 1], m->wmc[k], m->wg[k], 1);
+  HIPCHK(hipGetLastError());
+  m->wv_ready = 1;
+  return MSOM_OK;
+}
+// ws[0] <- inverse_wavelet_mask(sig_lev * wavelet_mask(ws[0])), all layers at once; dirichlet(0) ghost cells on every level
+static int wv_masked_apply(msomn *m) {
+  const int K = (int)m->wg.size(), nl = m->nl;
+  auto bc = [&](double *f, const NatGeom &g) { launch_fill_ghost(m->st, f, g, nl, BC_DIRICHLET0, WALL_ALL); };
+  bc(m->ws[0], m->wg[0]);
+  for (int k = 1; k < K; k++) {
+    launch_wv_restrict(m->st, m->ws[k - 1], m->wg[k - 1], m->ws[k], m->wg[k], nl);
+    bc(m->ws[k], m->wg[k]);
+  }
+  if (K == 1) launch_wv_root_m(m->st, m->ws[0], m->wsig[0], m->wmc[0], m->ws[0], m->wg[0], nl);
+  else {
+    launch_wv_root_m(m->st, m->ws[K - 1], m->wsig[K - 1], m->wmc[K - 1], m->wr[K - 1], m->wg[K - 1], nl);
+    bc(m->wr[K - 1], m->wg[K - 1]);
+  }
+  for (int k = K - 2; k >= 0; k--) {
+    double *out = k == 0 ? m->ws[0] : m->wr[k];
+    launch_wv_recon_m(m->st, m->ws[k], m->ws[k + 1], m->wr[k + 1], m->wsig[k], m->wmc[k], out, m->wg[k], m->wg[k + 1], nl);
+    bc(out, m->wg[k]);
+  }
+  HIPCHK(hipGetLastError());
+  return MSOM_OK;
+}
+static int invert_q(msomn *m, double *q);
+static int comp_q(msomn *m, const double *psi, double *q);
+extern "C" int msomn_wavelet_filter(msomn_t *m, double dtflt) {
+  NEED_NCONST(m);
+  int r;
+  if (!m->wv_ready && (r = wv_setup(m))) return r;
+  if ((r = invert_q(m, m->f[MSOMN_Q]))) return r;
+  launch_wv_vert2cell(m->st, m->f[MSOMN_PSI], m->g, m->ws[0], m->wg[0], m->nl);
+  if ((r = wv_masked_apply(m))) return r;
+  if (m->p.Lfmax < 1e30)  // `if (Lfmax < HUGE)`, :380
+    launch_wv_vertex_update(m->st, m->f[MSOMN_PSI], m->f[MSOMN_PSIF], m->ws[0], m->f[MSOMN_MASK], m->g, m->wg[0], m->nl, dtflt, m->nbar, 1);
+  launch_n_bnd_const(m->st, m->f[MSOMN_PSI], m->g, m->nl, m->psi_bc);
+  if ((r = comp_q(m, m->f[MSOMN_PSI], m->f[MSOMN_Q]))) return r;
+  m->nbar++;
+  HIPCHK(hipStreamSynchronize(m->st));
+  return MSOM_OK;
+}
+// what = 0: sig_lev as used at the cells, 1: mask_c; level k, out [n][n]
+extern "C" int msomn_dbg_wv_get(msomn_t *m, int what, int level, double *out) {
+  NEED_NCONST(m);
+  int r;
+  if (!m->wv_ready && (r = wv_setup(m))) return r;
+  if (level < 0 || level >= (int)m->wg.size() || !out) { msom_set_error("bad level %d", level); return MSOM_ERR_ARG; }
+  const NatGeom &g = m->wg[level];
+  const double *src = what ? m->wmc[level] : m->wsig[level];
+  HIPCHK(hipMemcpy2DAsync(out, g.nx * sizeof(double), src + nat_idx(g, 0, 0, 0), g.pitch * sizeof(double), g.nx * sizeof(double), g.ny, hipMemcpyDefault, m->st));
+  HIPCHK(hipStreamSynchronize(m->st));
+  return MSOM_OK;
+}
+// the masked transform pair alone on a cell field [nl][N][N]
+extern "C" int msomn_dbg_wv_apply(msomn_t *m, const double *in, double *out) {
+  NEED_NCONST(m);
+  int r;
+  if (!m->wv_ready && (r = wv_setup(m))) return r;
+  if (!in || !out) return MSOM_ERR_ARG;
+  const NatGeom &g = m->wg[0];
+  for (int l = 0; l < m->nl; l++)
+    HIPCHK(hipMemcpy2DAsync(m->ws[0] + nat_idx(g, l, 0, 0), g.pitch * sizeof(double), in + (size_t)l * g.nx * g.ny, g.nx * sizeof(double), g.nx * sizeof(double), g.ny,
+                            hipMemcpyDefault, m->st));
+  if ((r = wv_masked_apply(m))) return r;
+  for (int l = 0; l < m->nl; l++)
+    HIPCHK(hipMemcpy2DAsync(out + (size_t)l * g.nx * g.ny, g.nx * sizeof(double), m->ws[0] + nat_idx(g, l, 0, 0), g.pitch * sizeof(double), g.nx * sizeof(double), g.ny,
+                            hipMemcpyDefault, m->st));
+  HIPCHK(hipStreamSynchronize(m->st));
+  return MSOM_OK;
+}
+
 extern "C" int msomn_set_const(msomn_t *m) {
   if (!m) return MSOM_ERR_ARG;
   NodeParams &p = m->p;
@@ -572,6 +709,7 @@ extern "C" int msomn_set_const(msomn_t *m) {
   if ((r = comp_q(m, m->f[MSOMN_PSI], m->f[MSOMN_Q]))) return r;
   HIPCHK(hipStreamSynchronize(m->st));
   m->const_set = 1;
+  m->wv_ready = 0;
   return MSOM_OK;
 }
 
@@ -802,8 +940,8 @@ extern "C" int msomn_run(msomn_t *m, const char *workdir, long nsteps_max) {
     if ((r = msomn_set_const(m))) return r;
   }
   snprintf(name, sizeof name, "%svars.nc", dpath);
-  double tout = 0., tdiag = 0.;
-  const bool diag = p.dtdiag > 0;
+  double tout = 0., tdiag = 0., tflt = p.dtflt;   // event filter (t = dtflt; t <= tend + 1e-10; t += dtflt), qg_baroclinic_ms.h:405-408
+  const bool diag = p.dtdiag > 0, filt = p.dtflt > 0;
   char dname[800];
   snprintf(dname, sizeof dname, "%sdiag_1d.dat", dpath);
   long steps = 0;
@@ -821,6 +959,11 @@ extern "C" int msomn_run(msomn_t *m, const char *workdir, long nsteps_max) {
       tdiag += p.dtdiag;
     }
     if ((r = msomn_forcing(m))) return r;  // forcing (i++)
+    if (filt && tflt <= p.tend + 1e-10 && m->t >= tflt - 1e-12 * fmax(1., fabs(tflt))) {
+      fprintf(stdout, "Filter solution\n");
+      if ((r = msomn_wavelet_filter(m, p.dtflt))) return r;
+      tflt += p.dtflt;
+    }
     bool pending = tout <= p.tend + 1e-10;
     if (pending && m->t >= tout - 1e-12 * fmax(1., fabs(tout))) {  // output (t = 0; t <= tend + 1e-10; t += dtout)
       fprintf(stdout, "write file\n");
@@ -836,6 +979,7 @@ extern "C" int msomn_run(msomn_t *m, const char *workdir, long nsteps_max) {
     if (!pending) break;
     if (nsteps_max >= 0 && steps >= nsteps_max) break;
     m->tnext = diag && tdiag <= p.tend + 1e-10 ? fmin(tout, tdiag) : tout;
+    if (filt && tflt <= p.tend + 1e-10) m->tnext = fmin(m->tnext, tflt);
     if ((r = msomn_step(m, 0))) return r;
     steps++;
   }

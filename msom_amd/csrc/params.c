@@ -146,7 +146,7 @@ void msom_node_params_defaults(struct NodeParams *p) {
   memset(p, 0, sizeof *p);
   p->N = 64; p->nl = 1; p->L0 = 1.; p->f0 = 1.; p->scale_topo = 1.; p->tf1 = 1.; p->tf2 = 1.; p->dy_ws = 1.; p->forc_mode = 2.0;
   p->dh[0] = 1.; p->N2[0] = 1.; p->DT = 1e10; p->tend = 100; p->dtout = 1; p->CFL = 0.5; p->TOLERANCE = 1e-3; p->dtdiag = -1;
-  p->Lfmax = 1e10; p->dtflt = -1;
+  p->Lfmax = 1e30; p->Lfmin = 1e30; p->dtflt = -1; /* HUGE of Basilisk, qg-node/qg.h:119-120 */
 }
 int msom_node_params_parse_text(struct NodeParams *p, const char *text) {
   const char *s = text;

@@ -29,6 +29,7 @@ enum { ORN_PSI = 0, ORN_Q, ORN_ZETA, ORN_TMP, ORN_PSIPG, ORN_S2 /* nl-1 */, ORN_
        /* surface-QG variant (params key sqg = 1), the finished parts of qg-node/sqg_baroclinic_ms.h */
        ORN_BS /* bs: surface buoyancy, 1 layer (:77-86, argument `bs` of comp_stretch) */,
        ORN_S2S /* S2 of the surface "layer": N2[0] before, f/N2[0] after set_const (:545), 1 layer */,
+       ORN_PSIF /* psi_f: running mean of the filtered part, qg_baroclinic_ms.h:30,384 */,
        ORN_QEFF /* scratch: rhs of the elliptic problem = q minus the surface term */, ORN_D2BS /* scratch: laplacian(bs), :160-168 */,
        ORN_NFIELDS };
 
@@ -42,6 +43,8 @@ typedef struct {
   int N, nl, flag_ms, sqg;
   double L0, f0, beta, hEkb, tau0, tau1, tf1, tf2, dy_ws, forc_mode, nu, nu4, gp_low, iRd2_low, scale_topo, bc_fac, psi_bc;
   double DT, tend, dtout, CFL, TOLERANCE, noise_init;
+  double Lfmax, Lfmin, fac_filt_Rd, dtflt; int nbar; /* wavelet filter of the vertex model, qg-node/qg.h:118-122 */
+  double **wsig, **wmc, **ws, **ww; int wv_ready; /* cell pyramids of the filter: coefficients, mask_c, s, w (nl layers) */
   double dh[ORN_MAXNL], N2[ORN_MAXNL], idh0[ORN_MAXNL], idh1[ORN_MAXNL];
   int nitermax, nitermin, nrelax, smoother, quiet;
   vf f[ORN_NFIELDS];
@@ -69,7 +72,7 @@ orn_t *orn_create_str(const char *text) {
   /* defaults qg-node/qg.h:104-127, qg.c:61-66, Basilisk globals */
   o->N = 64; o->nl = 1; o->L0 = 1; o->f0 = 1.; o->tend = 100; o->dtout = 1; o->dh[0] = 1.; o->N2[0] = 1.; o->scale_topo = 1.;
   o->tf1 = 1; o->tf2 = 1; o->dy_ws = 1; o->forc_mode = 2.0; o->DT = 1e10; o->CFL = 0.5; o->TOLERANCE = 1e-3;
-  o->nitermax = 100; o->nitermin = 1; o->nrelax = 5;
+  o->nitermax = 100; o->nitermin = 1; o->nrelax = 5; o->Lfmax = 1e30; o->Lfmin = 1e30; o->dtflt = -1; /* HUGE, qg-node/qg.h:119-120 */
   char *copy = strdup(text), *save = NULL;
   for (char *line = strtok_r(copy, "\n", &save); line; line = strtok_r(NULL, "\n", &save)) {
     char b[300]; strncpy(b, line, 299); b[299] = 0; trim(b);
@@ -82,6 +85,7 @@ orn_t *orn_create_str(const char *text) {
     KD("hEkb", hEkb); KD("gp_low", gp_low); KD("scale_topo", scale_topo); KD("tau0", tau0); KD("tau1", tau1); KD("tf1", tf1);
     KD("tf2", tf2); KD("dy_ws", dy_ws); KD("forc_mode", forc_mode); KD("noise_init", noise_init); KD("bc_fac", bc_fac); KD("DT", DT);
     KD("tend", tend); KD("dtout", dtout); KD("CFL", CFL); KD("TOLERANCE", TOLERANCE); KD("amp_stoch", amp_stoch); KD("L_filt", L_filt);
+    KD("Lfmax", Lfmax); KD("Lfmin", Lfmin); KD("fac_filt_Rd", fac_filt_Rd); KD("dtflt", dtflt);
     else if (!strcmp(k, "dh")) arr(v, o->dh);
     else if (!strcmp(k, "N2")) arr(v, o->N2);
   }
@@ -487,6 +491,119 @@ void orn_filter_noise(orn_t *o) { cell_wavelet_filter(o); }
 void orn_get_csig(orn_t *o, int k, double *a) { const int n = o->N >> k; for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) a[(size_t)j * n + i] = o->csig[k][CI(n, i, j)]; }
 int orn_cell_levels(orn_t *o) { return o->cnlev; }
 
+/* ---------------------------------------------------------------- wavelet filter of the vertex model
+ * wavelet_filter qg_baroclinic_ms.h:346-400 ("temporary fix": the transform runs on the CELL average of psi), its
+ * coefficients sig_lev and the cell mask mask_c :525-578, wavelet_mask / inverse_wavelet_mask qg-node/wavelet_vertex.h:10-46.
+ * Cell pyramids: level k has (N >> k)^2 cells and one ghost ring (CI); nl layers one after the other. */
+#define CL(n) ((size_t)((n) + 2) * ((n) + 2))
+static void cell_bc_dirichlet(double *f, int n) { /* dirichlet(0): ghost = -interior, x sides first ([BASILISK RULE]) */
+  for (int j = 0; j < n; j++) { f[CI(n, n, j)] = -f[CI(n, n - 1, j)]; f[CI(n, -1, j)] = -f[CI(n, 0, j)]; }
+  for (int i = -1; i <= n; i++) { f[CI(n, i, n)] = -f[CI(n, i, n - 1)]; f[CI(n, i, -1)] = -f[CI(n, i, 0)]; }
+}
+static void wv_setup(orn_t *o) {
+  const int K = o->cnlev, N = o->N, nl = o->nl;
+  if (!o->wsig) {
+    o->wsig = (double **)calloc(K, sizeof(double *)); o->wmc = (double **)calloc(K, sizeof(double *));
+    o->ws = (double **)calloc(K, sizeof(double *)); o->ww = (double **)calloc(K, sizeof(double *));
+    for (int k = 0; k < K; k++) { const size_t sz = CL(N >> k);
+      o->wsig[k] = (double *)calloc(sz, sizeof(double)); o->wmc[k] = (double *)calloc(sz, sizeof(double));
+      o->ws[k] = (double *)calloc(sz * nl, sizeof(double)); o->ww[k] = (double *)calloc(sz * nl, sizeof(double)); }
+  }
+  /* sig_lev :527-552, a VERTEX scalar used at the cell with the same index (foreach_vertex_level ... w[] *= sig_lev[],
+   * :373-376): only the vertices (i, j) < n of a level are ever read, and their children (2i + a, 2j + b) are in range.
+   * Low pass only (the high-pass flip is commented out, :554-559).  L_filt2 = min(fac_filt_Rd dh[0] / sqrt(S2[]), Lfmax)
+   * with S2 of layer 0 at the vertex (injected on the coarse levels) when fac_filt_Rd > 0, else
+   * L_filt = Lfmax + (y / L0)(Lfmin - Lfmax), qg_baroclinic_ms.h:52 */
+  for (int k = 0; k < K; k++) {
+    const int n = N >> k; const double Delta = o->L0 / n;
+    for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) {
+      double ref_flag = 0;
+      if (k > 0) { const int m = n * 2; const double *c = o->wsig[k - 1];
+        ref_flag += c[CI(m, 2 * i, 2 * j)]; ref_flag += c[CI(m, 2 * i, 2 * j + 1)]; ref_flag += c[CI(m, 2 * i + 1, 2 * j)]; ref_flag += c[CI(m, 2 * i + 1, 2 * j + 1)]; }
+      double v;
+      if (ref_flag > 0) v = 1;
+      else {
+        double L2;
+        if (o->fac_filt_Rd > 0) L2 = fmin(o->fac_filt_Rd * o->dh[0] / sqrt(W(&o->f[ORN_S2], 0, i << k, j << k)), o->Lfmax);
+        else L2 = o->Lfmax + (j * Delta / o->L0) * (o->Lfmin - o->Lfmax);
+        if (L2 > 2 * Delta) v = 0;
+        else if (L2 <= 2 * Delta && L2 > Delta) v = 1 - (L2 - Delta) / Delta;
+        else v = 1;
+      }
+      o->wsig[k][CI(n, i, j)] = v;
+    }
+  }
+  /* mask_c :567-575: cell average of the vertex mask, restricted (mean of the 4 children) */
+  { vf *mk = &o->f[ORN_MASK];
+    for (int j = 0; j < N; j++) for (int i = 0; i < N; i++)
+      o->wmc[0][CI(N, i, j)] = 0.25 * (W(mk, 0, i, j) + W(mk, 0, i + 1, j) + W(mk, 0, i, j + 1) + W(mk, 0, i + 1, j + 1));
+    for (int k = 1; k < K; k++) { const int n = N >> k, m = n * 2; const double *f = o->wmc[k - 1];
+      for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) {
+        double sum = 0.; sum += f[CI(m, 2 * i, 2 * j)]; sum += f[CI(m, 2 * i, 2 * j + 1)]; sum += f[CI(m, 2 * i + 1, 2 * j)]; sum += f[CI(m, 2 * i + 1, 2 * j + 1)];
+        o->wmc[k][CI(n, i, j)] = sum / 4; } } }
+  o->wv_ready = 1;
+}
+/* psi_i <- inverse_wavelet_mask(sig_lev * wavelet_mask(psi_i)), all layers; ws[0] holds psi_i (interior) on entry */
+static void wv_masked_apply(orn_t *o) {
+  const int K = o->cnlev, N = o->N, nl = o->nl;
+  for (int l = 0; l < nl; l++) {
+    double *s0 = o->ws[0] + l * CL(N);
+    cell_bc_dirichlet(s0, N);
+    for (int k = 1; k < K; k++) { const int n = N >> k, m = n * 2; const double *f = o->ws[k - 1] + l * CL(m); double *c = o->ws[k] + l * CL(n);
+      for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) {
+        double sum = 0.; sum += f[CI(m, 2 * i, 2 * j)]; sum += f[CI(m, 2 * i, 2 * j + 1)]; sum += f[CI(m, 2 * i + 1, 2 * j)]; sum += f[CI(m, 2 * i + 1, 2 * j + 1)];
+        c[CI(n, i, j)] = sum / 4; }
+      cell_bc_dirichlet(c, n); }
+    /* w = (s - prolongation(s coarse)) * mask_c, then * sig_lev (wavelet_vertex.h:17-26, qg_baroclinic_ms.h:373-376) */
+    for (int k = 0; k < K - 1; k++) { const int n = N >> k; const double *s = o->ws[k] + l * CL(n), *sc = o->ws[k + 1] + l * CL(n >> 1); double *w = o->ww[k] + l * CL(n);
+      for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) {
+        double d = s[CI(n, i, j)]; d -= cell_bilinear(sc, n >> 1, i, j);
+        d = d * o->wmc[k][CI(n, i, j)];
+        w[CI(n, i, j)] = d * o->wsig[k][CI(n, i, j)]; } }
+    { const int n = N >> (K - 1); double *s = o->ws[K - 1] + l * CL(n); /* root: w = s mask_c; w *= sig_lev; s = w mask_c */
+      for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) {
+        double w = s[CI(n, i, j)] * o->wmc[K - 1][CI(n, i, j)]; w = w * o->wsig[K - 1][CI(n, i, j)];
+        s[CI(n, i, j)] = w * o->wmc[K - 1][CI(n, i, j)]; }
+      cell_bc_dirichlet(s, n); }
+    for (int k = K - 2; k >= 0; k--) { const int n = N >> k; double *s = o->ws[k] + l * CL(n), *w = o->ww[k] + l * CL(n); const double *sc = o->ws[k + 1] + l * CL(n >> 1);
+      for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) { double r = cell_bilinear(sc, n >> 1, i, j); r += w[CI(n, i, j)]; w[CI(n, i, j)] = r * o->wmc[k][CI(n, i, j)]; }
+      for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) s[CI(n, i, j)] = w[CI(n, i, j)];
+      cell_bc_dirichlet(s, n); }
+  }
+}
+static void invert_q(orn_t *o, vf *q);
+static void comp_q(orn_t *o, vf *psi, vf *q);
+void orn_wavelet_filter(orn_t *o, double dtflt) { /* qg_baroclinic_ms.h:346-400 */
+  const int N = o->N, nl = o->nl; vf *psi = &o->f[ORN_PSI], *pf = &o->f[ORN_PSIF], *mk = &o->f[ORN_MASK];
+  if (!o->wv_ready) wv_setup(o);
+  invert_q(o, &o->f[ORN_Q]);
+  for (int l = 0; l < nl; l++) { double *s = o->ws[0] + l * CL(N);
+    for (int j = 0; j < N; j++) for (int i = 0; i < N; i++)
+      s[CI(N, i, j)] = 0.25 * (W(psi, l, i, j) + W(psi, l, i + 1, j) + W(psi, l, i, j + 1) + W(psi, l, i + 1, j + 1)); }
+  wv_masked_apply(o);
+  if (o->Lfmax < 1e30) /* `if (Lfmax < HUGE)`, :380 */
+    for (int l = 0; l < nl; l++) { const double *s = o->ws[0] + l * CL(N);
+      for (int j = 0; j <= N; j++) for (int i = 0; i <= N; i++) {
+        const double psi_loc = 0.25 * (s[CI(N, i, j)] + s[CI(N, i - 1, j)] + s[CI(N, i, j - 1)] + s[CI(N, i - 1, j - 1)]);
+        W(pf, l, i, j) = (W(pf, l, i, j) * o->nbar + psi_loc / dtflt) / (o->nbar + 1);
+        W(psi, l, i, j) = (W(psi, l, i, j) - psi_loc) * W(mk, 0, i, j); } }
+  bnd_psi(o);
+  comp_q(o, psi, &o->f[ORN_Q]);
+  o->nbar++;
+}
+void orn_wv_get(orn_t *o, int what, int k, double *a) { /* 0: sig_lev (as used at the cells), 1: mask_c; level k, [n][n] */
+  if (!o->wv_ready) wv_setup(o);
+  const int n = o->N >> k; const double *f = what ? o->wmc[k] : o->wsig[k];
+  for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) a[(size_t)j * n + i] = f[CI(n, i, j)];
+}
+void orn_wv_apply(orn_t *o, const double *in, double *out) { /* the masked transform pair alone on a cell field [nl][N][N] */
+  const int N = o->N, nl = o->nl;
+  if (!o->wv_ready) wv_setup(o);
+  for (int l = 0; l < nl; l++) for (int j = 0; j < N; j++) for (int i = 0; i < N; i++) (o->ws[0] + l * CL(N))[CI(N, i, j)] = in[((size_t)l * N + j) * N + i];
+  wv_masked_apply(o);
+  for (int l = 0; l < nl; l++) for (int j = 0; j < N; j++) for (int i = 0; i < N; i++) out[((size_t)l * N + j) * N + i] = (o->ws[0] + l * CL(N))[CI(N, i, j)];
+}
+
 /* ---------------------------------------------------------------- set_const, time stepping */
 void orn_set_const(orn_t *o) { /* qg-node/qg.h:465-524 + qg_baroclinic_ms.h:449-510 + qg_barotropic.h:115-118 */
   const int nl = o->nl, N = o->N; const double D = o->L0 / N;
@@ -510,6 +627,7 @@ void orn_set_const(orn_t *o) { /* qg-node/qg.h:465-524 + qg_baroclinic_ms.h:449-
   } else if (o->gp_low != 0.) o->iRd2_low = o->f0 * o->f0 / (o->gp_low * o->dh[nl - 1]);
   build_levels(o);
   init_stoch(o);
+  o->wv_ready = 0;
   bnd_psi(o);
   if (o->nu != 0) o->DT = 0.5 * fmin(o->DT, D * D / o->nu / 4.);          /* qg-node/qg.h:511-512 */
   if (o->beta != 0) o->DT = fmin(o->DT, 1 / (2. * o->beta * o->L0));

@@ -363,6 +363,8 @@ class NodeOracleModel:
     def mgstats(self): return _stats(self.m.mgstats())
     def diag1d(self): return self.m.diag1d()
     def noise(self): return self.m.noise()
+    def wavelet_filter(self, dtflt): self.m.wavelet_filter(dtflt)
+    def wv_apply(self, c): return self.m.wv_apply(c)
     def close(self): self.m = None
 
 
@@ -398,6 +400,8 @@ class NodeGpuModel:
     def mgstats(self): return _stats(self.m.mgstats())
     def diag1d(self): return self.m.diag1d()
     def noise(self): return self.m.noise()
+    def wavelet_filter(self, dtflt): self.m.wavelet_filter(dtflt)
+    def wv_apply(self, c): return self.m.wv_apply(c)
     def close(self): self.m.close()
 
 
@@ -510,6 +514,25 @@ def case_node_sqg(make, inp, N, nl):
     return out
 
 
+def case_node_wavelet(make, inp, N, nl):
+    """wavelet filter of the vertex model (qg_baroclinic_ms.h:346-400, wavelet_vertex.h:10-46): two filter events, then two steps"""
+    dh, N2 = NODE_LAYERS[nl]
+    txt = NODE_PARAMS.format(N=N, nl=nl, bc_fac=1.0, dh=dh, N2=N2) + "Lfmax = 12\nLfmin = 3\n"
+    m = make(txt, TOLERANCE=1e-10)
+    m.set("MASK", inp["in_mask"])
+    m.set("PSI", inp["in_psi"])
+    m.set_const()
+    out = {"filtered_cells": m.wv_apply(inp["in_cells"])}
+    for k in (1, 2):
+        m.wavelet_filter(0.5)
+        out[f"psi_f{k}"], out[f"psif_f{k}"], out[f"q_f{k}"] = m.get("PSI"), m.get("PSIF"), m.get("Q")
+    for _ in range(2):
+        m.step()
+    out["q_end"] = m.get("Q")
+    m.close()
+    return out
+
+
 def case_node_stochastic(make, inp, N):
     """-D_STOCHASTIC of the vertex model (qg-node/qg_stochastic.h:15-65, qg.h:306-320), serial rand() stream, srand(11)"""
     txt = NODE_PARAMS.format(N=N, nl=1, bc_fac=1.0, dh=NODE_LAYERS[1][0], N2=NODE_LAYERS[1][1]) + "amp_stoch = 0.3\nL_filt = 8.0\n"
@@ -530,7 +553,13 @@ def sqg_inputs(N, nl, seed):
     return {"in_mask": d["in_mask"], "in_psi": d["in_psi"], "in_bs": 0.3 * np.outer(np.sin(np.pi * x), np.sin(2 * np.pi * x))[None] + 0.05}
 
 
+def wavelet_inputs(N, nl, seed):
+    d = node_inputs(N, nl, seed)
+    return {"in_mask": d["in_mask"], "in_psi": d["in_psi"], "in_cells": np.random.default_rng(seed).standard_normal((nl, N, N))}
+
+
 NODE_CASES = {
+    "node_wavelet_32x3": (case_node_wavelet, dict(N=32, nl=3), lambda: wavelet_inputs(32, 3, 205)),
     "node_sqg_32x3": (case_node_sqg, dict(N=32, nl=3), lambda: sqg_inputs(32, 3, 204)),
     "node_island_32x3": (case_node, dict(N=32, nl=3, bc_fac=1.0), lambda: node_inputs(32, 3, 201)),
     "node_island_64x1": (case_node, dict(N=64, nl=1, bc_fac=0.5), lambda: node_inputs(64, 1, 202)),

@@ -5,7 +5,7 @@ import numpy as np
 
 import orc
 
-PSI, Q, ZETA, TMP, PSIPG, S2, TOPO, QFORC, MASK, DQ, QPRED, QFORC3D, BS, S2S = range(14)
+PSI, Q, ZETA, TMP, PSIPG, S2, TOPO, QFORC, MASK, DQ, QPRED, QFORC3D, BS, S2S, PSIF = range(15)
 GS_LEX, GS_RB = 0, 1
 
 
@@ -34,6 +34,7 @@ def lib():
             ("orn_prolong_raw", None, [vp, ci, dp, dp]), ("orn_get_level_mask", None, [vp, ci, dp]),
             ("orn_diag1d", None, [vp, dp]), ("orn_get_noise", None, [vp, dp]), ("orn_set_noise", None, [vp, dp]), ("orn_filter_noise", None, [vp]),
             ("orn_get_csig", None, [vp, ci, dp]), ("orn_cell_levels", ci, [vp]),
+            ("orn_wavelet_filter", None, [vp, cd]), ("orn_wv_get", None, [vp, ci, ci, dp]), ("orn_wv_apply", None, [vp, dp, dp]),
         ]:
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
@@ -181,6 +182,22 @@ class NodeOracle:
 
     def cell_levels(self):
         return self.L.orn_cell_levels(self.h)
+
+    # wavelet filter of the vertex model (qg_baroclinic_ms.h:346-400)
+    def wavelet_filter(self, dtflt):
+        self.L.orn_wavelet_filter(self.h, dtflt)
+
+    def wv_get(self, what, k):
+        n = self.N >> k
+        a = np.empty((n, n))
+        self.L.orn_wv_get(self.h, what, k, _p(a))
+        return a
+
+    def wv_apply(self, cells):
+        cells = np.ascontiguousarray(cells, dtype=np.float64)
+        out = np.empty_like(cells)
+        self.L.orn_wv_apply(self.h, _p(cells), _p(out))
+        return out
 
     def level_mask(self, lev):
         n1 = (self.N >> lev) + 1

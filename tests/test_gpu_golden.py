@@ -19,7 +19,7 @@ FAST_RTOL = {
     "run_p0bas_32x32x3": 1e-7, "run_p0bas_32x32x3_tol1e-12": 1e-9,
     "run_C1_128x128x1": 1e-7, "run_C2_512x512x3": 1e-7,
     "stochastic_srand7_16x16x3": 1e-9, "tracers_32x32x3": 1e-9, "wavelet_64x64x3": 1e-7,
-    "node_island_32x3": 1e-6, "node_island_64x1": 1e-6, "node_stochastic_32x1": 1e-7, "node_sqg_32x3": 1e-6,
+    "node_island_32x3": 1e-6, "node_island_64x1": 1e-6, "node_stochastic_32x1": 1e-7, "node_sqg_32x3": 1e-6, "node_wavelet_32x3": 1e-6,
 }
 
 
