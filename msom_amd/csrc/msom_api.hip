@@ -104,7 +104,7 @@ struct msom {
   int block_small = 0;   // the same kernel on the launch-bound levels only (not marched, <= block_small cells wide): 2 launches per level visit instead of 8
   int march = 1;         // chained half-sweeps in register windows (kernels_march.hip) on wide single-GPU levels
   int march_k = 4;       // at most this many half-sweeps per pass (2..4)
-  int march_min = 24;    // log2 of the cell-layers a level needs for the chained pass
+  int march_min = 23;    // log2 of the cell-layers a level needs for the chained pass (2^23: 2048^2 x 3 1.83 -> 1.78 ms/step, and the 2048 x 1024 x 6 tiles of BASELINE's 2 x 4 layout qualify; 2^22 loses: 1024^2 x 6 2.76 -> 2.87)
   int march_correct = 0; // the last pass of the finest level writes psi + da instead of da; measured neutral (the pass runs at 4.3 TB/s, the post-cycle pass it relieves at 5.8): off
   int corr_req = 0, corr_done = 0;  // set around mg_cycle_levels by mg_solve / by the pass that did it
   int march_prolong = 1; // whole levels: prolongation folded into the first pass ((PL + 4) + 4 half-sweeps; coarse rows by LDS-DMA, kernels_march.hip): 7.63 -> 7.09 ms per step at 4096^2 x 6

@@ -331,3 +331,28 @@ def test_tiled_passive_tracers_wide_halo_messages():
     assert np.array_equal(assemble(out, "q", px, py), g.get(F["Q"]))
     assert np.array_equal(assemble(out, "extra", px, py), g.get(F["PTR"]))
     assert np.abs(g.get(F["PTR"]) - c0).max() > 0
+
+
+def test_baseline_c4_layout_2x4_tiles_of_2048x1024x6():
+    """BASELINE config 4 exactly as written -- 4096^2 x 6 on 2 x 4 tiles of 2048 x 1024 -- through the in-process
+    transport on ONE GPU (8 host threads, 8 x 1.8 GB of fields): one RK2 step, product build, default options (the
+    chained smoother with 4-deep halos on the two finest tile levels, agglomerated coarse levels, overlapped ring
+    exchanges).  Compared with the single tile on the same number of multigrid levels: the per-point arithmetic is the
+    same but FMA contraction is chosen per kernel and the kernels differ between tile and whole grid, hence 1e-10."""
+    px, py, tx, ty, nl = 2, 4, 2048, 1024, 6
+    gn = 4096
+    params = orc.double_gyre_params(gn, nl, extra="MGLEVELS = 10\n")
+    psi = orc.synthetic_psi(nl, gn, gn)
+    out = run_tiled(params, px, py, psi, nsteps=1, strict=False)
+    g = QG(params)
+    g.option("quiet", 1)
+    g.set(F["PSI"], psi)
+    g.set_const()
+    g.set_tnext(float("inf"))
+    dt = g.step()
+    p = assemble(out, "psi", px, py)
+    ref = g.get(F["PSI"])
+    assert p.shape == ref.shape == (nl, gn, gn)
+    assert np.abs(p - ref).max() <= 1e-10 * np.abs(ref).max()
+    for r in range(px * py):
+        assert out[r]["dts"] == [dt] and out[r]["st"].i == g.mgstats().i
