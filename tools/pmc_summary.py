@@ -19,16 +19,18 @@ f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 N, nl = 4096, 6
 wb = 8.0 * N * N * nl
 alg = {"k_relax_color_x2<6, true, true>": 1.5, "k_rhs_fused_pipe<32, 512, false>": 3.0, "k_correct_residual<true, true>": 4.0,
-       "k_residual2<false, true, true, false>": 3.25, "k_relax_red_prolong3<6, true>": 1.25, "k_relax_march<6, 4, false, false>": 2.5, "k_relax_march<6, 3, false, false>": 2.5, "k_rhs_lpw<4, true, false, true>": 3.0}
+       "k_residual2<false, true, true, false>": 3.25, "k_relax_red_prolong3<6, true>": 1.25, "k_relax_march<6, 4, false, false>": 2.5, "k_relax_march<6, 3, false, false>": 2.5, "k_rhs_lpw<4, true, false, true>": 3.0,
+       "k_relax_march_dma<6, 4, 2, 4, false>": 2.5, "k_relax_march_dma<6, 4, 4, 1, true>": 2.25, "k_relax_march_dma<6, 4, 2, 1, false>": 2.5}
 rows = []
 for k in sorted(f, key=lambda k: -sum(f[k])):
     n = len(f[k])
-    fk = max(f[k]) if "red_prolong" in k or "relax_color_x2<6, true, false>" in k else sum(f[k]) / n   # multi-level kernels: the finest level
-    wk = (max(w[k]) if "red_prolong" in k or "relax_color_x2<6, true, false>" in k else sum(w[k]) / max(1, len(w[k]))) if k in w else 0.0
+    multi = "red_prolong" in k or "relax_color_x2<6, true, false>" in k or "k_relax_march" in k or "k_restrict" in k   # multi-level kernels: the finest level
+    fk = max(f[k]) if multi else sum(f[k]) / n
+    wk = (max(w[k]) if multi else sum(w[k]) / max(1, len(w[k]))) if k in w else 0.0
     row = {"kernel": k, "dispatches": n, "read_GB": fk * 1024 * 2 / 1e9, "write_GB": wk * 1024 / 1e9}
     row["traffic_GB"] = row["read_GB"] + row["write_GB"]
     for a, c in alg.items():
         if a in k:
             row["algorithmic_GB"] = c * wb / 1e9
     rows.append(row)
-print(json.dumps(rows[:10], indent=1))
+print(json.dumps(rows[:12], indent=1))
