@@ -119,11 +119,13 @@ void launch_correct(hipStream_t st, double *a, const NatGeom &g, const double *d
 // tiles: the `rows` nearest rows of the S / N neighbour tiles of the input and of the residual (null at a wall), laid
 // out like `rows` rows of the level (ls doubles per layer)
 // last pass of the finest level: psi_out = psi + da instead of storing da
+// more_follow: further half-sweeps of the level come after this pass, so it only stores the colour of its last half-sweep
+// (the other colour is recomputed by the next half-sweep before anything reads it): w/2 fewer bytes written
 struct MarchCorrect { const double *psi; double *psi_out; NatGeom g; };
 struct MarchHalo { const double *in_s, *in_n, *res_s, *res_n; size_t ls; int rows; };
 int launch_relax_march(hipStream_t st, const double *in, double *out, const double *res, const SplitGeom &sg, int nl, const RelaxCoef &rc, int c1,
                        int K, int walls, int chunk_rows = 0, const MarchHalo *h = nullptr, const double *coarse = nullptr, const SplitGeom *cg = nullptr,
-                       const MarchCorrect *mc = nullptr);
+                       const MarchCorrect *mc = nullptr, int more_follow = 0);
 
 // ---- kernels_wavelet.hip
 void launch_wv_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl);

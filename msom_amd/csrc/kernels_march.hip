@@ -44,6 +44,7 @@ struct MarchArgs {
   SplitGeom g;
   int c1;  // colour of the first half-sweep (0 red, 1 black)
   int walls, H, remap, flip;
+  int partial;  // another half-sweep follows this pass: the colour updated by half-sweep K - 1 is overwritten before anybody reads it, only the last colour is stored
   int dbg;  // timing experiments only (results wrong): 1 = no stores, 2 = no loads after the first step
   RelaxCoef rc;
 };
@@ -293,8 +294,13 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
 //    (red + prolongation) + 4 + 3 in three.
 // Arithmetic, windows, ghost rules and stores are the ones above (same expression order => bit-identical,
 // tests/test_gpu_march.py).  LDS per wavefront: 3 NL (PL: 4 NL) layer-rows of 512 B = 9 (12) KB at NL = 6.
-template <int NL, int K, int HL, int WPB, bool PL>
+//  * CORR (last pass of the finest level): the correction a += da (mspg/elliptic.h:92-98) rides in the pass.  psi of the
+//    row that half-sweep K finished in step t - 1 is requested with the rows of step t + 1 (LDS-DMA, 16 bytes per lane =
+//    the lane's cell pair in the natural layout) and psi_out = psi + da of that row is written at the top of step t + 1,
+//    right after the wait that covers the request: nothing of the chain waits for psi, and da is never stored.
+template <int NL, int K, int HL, int WPB, bool PL, bool CORR = false>
 __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
+  static_assert(!(PL && CORR), "the prolongation and the correction never ride in the same pass");
   static_assert(HL % 2 == 0 && (!PL || HL % 4 == 0), "16-byte pieces: strips start at even kx (PL: at kx = 0 mod 4)");
   constexpr int OW = 64 - 2 * HL;
   constexpr int D1 = K >= 3 ? 3 : 1, D2 = K >= 4 ? 3 : 1;
@@ -303,7 +309,9 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
   // a coarse row serves 4 fine rows and is fetched ONCE, one new row every second step
   constexpr int NLE = (NL + 1) & ~1;                       // two layer-rows per DMA instruction
   constexpr int CB = 2 * NLE;                              // first coarse ring row
-  constexpr int LROWS = PL ? CB + 4 * NLE : 2 * ((3 * NL + 1) / 2);
+  constexpr int PB = 2 * ((3 * NL + 1) / 2);                // CORR: first row of the psi block (NL x 128 doubles)
+  constexpr int XB = PB + 2 * NL;                           // CORR: values of half-sweep K waiting one step for their psi row
+  constexpr int LROWS = PL ? CB + 4 * NLE : (CORR ? XB + NL : 2 * ((3 * NL + 1) / 2));
   __shared__ __align__(16) double ring_all[WPB][LROWS][64];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -360,6 +368,13 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
     J = rr >> 1;
     cy = (rr & 1) ? 1 : -1;
   };
+  // CORR: with the rows of step t comes psi of the row half-sweep K finished in step t - 1 (the lane's cell pair, natural layout)
+  auto request_psi = [&](int t) {
+    const int rk = min(max(ph(t - K), 0), ny - 1);
+    const double *ps = p.psi + nat_idx(p.ng, 0, rk, 2 * min(max(kx, 0), hk - 1));
+#pragma unroll
+    for (int l = 0; l < NL; l++) dma16(ps + l * p.ng.ls, PB + 2 * l);
+  };
   // requests the rows of marching step t
   auto request = [&](int t) {
     size_t st[3];
@@ -380,6 +395,7 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
       dma16((sub ? g1 : g0) + epc, 2 * d);
     }
     static_assert(!PL || 2 * ((2 * NL + 1) / 2) <= CB, "residual rows end before the coarse ring");
+    if constexpr (CORR) request_psi(t);
     if constexpr (PL) {
       bool neg;
       int J, cy;
@@ -438,6 +454,24 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
     for (int d = 0; d < D2; d++) R2[d][l] = 0.;
   }
   const int tA = y0 - K + 1, tB = y1 + K - 2;
+  // psi_out = psi + da of row r: the cell of parity px from half-sweep K (parked in LDS for one step: no registers), the
+  // other one from yv (half-sweep K - 1, one step before it); psi of the row is read from the ring layer by layer
+  auto correct_row = [&](int r, const double (&yv)[NL]) {
+    if constexpr (CORR) {
+      if (r >= y0 && r < y1 && own_lane && !(p.dbg & 1)) {
+        const int px = (r + p.c1 + K - 1) & 1;
+        double *po = p.psi_out + nat_idx(p.ng, 0, r, 2 * kx);   // wall ghosts of psi_out: one boundary pass after the launch
+        const double *pb = &ring[0][0] + PB * 64 + 2 * lane;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+          const double2 a = *reinterpret_cast<const double2 *>(pb + 128 * l);
+          const double xv = ring[XB + l][lane];
+          const double de = px ? yv[l] : xv, dd = px ? xv : yv[l];
+          *reinterpret_cast<double2 *>(po + l * p.ng.ls) = make_double2(a.x + de, a.y + dd);
+        }
+      }
+    }
+  };
   request(tA);
   // rows y0 - K and y0 - K + 1 of the input fill the first window (plain loads, once per chunk)
 #pragma unroll
@@ -491,11 +525,17 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
       if constexpr (!PL) W[0][2][l] = ring[2 * NL + l][lane];
       else { A0[l] = ring[CB + sJ0 * NLE + l][cld]; A1[l] = ring[CB + sJ1 * NLE + l][cld]; }
     }
+    // CORR: the row half-sweep K finished in the previous step (its other colour is one row down the window by now)
+    correct_row(ph(t - K), W[K - 1][0]);
     // the ring is free again once these reads have returned: the next step's rows have this whole step to arrive
     if (t < tB && !(p.dbg & 2)) {
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
       asm volatile("" ::: "memory");
       request(t + 1);
+    } else if (CORR && t == tB) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      asm volatile("" ::: "memory");
+      request_psi(t + 1);
     }
     if constexpr (PL) prolong_vals(ph(t + 1), (ph(t + 1) + c0) & 1, A0, A1, W[0][2]);
 #pragma unroll
@@ -556,10 +596,20 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
 #pragma unroll
         for (int l = 0; l < NL; l++) W[s][2][l] = x[l];
       }
-      if (s >= K - 1 && r >= y0 && r < y1 && own_lane && !(p.dbg & 1)) {  // the last update of each colour is what the level keeps
-        double *dst = p.out + off(px, r);
+      if constexpr (CORR) {
+        if (s == K) {
 #pragma unroll
-        for (int l = 0; l < NL; l++) dst[l * ls] = x[l];
+          for (int l = 0; l < NL; l++) ring[XB + l][lane] = x[l];
+        }
+      }
+      if (!CORR && s >= K - 1 && r >= y0 && r < y1 && own_lane && !(p.dbg & 1)) {  // the last update of each colour is what the level keeps
+        // partial: the colour of half-sweep K - 1 is recomputed by the next pass before anything reads it -- except through
+        // the wall ghosts that mirror its wall cells, which sit at positions of the OTHER colour and are input of that pass
+        if (s == K || !p.partial) {
+          double *dst = p.out + off(px, r);
+#pragma unroll
+          for (int l = 0; l < NL; l++) dst[l * ls] = x[l];
+        }
         const int i = 2 * kx + px;
         if (i == 0 || i == p.g.nx - 1 || r == 0 || r == ny - 1) {
 #pragma unroll
@@ -567,6 +617,11 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
         }
       }
     }
+  }
+  if constexpr (CORR) {   // the last row of the chunk
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    correct_row(ph(tB - K + 1), W[K - 1][1]);
   }
 }
 
@@ -623,7 +678,7 @@ int g_march_dma = 2;    // LDS-DMA version of the pass (option march_dma: 0 regi
 
 template <int NL>
 static int march_dispatch(hipStream_t st, const MarchArgs &a, int K, int rows) {
-  if (g_march_dma && !a.psi_out && !(K == 4 && NL > 6) && !(a.coarse && NL > 6)) {
+  if (g_march_dma && !(K == 4 && NL > 6) && !((a.coarse || a.psi_out) && NL > 6)) {
     // 1: one strip per workgroup; 2 (default): four adjacent strips per workgroup, marching in step, for the plain pass
     // (the pass with the prolongation measured faster with one: 7.09 vs 7.25 ms per RK2 step); 3: four for both
     constexpr int NLS = NL;
@@ -632,6 +687,9 @@ static int march_dispatch(hipStream_t st, const MarchArgs &a, int K, int rows) {
     if (a.coarse) {                                                                                                          \
       if (four) march_launch(st, k_relax_march_dma<NLS, KK, 4, 4, true>, a, 56 * 4, rows, 256);                                \
       else march_launch(st, k_relax_march_dma<NLS, KK, 4, 1, true>, a, 56, rows, 64);                                          \
+    } else if (a.psi_out) {                                                                                                  \
+      if (four) march_launch(st, k_relax_march_dma<NLS, KK, 2, 4, false, true>, a, 60 * 4, rows, 256);                         \
+      else march_launch(st, k_relax_march_dma<NLS, KK, 2, 1, false, true>, a, 60, rows, 64);                                   \
     } else if (four) march_launch(st, k_relax_march_dma<NLS, KK, 2, 4, false>, a, 60 * 4, rows, 256);                          \
     else march_launch(st, k_relax_march_dma<NLS, KK, 2, 1, false>, a, 60, rows, 64);                                           \
     return 0;
@@ -670,8 +728,9 @@ static int march_dispatch(hipStream_t st, const MarchArgs &a, int K, int rows) {
 
 // K (2..4) half-sweeps starting with colour c1, in -> out; returns -1 if (nl, K) has no instantiation
 int launch_relax_march(hipStream_t st, const double *in, double *out, const double *res, const SplitGeom &sg, int nl, const RelaxCoef &rc, int c1,
-                       int K, int walls, int chunk_rows, const MarchHalo *h, const double *coarse, const SplitGeom *cg, const MarchCorrect *mc) {
+                       int K, int walls, int chunk_rows, const MarchHalo *h, const double *coarse, const SplitGeom *cg, const MarchCorrect *mc, int more_follow) {
   MarchArgs a;
+  a.partial = more_follow != 0;
   a.psi = mc ? mc->psi : nullptr; a.psi_out = mc ? mc->psi_out : nullptr;
   if (mc) a.ng = mc->g;
   if (mc && coarse) return -1;

@@ -104,8 +104,9 @@ struct msom {
   int block_small = 0;   // the same kernel on the launch-bound levels only (not marched, <= block_small cells wide): 2 launches per level visit instead of 8
   int march = 1;         // chained half-sweeps in register windows (kernels_march.hip) on wide single-GPU levels
   int march_k = 4;       // at most this many half-sweeps per pass (2..4)
+  int march_partial = 1; // a pass that is followed by more half-sweeps stores only the colour of its last half-sweep
   int march_min = 23;    // log2 of the cell-layers a level needs for the chained pass (2^23: 2048^2 x 3 1.83 -> 1.78 ms/step, and the 2048 x 1024 x 6 tiles of BASELINE's 2 x 4 layout qualify; 2^22 loses: 1024^2 x 6 2.76 -> 2.87)
-  int march_correct = 0; // the last pass of the finest level writes psi + da instead of da; measured neutral (the pass runs at 4.3 TB/s, the post-cycle pass it relieves at 5.8): off
+  int march_correct = 1; // the last pass of the finest level writes psi + da instead of da (psi rows by LDS-DMA, deferred write): 7.02 -> 6.86 ms per step at 4096^2 x 6
   int corr_req = 0, corr_done = 0;  // set around mg_cycle_levels by mg_solve / by the pass that did it
   int march_prolong = 1; // whole levels: prolongation folded into the first pass ((PL + 4) + 4 half-sweeps; coarse rows by LDS-DMA, kernels_march.hip): 7.63 -> 7.09 ms per step at 4096^2 x 6
   int mg_fused = 1;  // fused residual+restriction and correction+residual passes of the multigrid cycle
@@ -625,6 +626,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "march")) m->march = (int)v;
   else if (!strcmp(key, "march_rows")) g_march_rows = (int)v;
   else if (!strcmp(key, "march_min")) m->march_min = (int)v;
+  else if (!strcmp(key, "march_partial")) m->march_partial = (int)v;
   else if (!strcmp(key, "march_prolong")) m->march_prolong = (int)v;
   else if (!strcmp(key, "march_correct")) m->march_correct = (int)v;
   else if (!strcmp(key, "march_xcd")) { extern int g_march_remap; g_march_remap = (int)v; }
@@ -1066,7 +1068,8 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
       int K = n < kmax ? n : kmax;
       if (n - K == 1 && K > 3) K--;
       if (prof) prof_begin(m, m->prof_march_pl);
-      if (launch_relax_march(m->st, nullptr, *L.da_alt, L.res, *L.sg, nl, *L.rc, 0, K, L.walls, g_march_rows, nullptr, *coarse->da, coarse->sg)) m->sticky = MSOM_ERR_ARG;
+      if (launch_relax_march(m->st, nullptr, *L.da_alt, L.res, *L.sg, nl, *L.rc, 0, K, L.walls, g_march_rows, nullptr, *coarse->da, coarse->sg, nullptr, m->march_partial && n - K >= 1))
+        m->sticky = MSOM_ERR_ARG;
       if (prof) prof_end(m, m->prof_march_pl);
       std::swap(*L.da, *L.da_alt);
       n -= K; c = K & 1;
@@ -1085,7 +1088,7 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
       MarchCorrect mc{m->f[MSOM_PSI], m->psi_alt, m->g};
       if (prof) prof_begin(m, m->prof_march[K]);
       if (launch_relax_march(m->st, *L.da, *L.da_alt, L.res, *L.sg, nl, *L.rc, c, K, L.walls, g_march_rows, L.tiled ? &mh : nullptr, nullptr, nullptr,
-                             corr ? &mc : nullptr))
+                             corr ? &mc : nullptr, m->march_partial && n - K >= 1))
         m->sticky = MSOM_ERR_ARG;
       if (prof) prof_end(m, m->prof_march[K]);
       n -= K; c = (c + K) & 1;
@@ -1262,6 +1265,7 @@ static int mg_solve(msom *m, const double *b, msom_mgstats *s) {
     if (m->corr_done) {  // a_new = a + da already sits in psi_alt (last smoother pass): boundary(a), then max |res|, max |u|
       std::swap(m->f[MSOM_PSI], m->psi_alt);
       if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], m->nl, m->bc, 1));
+      else launch_fill_ghost(m->st, m->f[MSOM_PSI], m->g, m->nl, m->bc, m->walls);   // the LDS-DMA pass leaves the wall ghosts to this
       residual2(m, 8, b, SC_RES1, 0);
       m->umax_ready = 1;
     } else if (fused) {
