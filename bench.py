@@ -206,14 +206,17 @@ class Leg:
         plain_bytes = (3.0 + sigma) * w / 2.0
         spec = [
             ("march4", "k_relax_march_dma<nl,4> (4 chained red-black half-sweeps per pass, rows by LDS-DMA)", 2.5 * w, "other colour in w/2 + residual w + both colours out w"),
-            ("march_pl", "k_relax_march_dma<nl,4,PL> (bilinear prolongation + 4 chained half-sweeps: first pass of a level visit)", 2.25 * w,
-             "coarse correction w/4 + residual w + both colours out w"),
+            ("march_pl", "k_relax_march_dma<nl,4,PL> (bilinear prolongation + 4 chained half-sweeps: first pass of a level visit)", 1.75 * w,
+             "coarse correction w/4 + residual w + last colour out w/2 (the other colour is recomputed by the next pass before anything reads it)"),
+            ("march_corr", "k_relax_march_dma<nl,4,CORR> (4 chained half-sweeps + correction psi += da: last pass of the cycle)", 3.5 * w,
+             "other colour in w/2 + residual w + psi in w + psi out w"),
             ("march3", "k_relax_march<nl,3> (3 chained half-sweeps per pass)", 2.5 * w, "as march4"),
             ("march2", "k_relax_march<nl,2>", 2.5 * w, "as march4"),
             ("sweep", "k_relax_color_x2 red + black (two launches)", 2.0 * plain_bytes, "per colour: other colour in, own residual in [, S], own colour out"),
             ("red_prolong", "k_relax_red_prolong3 (first red half-sweep + bilinear prolongation)", 1.25 * w, "residual w/2 + coarse w/4 + red out w/2"),
             ("resid_restrict", "k_residual2<write+restrict> (pre-cycle residual + first restriction)", 3.25 * w, "psi, q in, residual out, level-1 residual out w/4"),
             ("resid_correct", "k_correct_residual (psi += da, residual max, max|u|)", 4.0 * w, "psi, da, q in, psi out"),
+            ("resid_max", "k_correct_residual<max only> (max|res|, max|u| of the corrected psi)", 2.0 * w, "psi, q in"),
             ("rhs", "k_rhs_lpw (Arakawa Jacobians + beta + dissipation + drag + forcing + advance)", 3.0 * w, "psi, q_in in, q_out out"),
         ]
         out = {}
@@ -231,11 +234,11 @@ class Leg:
 def roofline(leg, world):
     ks, w, plain_bytes, uniform = leg.kernels()
     nl = leg.nl
-    dom = next((k for k in ("march4", "march3", "march2") if k in ks), "sweep" if "sweep" in ks else None)
+    dom = next((k for k in ("march_corr", "march4", "march3", "march2") if k in ks), "sweep" if "sweep" in ks else None)
     if dom is None:
         return {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None, "kernels": ks}
     d = ks[dom]
-    K = int(dom[-1]) if dom.startswith("march") else 2
+    K = 4 if dom == "march_corr" else (int(dom[-1]) if dom.startswith("march") else 2)
     nbytes, ms = d["compulsory_bytes_per_launch"], d["avg_launch_ms"]
     if dom == "sweep":      # two launches per timed pair: report one colour half-sweep launch
         nbytes, ms, K = nbytes / 2.0, ms / 2.0, 1
@@ -246,7 +249,7 @@ def roofline(leg, world):
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_march.json")))
         if (leg.tx, leg.ty, nl, world) == (4096, 4096, 6, 1) and uniform and dom.startswith("march"):
-            traffic = pmc.get(f"traffic_bytes_per_launch_K{K}")
+            traffic = pmc.get(f"traffic_bytes_per_launch_{dom}")
     except Exception:
         pass
     # SURVEY 8(d)'s accounting unit for the smoother is a red+black SWEEP = (3 + sigma) w [R a, R b, W a]; a pass of K

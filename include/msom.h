@@ -217,7 +217,8 @@ int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, double add, doub
 /* ---- measurement: average HIP-event duration (events recorded on the library's own stream while the option
  * "profile" is on, i.e. inside the timed steps) of the finest-level launches named
  *   "sweep" (red + black half-sweep pair), "march2" / "march3" / "march4" (passes of K chained half-sweeps),
- *   "march_pl" (first pass of a level visit: prolongation + K half-sweeps),
+ *   "march_pl" (first pass of a level visit: prolongation + K half-sweeps), "march_corr" (last pass of the cycle: K half-sweeps
+ *   + correction), "resid_max" (max|res|, max|u| of the corrected psi),
  *   "red_prolong" (first red half-sweep + prolongation), "resid_restrict" (pre-cycle residual + restriction),
  *   "resid_correct" (correction + residual + max|u|), "residual" (both of the former), "rhs" (fused PV tendency
  *   [+ advance] pass), "block2";

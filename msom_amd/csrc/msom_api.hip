@@ -136,6 +136,7 @@ struct msom {
   int profile = 0;
   ProfSlot prof_sweep, prof_resid, prof_block, prof_march[5];  // prof_march[K]: passes of K chained half-sweeps
   ProfSlot prof_march_pl;  // first pass of a level with the prolongation folded in
+  ProfSlot prof_march_corr, prof_resmax;  // last pass of the finest level with the correction folded in; max-only residual pass after it
   ProfSlot prof_rhs, prof_redprol, prof_rescorr, prof_respre;   // tendency pass, finest red+prolongation, post- / pre-cycle residual passes
 };
 
@@ -594,7 +595,7 @@ extern "C" int msom_destroy(msom_t *m) {
   if (m->d_scal) hipFree(m->d_scal);
   if (m->h_scal) hipHostFree(m->h_scal);
   if (m->d_wind) hipFree(m->d_wind);
-  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4], &m->prof_rhs, &m->prof_redprol, &m->prof_rescorr, &m->prof_respre, &m->prof_march_pl})
+  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4], &m->prof_rhs, &m->prof_redprol, &m->prof_rescorr, &m->prof_respre, &m->prof_march_pl, &m->prof_march_corr, &m->prof_resmax})
     for (auto e : ps->ev) hipEventDestroy(e);
   if (m->comm) comm_destroy(m->comm);
   if (m->ev_c2x) hipEventDestroy(m->ev_c2x);
@@ -1086,11 +1087,11 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
       // the very last pass of the finest level can apply the correction itself: psi_alt = psi + da (mg_solve swaps)
       const bool corr = m->corr_req && L.fine && n == K;
       MarchCorrect mc{m->f[MSOM_PSI], m->psi_alt, m->g};
-      if (prof) prof_begin(m, m->prof_march[K]);
+      if (prof) prof_begin(m, corr ? m->prof_march_corr : m->prof_march[K]);
       if (launch_relax_march(m->st, *L.da, *L.da_alt, L.res, *L.sg, nl, *L.rc, c, K, L.walls, g_march_rows, L.tiled ? &mh : nullptr, nullptr, nullptr,
                              corr ? &mc : nullptr, m->march_partial && n - K >= 1))
         m->sticky = MSOM_ERR_ARG;
-      if (prof) prof_end(m, m->prof_march[K]);
+      if (prof) prof_end(m, corr ? m->prof_march_corr : m->prof_march[K]);
       n -= K; c = (c + K) & 1;
       if (corr) { m->corr_done = 1; return; }  // da of this level was consumed in registers; nothing reads it any more
       std::swap(*L.da, *L.da_alt);
@@ -1200,7 +1201,7 @@ static void residual(msom *m, const double *a, const double *b, int slot, int wa
 }
 // fused variants (kernels_mg.hip k_residual2); mode bits 1 = CORRECT, 2 = WRITE, 4 = RESTRICT
 static void residual2(msom *m, int mode, const double *b, int slot, int want_sum) {
-  ProfSlot &which = (mode & 1) ? m->prof_rescorr : m->prof_respre;
+  ProfSlot &which = (mode & 8) ? m->prof_resmax : (mode & 1) ? m->prof_rescorr : m->prof_respre;
   if (m->profile) { prof_begin(m, m->prof_resid); prof_begin(m, which); }
   launch_residual2(m->st, mode, m->f[MSOM_PSI], m->da[0], m->psi_alt, b, m->f[MSOM_S], m->g, m->res[0], m->sg[0],
                    m->nlev > 1 ? m->res[1] : nullptr, m->sg[m->nlev > 1 ? 1 : 0], m->nl, m->rc[0], m->uniformS, m->walls, m->d_scal + slot,
@@ -2309,14 +2310,14 @@ extern "C" int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, doubl
 
 extern "C" int msom_profile_reset(msom_t *m) {
   if (!m) return MSOM_ERR_ARG;
-  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4], &m->prof_rhs, &m->prof_redprol, &m->prof_rescorr, &m->prof_respre, &m->prof_march_pl}) { ps->used = 0; ps->total_ms = 0; ps->launches = 0; }
+  for (auto *ps : {&m->prof_sweep, &m->prof_resid, &m->prof_block, &m->prof_march[2], &m->prof_march[3], &m->prof_march[4], &m->prof_rhs, &m->prof_redprol, &m->prof_rescorr, &m->prof_respre, &m->prof_march_pl, &m->prof_march_corr, &m->prof_resmax}) { ps->used = 0; ps->total_ms = 0; ps->launches = 0; }
   return MSOM_OK;
 }
 extern "C" int msom_profile_read(msom_t *m, const char *kernel, double *avg_ms, long *launches) {
   if (!m || !kernel) return MSOM_ERR_ARG;
   ProfSlot *ps = !strcmp(kernel, "sweep") ? &m->prof_sweep : !strcmp(kernel, "residual") ? &m->prof_resid : !strcmp(kernel, "block2") ? &m->prof_block :
                  !strcmp(kernel, "march2") ? &m->prof_march[2] : !strcmp(kernel, "march3") ? &m->prof_march[3] : !strcmp(kernel, "march4") ? &m->prof_march[4] :
-                 !strcmp(kernel, "march_pl") ? &m->prof_march_pl : !strcmp(kernel, "rhs") ? &m->prof_rhs : !strcmp(kernel, "red_prolong") ? &m->prof_redprol : !strcmp(kernel, "resid_correct") ? &m->prof_rescorr :
+                 !strcmp(kernel, "march_pl") ? &m->prof_march_pl : !strcmp(kernel, "march_corr") ? &m->prof_march_corr : !strcmp(kernel, "resid_max") ? &m->prof_resmax : !strcmp(kernel, "rhs") ? &m->prof_rhs : !strcmp(kernel, "red_prolong") ? &m->prof_redprol : !strcmp(kernel, "resid_correct") ? &m->prof_rescorr :
                  !strcmp(kernel, "resid_restrict") ? &m->prof_respre : nullptr;
   if (!ps) { msom_set_error("unknown kernel %s", kernel); return MSOM_ERR_ARG; }
   prof_collect(m, *ps);
