@@ -11,9 +11,11 @@ enum { RED_MAX = 0, RED_MIN = 1, RED_SUM = 2 };
 // directions of the 8 neighbours (buffer slots)
 enum { DIR_W = 0, DIR_E = 1, DIR_S = 2, DIR_N = 3, DIR_SW = 4, DIR_SE = 5, DIR_NW = 6, DIR_NE = 7 };
 
+// directions W E S N SW SE NW NE and their opposites
+static const int COMM_OPP[8] = {1, 0, 3, 2, 7, 6, 5, 4};
 struct Xfer {
   int peer;        // rank of the neighbour
-  int tag;         // direction of travel, so that the two ends pair up (sender dir d <-> receiver dir opposite(d))
+  int tag;         // direction (DIR_*) of this tile's edge = direction the sent message travels in
   double *send, *recv;
   size_t count;    // doubles (same in both directions)
 };

@@ -262,17 +262,26 @@ double *comm_sendbuf(Comm *c, int dir) { return c->sendbuf[dir]; }
 double *comm_recvbuf(Comm *c, int dir) { return c->recvbuf[dir]; }
 size_t comm_bufcount(const Comm *c) { return c->bufcount; }
 
-// all messages of one exchange: x[k].send -> peer's x[k'].recv where the peer's entry k' has
-// peer == my rank and tag == x[k].tag
+// all messages of one exchange.  Entry k describes the edge in direction tag = d of this tile: its send buffer travels in
+// direction d, its receive buffer takes the peer's message travelling in direction OPP[d] (the peer's entry for OPP[d])
 int comm_exchange(Comm *c, const Xfer *x, int nx) {
   if (!c || c->kind == COMM_NONE) return MSOM_OK;
   if (c->kind == COMM_RCCL) {
     if (nx == 0) return MSOM_OK;
+    // Within a group the sends of one rank to a peer pair up with that peer's receives in posting order.  When both neighbours
+    // of an axis are the same rank (periodic tiling, 1 or 2 tiles per side) two messages go to one peer: sends are posted in
+    // the order of their direction, receives in the order of the direction the incoming message travels in (the opposite).
+    int so[16], ro[16];
+    if (nx > 16) return MSOM_ERR_ARG;
+    for (int k = 0; k < nx; k++) so[k] = ro[k] = k;
+    for (int a = 1; a < nx; a++)
+      for (int b = a; b > 0; b--) {
+        if (x[so[b]].tag < x[so[b - 1]].tag) { const int t = so[b]; so[b] = so[b - 1]; so[b - 1] = t; }
+        if (COMM_OPP[x[ro[b]].tag & 7] < COMM_OPP[x[ro[b - 1]].tag & 7]) { const int t = ro[b]; ro[b] = ro[b - 1]; ro[b - 1] = t; }
+      }
     NCCLCHK(g_rccl.GroupStart());
-    for (int k = 0; k < nx; k++) {
-      NCCLCHK(g_rccl.Send(x[k].send, x[k].count, ncclDouble, x[k].peer, c->nccl, c->st));
-      NCCLCHK(g_rccl.Recv(x[k].recv, x[k].count, ncclDouble, x[k].peer, c->nccl, c->st));
-    }
+    for (int k = 0; k < nx; k++) NCCLCHK(g_rccl.Send(x[so[k]].send, x[so[k]].count, ncclDouble, x[so[k]].peer, c->nccl, c->st));
+    for (int k = 0; k < nx; k++) NCCLCHK(g_rccl.Recv(x[ro[k]].recv, x[ro[k]].count, ncclDouble, x[ro[k]].peer, c->nccl, c->st));
     NCCLCHK(g_rccl.GroupEnd());
     return MSOM_OK;
   }
@@ -288,7 +297,7 @@ int comm_exchange(Comm *c, const Xfer *x, int nx) {
     const int pn = h->posted_n[x[k].peer];
     const Xfer *src = nullptr;
     for (int q = 0; q < pn; q++)
-      if (px[q].peer == c->rank && px[q].tag == x[k].tag) src = &px[q];
+      if (px[q].peer == c->rank && px[q].tag == COMM_OPP[x[k].tag & 7]) src = &px[q];
     if (!src || src->count != x[k].count || x[k].count > c->bufcount) {
       msom_set_error("local exchange: no matching message from rank %d tag %d", x[k].peer, x[k].tag);
       err = MSOM_ERR_COMM;
@@ -442,7 +451,9 @@ extern "C" int msom_dbg_rccl_selftest(void) {
     std::vector<double> out(6 * n, 0.);
     HIPCHKC(hipMemcpyAsync(out.data(), d, 6 * n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHKC(hipStreamSynchronize(st));
-    for (int k = 0; k < 2 * n; k++) bad += out[2 * n + k] != 1.5 * k - 7.;
+    // a tile that is its own W and E neighbour (periodic, one tile per side): the W edge receives what the E edge sent and
+    // vice versa -- the pairing by direction of travel and posting order of comm_exchange, on the real library
+    for (int k = 0; k < n; k++) bad += out[2 * n + k] != 1.5 * (n + k) - 7. || out[3 * n + k] != 1.5 * k - 7.;
     for (int k = 0; k < n; k++) bad += out[4 * n + k] != 1.5 * k - 7.;
     bad += hs[0] != 1.5 * 1 - 7. || hs[1] != 1.5 * 2 - 7.;
   }

@@ -211,7 +211,10 @@ static int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 static const int OPP[8] = {DIR_E, DIR_W, DIR_N, DIR_S, DIR_NE, DIR_NW, DIR_SE, DIR_SW};
 // both ends of a neighbour pair label their message with the same axis id
-#define AXIS(dir) ((dir) < OPP[dir] ? (dir) : OPP[dir])
+// a message is labelled with the direction it travels in (the sender's); the receiving end of direction d pairs with the peer's
+// message of direction OPP[d] (comm.hip).  On a periodic tiling with 1 or 2 tiles per side both neighbours of an axis are the
+// same rank (or the tile itself): the direction tells the two messages apart.
+#define AXIS(dir) (dir)
 
 // communication stream <-> compute stream ordering (tiled runs)
 static void comm_begin(msom *m) {  // st2 continues after everything queued on st so far
@@ -496,9 +499,13 @@ static msom *create_common(const Params &p0, int px, int py, int rank, const voi
     msom_set_error("nptr = %d outside 0..%d", p.nptr, MSOM_MAXNL);
     return nullptr;
   }
-  if (p.sbc == -1 && px * py > 1) {
-    msom_set_error("sbc = -1 (doubly periodic) is supported on a single tile only");
-    return nullptr;
+  if (p.sbc == -1 && px * py > 1) {  // periodic(right); periodic(top) under MPI, msqg/qg.h:842-846: the tile neighbours wrap around
+    bool pg = false;
+    for (int l = 0; l < p.nl; l++) pg = pg || p.upg[l] != 0. || p.vpg[l] != 0.;
+    if (pg) {
+      msom_set_error("sbc = -1 on tiles: the large-scale flow upg / vpg (linear-Dirichlet stream function, msqg/qg.h:1105-1114) is supported on a single tile only");
+      return nullptr;
+    }
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
@@ -515,7 +522,9 @@ static msom *create_common(const Params &p0, int px, int py, int rank, const voi
   m->walls = 0;
   if (p.sbc == -1) {  // periodic(right); periodic(top), msqg/qg.h:842-846
     m->bc = BC_PERIODIC;
-    m->walls = WALL_PER;
+    // one tile: ghost cells are wrapped copies kept by the owning thread (WALL_PER); tiles: no walls at all, every edge is
+    // an exchange with the (wrapped) neighbour
+    m->walls = px * py > 1 ? 0 : WALL_PER;
   } else {
     if (m->ix == 0) m->walls |= WALL_W;
     if (m->ix == px - 1) m->walls |= WALL_E;
@@ -528,7 +537,8 @@ static msom *create_common(const Params &p0, int px, int py, int rank, const voi
     const int dx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, dy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
     for (int d = 0; d < 8; d++) {
       const int jx = m->ix + dx[d], jy = m->iy + dy[d];
-      if (jx >= 0 && jx < px && jy >= 0 && jy < py) m->nb[d] = jy * px + jx;
+      if (p.sbc == -1 && px * py > 1) m->nb[d] = ((jy + py) % py) * px + (jx + px) % px;
+      else if (jx >= 0 && jx < px && jy >= 0 && jy < py) m->nb[d] = jy * px + jx;
     }
   }
   if (alloc_all(m) != MSOM_OK ||
@@ -867,7 +877,7 @@ static int setup_mg_coarse(msom *m) {
   CoarseArgs h;
   memset(&h, 0, sizeof h);
   h.n = m->nlev - k0;
-  h.walls = glob ? WALL_ALL : m->walls;
+  h.walls = glob ? (m->bc == BC_PERIODIC ? WALL_PER : WALL_ALL) : m->walls;
   h.prolong_fused = m->prolong_fused;
   for (int k = k0; k < m->nlev; k++) {
     CoarseLev &L = h.lev[k - k0];
@@ -1007,7 +1017,7 @@ static Lev tile_lev(msom *m, int k) {
 }
 static Lev glob_lev(msom *m, int k) {
   const int q = k - m->agg_level;
-  return Lev{&m->gda[q], &m->gda_alt[q], m->gres[q], nullptr, &m->gsg[q], &m->rc[k], WALL_ALL, false, false, -1};
+  return Lev{&m->gda[q], &m->gda_alt[q], m->gres[q], nullptr, &m->gsg[q], &m->rc[k], m->bc == BC_PERIODIC ? WALL_PER : WALL_ALL, false, false, -1};
 }
 
 // can the level use the temporally blocked smoother (k_relax_block: 2 sweeps per pass)?
@@ -1351,7 +1361,7 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
   if (m->fused && !m->have_pg && !m->have_zpg && !m->flag_topo && !m->stochastic && (m->nranks == 1 || (m->nx >= 4 && m->ny >= 4))) {
     // tiles: the fused kernel needs psi on a 3-cell halo (zeta on 2, lap(zeta) on 1)
     if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], nl, m->bc, 3));
-    if (m->bc == BC_PERIODIC) launch_fill_periodic(m->st, m->f[MSOM_PSI], m->g, nl, 3);
+    if (m->bc == BC_PERIODIC && m->nranks == 1) launch_fill_periodic(m->st, m->f[MSOM_PSI], m->g, nl, 3);
     if (!m->adv_fused) adv_out = -1;
     // the advance rides along: the pass can also emit the first residual of the inversion of q[adv_out]
     // the residual by-product exists only in the LDS-tile kernel: asking for it selects that kernel

@@ -21,18 +21,38 @@ def tile_of_rank(rank, px, py):
     return rank % px, rank // px
 
 
-def neighbours(rank, px, py):
+OPPOSITE = dict(W="E", E="W", S="N", N="S", SW="NE", NE="SW", SE="NW", NW="SE")
+
+
+def neighbours(rank, px, py, periodic=False):
+    """periodic (sbc = -1 on tiles, msqg/qg.h:842-846): the neighbours wrap around; with 1 or 2 tiles per side both
+    neighbours of an axis are the same rank (or the tile itself)"""
     ix, iy = tile_of_rank(rank, px, py)
     out = {}
     for name, (dx, dy) in DIRS.items():
         jx, jy = ix + dx, iy + dy
-        out[name] = jy * px + jx if (0 <= jx < px and 0 <= jy < py) else -1
+        if periodic:
+            out[name] = (jy % py) * px + jx % px
+        else:
+            out[name] = jy * px + jx if (0 <= jx < px and 0 <= jy < py) else -1
     return out
 
 
-def walls(rank, px, py):
+def walls(rank, px, py, periodic=False):
     ix, iy = tile_of_rank(rank, px, py)
+    if periodic:
+        return dict(W=False, E=False, S=False, N=False)
     return dict(W=ix == 0, E=ix == px - 1, S=iy == 0, N=iy == py - 1)
+
+
+def exchange_order(names):
+    """posting order of one exchange (comm.hip): sends in the order of the direction they travel in, receives in the order
+    of the direction the INCOMING message travels in (the opposite of the edge), so that two messages between the same
+    pair of ranks pair up"""
+    order = list(DIRS)
+    sends = sorted(names, key=order.index)
+    recvs = sorted(names, key=lambda n: order.index(OPPOSITE[n]))
+    return sends, recvs
 
 
 def tile_slice(rank, px, py, nx, ny):

@@ -356,3 +356,38 @@ def test_baseline_c4_layout_2x4_tiles_of_2048x1024x6():
     assert np.abs(p - ref).max() <= 1e-10 * np.abs(ref).max()
     for r in range(px * py):
         assert out[r]["dts"] == [dt] and out[r]["st"].i == g.mgstats().i
+
+
+@pytest.mark.parametrize("px,py,tile,nl", [(2, 2, 32, 3), (2, 1, 32, 2), (1, 2, 32, 3), (2, 4, 16, 2), (2, 2, 512, 2)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_periodic_domain_on_tiles(px, py, tile, nl, strict):
+    """sbc = -1 (doubly periodic, msqg/qg.h:842-846) on tiles: the neighbours wrap around, no tile has a wall, with 1 or 2
+    tiles per side both neighbours of an axis are the same rank (or the tile itself).  Equal to the periodic single tile bit
+    for bit (strict and product builds), incl. the agglomerated periodic coarse grid."""
+    gnx, gny = tile * px, tile * py
+    levels = int(np.log2(tile))
+    extra = (f"Ny = {gny}\n" if gny != gnx else "") + f"MGLEVELS = {levels}\nsbc = -1\nTOLERANCE = 1e-8\n"
+    params = orc.double_gyre_params(gnx, nl, extra=extra)
+    x = (np.arange(gnx) + 0.5) / gnx
+    y = (np.arange(gny) + 0.5) / gny
+    psi = np.stack([1e-3 * (1 - 0.2 * l) * (np.outer(np.sin(2 * np.pi * y), np.cos(4 * np.pi * x)) + 0.5 * np.outer(np.cos(6 * np.pi * y + l), np.sin(2 * np.pi * x)))
+                    for l in range(nl)])
+    out = run_tiled(params, px, py, psi, nsteps=3, strict=strict)
+    g = QG(params, strict=strict)
+    g.option("quiet", 1)
+    g.set(F["PSI"], psi)
+    g.set_const()
+    g.set_tnext(float("inf"))
+    dts = [g.step() for _ in range(3)]
+    for r in range(px * py):
+        assert out[r]["dts"] == dts, r
+        assert (out[r]["st"].i, out[r]["st"].resa) == (g.mgstats().i, g.mgstats().resa)
+    assert np.array_equal(assemble(out, "q", px, py), g.get(F["Q"]))
+    assert np.array_equal(assemble(out, "psi", px, py), g.get(F["PSI"]))
+
+
+def test_periodic_tiles_reject_the_large_scale_flow():
+    from msom_amd import MsomError
+    params = orc.double_gyre_params(64, 2, extra="sbc = -1\nupg = [0.1,0.0]\n")
+    with pytest.raises(MsomError, match="single tile only"):
+        QG(params, tiled=(2, 2, 0, b"MSOMLOCL" + os.urandom(8) + bytes(112)))
