@@ -117,6 +117,11 @@ struct msom {
   int quiet = 0;
   // wavelet scale filter (msqg/qg.h:509-560): pyramids s (restricted psi), r (filtered), sig_lev
   int wv_nlev = 0, wv_ready = 0;
+  // tiles: levels 0 .. wv_kt live on the tile (halo exchange per level), the levels above on a gathered top grid that every
+  // rank transforms on the host (a handful of cells); wv_top_sig[k - wv_kt]: sig_lev of the gathered levels
+  int wv_kt = 0, wv_gx = 0, wv_gy = 0;
+  std::vector<std::vector<double>> wv_top_sig;
+  double *wv_gsend = nullptr, *wv_grecv = nullptr;
   int nme_ft = 0;  // msqg/qg_energy.h:17
   // coarse levels (<= MGC_MAXDIM cells a side) solved by ONE launch (k_mg_coarse)
   CoarseArgs *d_cargs = nullptr;
@@ -249,8 +254,10 @@ static bool fits_comm(msom *m, size_t count) {
 // halo exchange of a natural field, `depth` ghost columns/rows, corners included: two phases
 // (x, then y over the x-ghost columns) with the wall BCs applied in between, exactly the
 // order of Basilisk's boundary() (x direction first).
-static int exch_nat(msom *m, double *f, int nl, int bc, int depth) {
-  const NatGeom &g = m->g;
+static int exch_nat_g(msom *m, double *f, const NatGeom &g, int nl, int bc, int depth);
+static int exch_nat(msom *m, double *f, int nl, int bc, int depth) { return exch_nat_g(m, f, m->g, nl, bc, depth); }
+// the same on any level of a natural-layout pyramid of the tile (wavelet filter)
+static int exch_nat_g(msom *m, double *f, const NatGeom &g, int nl, int bc, int depth) {
   const int d = depth;
   if (m->nranks > 1 && !fits_comm(m, (size_t)d * ((g.nx > g.ny ? g.nx : g.ny) + 2 * d) * nl)) return MSOM_ERR_ARG;
   hipStream_t cs = m->nranks > 1 ? m->st2 : m->st;  // packs, wall BCs and unpacks ride on the communication stream
@@ -592,6 +599,7 @@ extern "C" int msom_destroy(msom_t *m) {
   }
   free_agglomeration(m);
   for (size_t k = 0; k < m->wv_sig.size(); k++) {
+    if (k == 0) { if (m->wv_gsend) hipFree(m->wv_gsend); if (m->wv_grecv) hipFree(m->wv_grecv); }
     if (k > 0 && m->wv_s[k]) hipFree(m->wv_s[k]);
     if (k > 0 && m->wv_r[k]) hipFree(m->wv_r[k]);
     if (m->wv_sig[k]) hipFree(m->wv_sig[k]);
@@ -1681,17 +1689,47 @@ static int ensure_field(msom *m, int field) {
   return MSOM_OK;
 }
 // pyramid geometry + filter coefficients sig_lev (set_const, msqg/qg.h:1059-1090): init-time host pass
+// all-gather of a small tile block [nlay][ny][nx] (host in / host out: [rank][nlay][ny][nx]) through the communicator
+static int wv_gather(msom *m, const std::vector<double> &mine, std::vector<double> &all) {
+  const size_t cnt = mine.size();
+  all.resize(cnt * m->nranks);
+  HIPCHK(hipMemcpyAsync(m->wv_gsend, mine.data(), cnt * sizeof(double), hipMemcpyHostToDevice, m->st));
+  HIPCHK(hipStreamSynchronize(m->st));
+  comm_begin(m);
+  int r = comm_allgather(m->comm, m->wv_gsend, m->wv_grecv, cnt);
+  comm_end(m);
+  if (r) return r;
+  HIPCHK(hipMemcpyAsync(all.data(), m->wv_grecv, cnt * m->nranks * sizeof(double), hipMemcpyDeviceToHost, m->st));
+  HIPCHK(hipStreamSynchronize(m->st));
+  return MSOM_OK;
+}
+// gathered tile blocks -> one global array [nlay][gy][gx]
+static void wv_assemble(const msom *m, const std::vector<double> &all, int nlay, int bx, int by, std::vector<double> &out) {
+  const int gx = bx * m->px, gy = by * m->py;
+  out.assign((size_t)nlay * gx * gy, 0.);
+  for (int r = 0; r < m->nranks; r++) {
+    const int ox = (r % m->px) * bx, oy = (r / m->px) * by;
+    for (int l = 0; l < nlay; l++)
+      for (int j = 0; j < by; j++)
+        for (int i = 0; i < bx; i++) out[((size_t)l * gy + oy + j) * gx + ox + i] = all[(size_t)r * nlay * bx * by + ((size_t)l * by + j) * bx + i];
+  }
+}
+// pyramid geometry + filter coefficients sig_lev (set_const, msqg/qg.h:1059-1090): init-time host pass
 static int wavelet_setup(msom *m) {
   if (m->wv_ready) return MSOM_OK;
-  if (m->nranks > 1) { msom_set_error("the wavelet filter needs a single-tile grid"); return MSOM_ERR_STATE; }
   const Params &p = m->p;
   int r;
+  const bool tiled = m->nranks > 1;
   if (m->wv_nlev == 0) {
-    int n = 1;
-    while ((m->nx >> n) >= 1 && (m->ny >> n) >= 1 && ((m->nx >> n) << n) == m->nx && ((m->ny >> n) << n) == m->ny) n++;
-    m->wv_nlev = n;  // Basilisk levels depth() ... 0
-    m->wv_g.resize(n); m->wv_s.assign(n, nullptr); m->wv_r.assign(n, nullptr); m->wv_sig.assign(n, nullptr);
-    for (int k = 0; k < n; k++) {
+    int n = 1;   // Basilisk levels depth() ... 0 of the GLOBAL grid
+    while ((m->gnx >> n) >= 1 && (m->gny >> n) >= 1 && ((m->gnx >> n) << n) == m->gnx && ((m->gny >> n) << n) == m->gny) n++;
+    m->wv_nlev = n;
+    int kt = 0;  // coarsest level that still has a cell of every tile
+    while (kt + 1 < n && (m->nx >> (kt + 1)) >= 1 && (m->ny >> (kt + 1)) >= 1) kt++;
+    m->wv_kt = tiled ? kt : n - 1;
+    const int nt = m->wv_kt + 1;
+    m->wv_g.resize(nt); m->wv_s.assign(nt, nullptr); m->wv_r.assign(nt, nullptr); m->wv_sig.assign(nt, nullptr);
+    for (int k = 0; k < nt; k++) {
       m->wv_g[k] = make_nat(m->nx >> k, m->ny >> k);
       const size_t ls = m->wv_g[k].ls;
       HIPCHK(hipMalloc(&m->wv_sig[k], ls * sizeof(double)));
@@ -1702,8 +1740,14 @@ static int wavelet_setup(msom *m) {
       HIPCHK(hipMemsetAsync(m->wv_s[k], 0, ls * m->nl * sizeof(double), m->st));
       HIPCHK(hipMemsetAsync(m->wv_r[k], 0, ls * m->nl * sizeof(double), m->st));
     }
+    if (tiled) {
+      const size_t blk = (size_t)(m->nx >> kt) * (m->ny >> kt) * (m->nl > 2 ? m->nl : 2);
+      HIPCHK(hipMalloc(&m->wv_gsend, blk * sizeof(double)));
+      HIPCHK(hipMalloc(&m->wv_grecv, blk * m->nranks * sizeof(double)));
+      m->wv_gx = (m->nx >> kt) * m->px; m->wv_gy = (m->ny >> kt) * m->py;
+    }
   }
-  const int K = m->wv_nlev;
+  const int K = m->wv_kt + 1;   // levels on the tile
   std::vector<std::vector<double>> sf(K), sl(K);
   sf[0].resize((size_t)m->nx * m->ny);
   HIPCHK(hipStreamSynchronize(m->st));
@@ -1711,36 +1755,59 @@ static int wavelet_setup(msom *m) {
   HIPCHK(hipMemcpyAsync(sf[0].data(), m->staging, sf[0].size() * sizeof(double), hipMemcpyDeviceToHost, m->st));
   HIPCHK(hipStreamSynchronize(m->st));
   for (double &v : sf[0]) v = fmin(p.afilt * v, p.Lfmax);  // sig_filt = min(afilt * Rd, Lfmax) :1060
-  for (int k = 1; k < K; k++) {  // restriction({sig_filt}) :1063
-    const int nx = m->nx >> k, ny = m->ny >> k, fx = nx * 2;
-    sf[k].resize((size_t)nx * ny);
+  auto restrict_host = [](const std::vector<double> &f, int nx, int ny, std::vector<double> &c) {  // restriction({sig_filt}) :1063
+    const int fx = nx * 2;
+    c.resize((size_t)nx * ny);
     for (int j = 0; j < ny; j++)
       for (int i = 0; i < nx; i++) {
         double sum = 0.;
-        sum += sf[k - 1][(size_t)(2 * j) * fx + 2 * i]; sum += sf[k - 1][(size_t)(2 * j + 1) * fx + 2 * i];
-        sum += sf[k - 1][(size_t)(2 * j) * fx + 2 * i + 1]; sum += sf[k - 1][(size_t)(2 * j + 1) * fx + 2 * i + 1];
-        sf[k][(size_t)j * nx + i] = sum / 4;
+        sum += f[(size_t)(2 * j) * fx + 2 * i]; sum += f[(size_t)(2 * j + 1) * fx + 2 * i];
+        sum += f[(size_t)(2 * j) * fx + 2 * i + 1]; sum += f[(size_t)(2 * j + 1) * fx + 2 * i + 1];
+        c[(size_t)j * nx + i] = sum / 4;
       }
-  }
-  for (int k = 0; k < K; k++) {  // low pass, from the finest level down :1066-1083
-    const int nx = m->nx >> k, ny = m->ny >> k, fx = nx * 2;
+  };
+  auto lowpass_host = [&](const std::vector<double> &sfk, const std::vector<double> *child, int nx, int ny, int k, std::vector<double> &out) {  // :1066-1083
+    const int fx = nx * 2;
     const double Delta = p.L0 / (double)(m->gnx >> k);
-    sl[k].resize((size_t)nx * ny);
+    out.resize((size_t)nx * ny);
     for (int j = 0; j < ny; j++)
       for (int i = 0; i < nx; i++) {
         double ref_flag = 0;
-        if (k > 0) {
-          ref_flag += sl[k - 1][(size_t)(2 * j) * fx + 2 * i]; ref_flag += sl[k - 1][(size_t)(2 * j + 1) * fx + 2 * i];
-          ref_flag += sl[k - 1][(size_t)(2 * j) * fx + 2 * i + 1]; ref_flag += sl[k - 1][(size_t)(2 * j + 1) * fx + 2 * i + 1];
+        if (child) {
+          ref_flag += (*child)[(size_t)(2 * j) * fx + 2 * i]; ref_flag += (*child)[(size_t)(2 * j + 1) * fx + 2 * i];
+          ref_flag += (*child)[(size_t)(2 * j) * fx + 2 * i + 1]; ref_flag += (*child)[(size_t)(2 * j + 1) * fx + 2 * i + 1];
         }
-        const double s = sf[k][(size_t)j * nx + i];
+        const double sv = sfk[(size_t)j * nx + i];
         double v;
         if (ref_flag > 0) v = 1;
-        else if (s > 2 * Delta) v = 0;
-        else if (s <= 2 * Delta && s > Delta) v = 1 - (s - Delta) / Delta;
+        else if (sv > 2 * Delta) v = 0;
+        else if (sv <= 2 * Delta && sv > Delta) v = 1 - (sv - Delta) / Delta;
         else v = 1;
-        sl[k][(size_t)j * nx + i] = v;
+        out[(size_t)j * nx + i] = v;
       }
+  };
+  for (int k = 1; k < K; k++) restrict_host(sf[k - 1], m->nx >> k, m->ny >> k, sf[k]);
+  for (int k = 0; k < K; k++) lowpass_host(sf[k], k > 0 ? &sl[k - 1] : nullptr, m->nx >> k, m->ny >> k, k, sl[k]);
+  if (tiled) {  // the levels above the tiles: gathered sig_filt and low-pass flags of level kt, continued on the global top grid
+    const int kt = m->wv_kt, bx = m->nx >> kt, by = m->ny >> kt;
+    std::vector<double> mine((size_t)2 * bx * by), all, top;
+    std::copy(sf[kt].begin(), sf[kt].end(), mine.begin());
+    std::copy(sl[kt].begin(), sl[kt].end(), mine.begin() + (size_t)bx * by);
+    if ((r = wv_gather(m, mine, all))) return r;
+    wv_assemble(m, all, 2, bx, by, top);
+    int gx = m->wv_gx, gy = m->wv_gy;
+    std::vector<double> tsf(top.begin(), top.begin() + (size_t)gx * gy), tsl(top.begin() + (size_t)gx * gy, top.end());
+    m->wv_top_sig.assign(m->wv_nlev - kt, std::vector<double>());
+    m->wv_top_sig[0] = tsl;
+    for (int k = kt + 1; k < m->wv_nlev; k++) {
+      std::vector<double> csf, csl;
+      gx >>= 1; gy >>= 1;
+      restrict_host(tsf, gx, gy, csf);
+      lowpass_host(csf, &tsl, gx, gy, k, csl);
+      m->wv_top_sig[k - kt] = csl;
+      tsf.swap(csf); tsl.swap(csl);
+    }
+    for (auto &v : m->wv_top_sig) for (double &q : v) q = 1 - q;   // high pass :1086-1090
   }
   for (int k = 0; k < K; k++) {  // high pass :1086-1090, then to the device
     for (double &v : sl[k]) v = 1 - v;
@@ -1749,35 +1816,116 @@ static int wavelet_setup(msom *m) {
                             hipMemcpyHostToDevice, m->st));
   }
   HIPCHK(hipStreamSynchronize(m->st));
-  (void)r;
   m->wv_ready = 1;
   return MSOM_OK;
 }
 static void wv_fill(msom *m, double *f, const NatGeom &g) {
+  if (m->nranks > 1) { STICKY(m, exch_nat_g(m, f, g, m->nl, m->bc, 1)); return; }
   if (m->bc == BC_PERIODIC) launch_fill_periodic(m->st, f, g, m->nl, 1);
   else launch_fill_ghost(m->st, f, g, m->nl, m->bc, m->walls);
 }
+// host arrays of the gathered top levels: [nl][gy + 2][gx + 2] with a ghost ring filled like boundary() does
+struct WvTop {
+  int gx, gy, nl;
+  std::vector<double> v;
+  double &at(int l, int j, int i) { return v[((size_t)l * (gy + 2) + (j + 1)) * (gx + 2) + (i + 1)]; }
+  void init(int gx_, int gy_, int nl_) { gx = gx_; gy = gy_; nl = nl_; v.assign((size_t)nl * (gx + 2) * (gy + 2), 0.); }
+  void fill(int bc) {  // x sides first, then y over the x-ghost columns (corners = y rule of the x ghost)
+    for (int l = 0; l < nl; l++) {
+      for (int j = 0; j < gy; j++) {
+        if (bc == BC_PERIODIC) { at(l, j, -1) = at(l, j, gx - 1); at(l, j, gx) = at(l, j, 0); }
+        else if (bc == BC_NEUMANN) { at(l, j, -1) = at(l, j, 0); at(l, j, gx) = at(l, j, gx - 1); }
+        else { at(l, j, -1) = -at(l, j, 0); at(l, j, gx) = -at(l, j, gx - 1); }
+      }
+      for (int i = -1; i <= gx; i++) {
+        if (bc == BC_PERIODIC) { at(l, -1, i) = at(l, gy - 1, i); at(l, gy, i) = at(l, 0, i); }
+        else if (bc == BC_NEUMANN) { at(l, -1, i) = at(l, 0, i); at(l, gy, i) = at(l, gy - 1, i); }
+        else { at(l, -1, i) = -at(l, 0, i); at(l, gy, i) = -at(l, gy - 1, i); }
+      }
+    }
+  }
+  double bilin(int l, int i, int j) {  // fine cell (i, j) of the next finer level from this one, as k_wv_recon's bilin()
+    const int I = i >> 1, J = j >> 1, cx = (i & 1) ? 1 : -1, cy = (j & 1) ? 1 : -1;
+    return (9. * at(l, J, I) + 3. * (at(l, J, I + cx) + at(l, J + cy, I)) + at(l, J + cy, I + cx)) / 16.;
+  }
+};
 // field <- inverse_wavelet(sig_lev * wavelet(field)), all layers (msqg/qg.h:524-539)
 static int wavelet_apply(msom *m, double *f) {
   m->res_ready = -1;
   int r = wavelet_setup(m);
   if (r) return r;
-  const int K = m->wv_nlev, nl = m->nl;
+  const int K = m->wv_kt + 1, nl = m->nl;   // levels on the tile (all of them on a single tile)
+  const bool tiled = m->nranks > 1;
   wv_fill(m, f, m->g);
   for (int k = 1; k < K; k++) {
     launch_wv_restrict(m->st, k == 1 ? f : m->wv_s[k - 1], m->wv_g[k - 1], m->wv_s[k], m->wv_g[k], nl);
     wv_fill(m, m->wv_s[k], m->wv_g[k]);
   }
-  if (K == 1) launch_wv_root(m->st, f, m->wv_sig[0], f, m->g, nl);
-  else launch_wv_root(m->st, m->wv_s[K - 1], m->wv_sig[K - 1], m->wv_r[K - 1], m->wv_g[K - 1], nl);
-  if (K > 1) wv_fill(m, m->wv_r[K - 1], m->wv_g[K - 1]);
+  if (!tiled) {
+    if (K == 1) launch_wv_root(m->st, f, m->wv_sig[0], f, m->g, nl);
+    else launch_wv_root(m->st, m->wv_s[K - 1], m->wv_sig[K - 1], m->wv_r[K - 1], m->wv_g[K - 1], nl);
+    if (K > 1) wv_fill(m, m->wv_r[K - 1], m->wv_g[K - 1]);
+  } else {
+    // levels kt .. depth 0 on the gathered top grid, on the host (a few cells), every rank the same arithmetic as the kernels:
+    // s_k+1 = mean of the 4 children, w = (s - bilinear(s coarse)) sig, r = bilinear(r coarse) + w, root r = s sig
+    if (m->sticky) return m->sticky;
+    const int kt = m->wv_kt, bx = m->nx >> kt, by = m->ny >> kt, nt = m->wv_nlev - kt;
+    const NatGeom &gk = m->wv_g[kt];
+    const double *src = kt == 0 ? f : m->wv_s[kt];
+    std::vector<double> mine((size_t)nl * bx * by), all, top;
+    for (int l = 0; l < nl; l++)
+      HIPCHK(hipMemcpy2DAsync(mine.data() + (size_t)l * bx * by, bx * sizeof(double), src + nat_idx(gk, l, 0, 0), gk.pitch * sizeof(double), bx * sizeof(double), by,
+                              hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    if ((r = wv_gather(m, mine, all))) return r;
+    wv_assemble(m, all, nl, bx, by, top);
+    std::vector<WvTop> S(nt), R(nt);
+    int gx = m->wv_gx, gy = m->wv_gy;
+    S[0].init(gx, gy, nl);
+    for (int l = 0; l < nl; l++) for (int j = 0; j < gy; j++) for (int i = 0; i < gx; i++) S[0].at(l, j, i) = top[((size_t)l * gy + j) * gx + i];
+    S[0].fill(m->bc);
+    for (int q = 1; q < nt; q++) {
+      S[q].init(S[q - 1].gx >> 1, S[q - 1].gy >> 1, nl);
+      for (int l = 0; l < nl; l++) for (int j = 0; j < S[q].gy; j++) for (int i = 0; i < S[q].gx; i++) {
+        double sum = 0.;
+        sum += S[q - 1].at(l, 2 * j, 2 * i); sum += S[q - 1].at(l, 2 * j + 1, 2 * i); sum += S[q - 1].at(l, 2 * j, 2 * i + 1); sum += S[q - 1].at(l, 2 * j + 1, 2 * i + 1);
+        S[q].at(l, j, i) = sum / 4;
+      }
+      S[q].fill(m->bc);
+    }
+    R[nt - 1].init(S[nt - 1].gx, S[nt - 1].gy, nl);
+    for (int l = 0; l < nl; l++) for (int j = 0; j < R[nt - 1].gy; j++) for (int i = 0; i < R[nt - 1].gx; i++)
+      R[nt - 1].at(l, j, i) = S[nt - 1].at(l, j, i) * m->wv_top_sig[nt - 1][(size_t)j * R[nt - 1].gx + i];
+    R[nt - 1].fill(m->bc);
+    for (int q = nt - 2; q >= 0; q--) {
+      R[q].init(S[q].gx, S[q].gy, nl);
+      for (int l = 0; l < nl; l++) for (int j = 0; j < R[q].gy; j++) for (int i = 0; i < R[q].gx; i++) {
+        double d = S[q].at(l, j, i);
+        d -= S[q + 1].bilin(l, i, j);
+        const double w = d * m->wv_top_sig[q][(size_t)j * R[q].gx + i];
+        double rr = R[q + 1].bilin(l, i, j);
+        rr += w;
+        R[q].at(l, j, i) = rr;
+      }
+      R[q].fill(m->bc);
+    }
+    // this tile's block of the filtered level kt, with its ring (neighbour cells or wall ghosts), back to the device
+    double *dst = kt == 0 ? f : m->wv_r[kt];
+    std::vector<double> blk((size_t)nl * (bx + 2) * (by + 2));
+    for (int l = 0; l < nl; l++) for (int j = -1; j <= by; j++) for (int i = -1; i <= bx; i++)
+      blk[((size_t)l * (by + 2) + j + 1) * (bx + 2) + i + 1] = R[0].at(l, m->iy * by + j, m->ix * bx + i);
+    for (int l = 0; l < nl; l++)
+      HIPCHK(hipMemcpy2DAsync(dst + nat_idx(gk, l, -1, -1), gk.pitch * sizeof(double), blk.data() + (size_t)l * (bx + 2) * (by + 2), (bx + 2) * sizeof(double),
+                              (bx + 2) * sizeof(double), by + 2, hipMemcpyHostToDevice, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+  }
   for (int k = K - 2; k >= 0; k--) {
     double *s = k == 0 ? f : m->wv_s[k], *out = k == 0 ? f : m->wv_r[k];
     launch_wv_recon(m->st, s, m->wv_s[k + 1], m->wv_r[k + 1], m->wv_sig[k], out, m->wv_g[k], m->wv_g[k + 1], nl);
     wv_fill(m, out, m->wv_g[k]);
   }
   HIPCHK(hipGetLastError());
-  return MSOM_OK;
+  return m->sticky;
 }
 static int wavelet_filter(msom *m, int qof_field, double dtflt) {
   NEED_CONST(m);
@@ -1896,7 +2044,7 @@ extern "C" int msom_dbg_siglev(msom_t *m, int level, double *out) {
   if (!m || !out) return MSOM_ERR_ARG;
   int r = wavelet_setup(m);
   if (r) return r;
-  if (level < 0 || level >= m->wv_nlev) { msom_set_error("bad level %d", level); return MSOM_ERR_ARG; }
+  if (level < 0 || level >= (int)m->wv_g.size()) { msom_set_error("bad level %d (tiles: only the levels that live on the tile)", level); return MSOM_ERR_ARG; }
   const NatGeom &g = m->wv_g[level];
   HIPCHK(hipMemcpy2DAsync(out, g.nx * sizeof(double), m->wv_sig[level] + nat_idx(g, 0, 0, 0), g.pitch * sizeof(double), g.nx * sizeof(double), g.ny,
                           hipMemcpyDefault, m->st));
@@ -2104,8 +2252,8 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
   // tiled runs (one process / thread per tile): every call below that moves field data is collective; rank 0 alone
   // creates the directory, prints and writes (the reference's pid() == 0 branches, msqg/qg.h:766-780)
   const bool root = m->rank == 0;
-  if (m->nranks > 1 && (p.dtflt > 0 || p.ediag > -1)) {
-    msom_set_error("msom_run: the wavelet filter and the energy budgets need a single-tile grid");
+  if (m->nranks > 1 && p.ediag > -1) {
+    msom_set_error("msom_run: the energy budgets need a single-tile grid");
     return MSOM_ERR_STATE;
   }
   char dpath[600] = "", name[700];

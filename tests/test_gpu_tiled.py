@@ -391,3 +391,49 @@ def test_periodic_tiles_reject_the_large_scale_flow():
     params = orc.double_gyre_params(64, 2, extra="sbc = -1\nupg = [0.1,0.0]\n")
     with pytest.raises(MsomError, match="single tile only"):
         QG(params, tiled=(2, 2, 0, b"MSOMLOCL" + os.urandom(8) + bytes(112)))
+
+
+@pytest.mark.parametrize("px,py,tile,nl,extra", [(2, 2, 32, 3, ""), (2, 1, 32, 2, ""), (2, 4, 16, 2, ""), (2, 2, 32, 2, "sbc = -1\n")])
+@pytest.mark.parametrize("strict", [True, False])
+def test_wavelet_filter_on_tiles(px, py, tile, nl, extra, strict):
+    """msom_wavelet_filter (msqg/qg.h:509-560) on tiles: the pyramid levels that still have a cell of every tile live on
+    the tile (halo exchange with corners per level), the levels above are gathered and transformed by every rank with the
+    same arithmetic; coefficients sig_lev from a non-uniform Rd.  Equal to the single tile bit for bit, and the model keeps
+    stepping on the filtered state."""
+    gnx, gny = tile * px, tile * py
+    levels = int(np.log2(tile))
+    ex = (f"Ny = {gny}\n" if gny != gnx else "") + f"MGLEVELS = {levels}\nafilt = 4\nTOLERANCE = 1e-10\n" + extra
+    params = orc.double_gyre_params(gnx, nl, extra=ex)
+    psi = orc.synthetic_psi(nl, gny, gnx)
+    if extra:
+        x = (np.arange(gnx) + 0.5) / gnx
+        y = (np.arange(gny) + 0.5) / gny
+        psi = np.stack([1e-3 * (1 - 0.2 * l) * np.outer(np.sin(2 * np.pi * y), np.cos(4 * np.pi * x)) for l in range(nl)])
+    Rd = np.ones((1, gny, gnx)); Rd[0, :, gnx // 2:] = 3.0; Rd[0, : gny // 4] = 0.5
+    ty, tx = gny // py, gnx // px
+
+    def pre(g, rank):
+        ix, iy = rank % px, rank // px
+        g.set(F["RD"], Rd[:, iy * ty:(iy + 1) * ty, ix * tx:(ix + 1) * tx])
+        g.set_const()
+
+    def fn(g, rank):
+        g.wavelet_filter(0.5)
+        res = [g.get(F["PSI"]), g.get(F["Q"]), g.get(F["QOF"])]
+        g.step()
+        return res + [g.get(F["Q"])]
+
+    out = run_tiled(params, px, py, psi, nsteps=0, strict=strict, pre=pre, fn=fn)
+    g = QG(params, strict=strict)
+    g.option("quiet", 1)
+    g.set(F["RD"], Rd)
+    g.set(F["PSI"], psi)
+    g.set_const()
+    g.set_tnext(float("inf"))
+    g.wavelet_filter(0.5)
+    ref = [g.get(F["PSI"]), g.get(F["Q"]), g.get(F["QOF"])]
+    g.step()
+    ref.append(g.get(F["Q"]))
+    for k in range(4):
+        got = np.concatenate([np.concatenate([out[iy * px + ix]["extra"][k] for ix in range(px)], axis=2) for iy in range(py)], axis=1)
+        assert np.array_equal(got, ref[k]), k
