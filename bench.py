@@ -231,6 +231,39 @@ class Leg:
         return out, w, plain_bytes, uniform
 
 
+def vertex_sqg_leg(N=2048, nl=3, steps=6):
+    """BASELINE config 5, second half: the vertex-grid model (qg-node) with the surface-QG option and an island mask,
+    (N + 1)^2 x nl vertices, TOLERANCE 1e-5 (qg-node/params.in:22); a short leg, the vertex path is correct-first code"""
+    from msom_amd import NodeQG
+
+    dh, n2 = "[0.1,0.3,0.6]", "[300.,9000.,3000.]"
+    txt = (f"N = {N}\nnl = {nl}\nL0 = 100\nf0 = 46.5\nhEkb = 0.01\ntau0 = 1e-3\nnu = 5.0\nnu4 = 0.0\nbeta = 0.5\nbc_fac = 1.0\n"
+           f"dh = {dh}\nN2 = {n2}\nDT = 5.e-2\ntend = 100.\ndtout = 1\nCFL = 0.2\nTOLERANCE = 1e-5\nsqg = 1\n")
+    g = NodeQG(txt)
+    g.set_option("quiet", 1)
+    x = np.arange(N + 1) / N
+    mk = np.ones((1, N + 1, N + 1))
+    mk[0, N // 4: N // 4 + N // 8, N // 2: N // 2 + N // 8] = 0
+    mk[0, 0, :] = mk[0, -1, :] = mk[0, :, 0] = mk[0, :, -1] = 0
+    psi = np.stack([1e-2 * (1 - 0.2 * l) * sum(np.sin(1.3 * k + 2.1 * m + 0.7 * l) / (k * m) * np.outer(np.sin(m * np.pi * x), np.sin(k * np.pi * x))
+                                              for k in range(1, 4) for m in range(1, 4)) for l in range(nl)]) * mk
+    g.set("MASK", mk)
+    g.set("BS", 0.3 * np.outer(np.sin(np.pi * x), np.sin(2 * np.pi * x))[None] + 0.05)
+    g.set("PSI", psi)
+    g.set_const()
+    for _ in range(3):
+        g.step(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.step(True)
+    el = time.perf_counter() - t0
+    out = {"grid": f"{N + 1}x{N + 1}x{nl} vertices", "value": (N + 1) ** 2 * nl * steps / el, "unit": "vertex-updates/s", "ms_per_step": el / steps * 1e3,
+           "steps": steps, "mg_cycles_per_solve": g.mgstats().i,
+           "variant": "qg-node vertex model, sqg = 1 (surface buoyancy prescribed), island mask, no-slip, 5 sweeps per level and cycle"}
+    g.close()
+    return out
+
+
 def roofline(leg, world):
     ks, w, plain_bytes, uniform = leg.kernels()
     nl = leg.nl
@@ -336,6 +369,7 @@ def main():
                     s["variant"] = "msqg/qg_stochastic.h, device Philox noise (noise_mode 1), tr_stoch 50, amp_stoch 1e-5, sigma = 1"
                 extra[name] = s
                 lg.g.close()
+            extra["C5_vertex_sqg"] = vertex_sqg_leg()
         elif world > 1 and not args.split and not args.tile:
             # BASELINE C4 as written: the configuration's own grid split over the ranks (2 x 4 tiles of 2048 x 1024 at N = 8)
             lg = Leg(cfg["N"] // px, cfg["N"] // py, nl, px, py, rank, dist, cfg["N"], stochastic=cfg["stochastic"], local_rank=local_rank)

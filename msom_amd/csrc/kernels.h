@@ -165,6 +165,12 @@ int launch_n_relax_tile(hipStream_t st, const double *a_in, double *a_out, const
                         int nl, int ns, double D, double iRd2, const LayerCoef &lc);
 void launch_n_residual(hipStream_t st, const double *a, const double *b, const double *mk, const double *S2, double *res, double *maxres,
                        const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc);
+// coarse levels of a vpoisson cycle in one launch (k_n_mg_coarse): lev[0] = finest of the group
+#define NMGC_MAXLEV 8
+#define NMGC_NT 1024
+struct NCoarseLev { double *da, *res; const double *mask, *S2; NatGeom g; double sqD; };
+struct NCoarseArgs { NCoarseLev lev[NMGC_MAXLEV]; int n; double iRd2; LayerCoef lc; };
+void launch_n_mg_coarse(hipStream_t st, const NCoarseArgs &a, int nrelax, int nl);
 void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind);
 void launch_n_prolong(hipStream_t st, const double *c, const NatGeom &cg, double *f, const NatGeom &fg, int nl);
 void launch_n_correct(hipStream_t st, double *a, const double *da, const NatGeom &g, int nl, double bcv);

@@ -327,10 +327,8 @@ __device__ __forceinline__ void n_col_solve(const NRelaxArgs &p, size_t c, const
 #endif
 }
 template <int NL>
-__global__ void __launch_bounds__(BX *BY) k_n_relax(NRelaxArgs p) {
+__device__ __forceinline__ void n_relax_pt(const NRelaxArgs &p, int i, int j) {
   const int n = p.g.nx - 1;
-  const int j = 1 + blockIdx.y * BY + threadIdx.y;
-  const int i = 1 + 2 * (blockIdx.x * BX + threadIdx.x) + ((j + p.color + 1) & 1);  // (i + j) & 1 == color
   if (i >= n || j >= n) return;
   const int pitch = p.g.pitch;
   const size_t ls = p.g.ls, c = nat_idx(p.g, 0, j, i);
@@ -344,6 +342,12 @@ __global__ void __launch_bounds__(BX *BY) k_n_relax(NRelaxArgs p) {
   n_col_solve<NL>(p, c, ew, ns, x);
 #pragma unroll
   for (int l = 0; l < NL; l++) p.a[c + l * ls] = x[l];
+}
+template <int NL>
+__global__ void __launch_bounds__(BX *BY) k_n_relax(NRelaxArgs p) {
+  const int j = 1 + blockIdx.y * BY + threadIdx.y;
+  const int i = 1 + 2 * (blockIdx.x * BX + threadIdx.x) + ((j + p.color + 1) & 1);  // (i + j) & 1 == color
+  n_relax_pt<NL>(p, i, j);
 }
 // NS full red-black sweeps in ONE pass over HBM, out of place (a_in -> a_out; neighbouring workgroups read each
 // other's tiles): a 64 x TH tile of the correction with a 2 NS halo goes to LDS, half-sweep h updates the
@@ -488,8 +492,7 @@ void launch_n_residual(hipStream_t st, const double *a, const double *b, const d
   hipLaunchKernelGGL(k_n_residual, grid_capped(g.nx, g.ny), block2d(), 0, st, p);
 }
 // restriction_coarsen_vert (residual), restriction_coarsen_vert2 (mask), restriction_vert (injection), my_vertex.h:49-75
-__global__ void k_n_restrict(const double *__restrict__ f, NatGeom fg, double *c, NatGeom cg, int nl, int kind) {
-  VTX(cg, I, J);
+__device__ __forceinline__ void n_restrict_pt(const double *__restrict__ f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind, int I, int J) {
   for (int l = 0; l < nl; l++) {
     const size_t k = nat_idx(fg, l, 2 * J, 2 * I);
     const int p = fg.pitch;
@@ -501,12 +504,15 @@ __global__ void k_n_restrict(const double *__restrict__ f, NatGeom fg, double *c
     c[nat_idx(cg, l, J, I)] = v;
   }
 }
+__global__ void k_n_restrict(const double *__restrict__ f, NatGeom fg, double *c, NatGeom cg, int nl, int kind) {
+  VTX(cg, I, J);
+  n_restrict_pt(f, fg, c, cg, nl, kind, I, J);
+}
 void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind) {
   hipLaunchKernelGGL(k_n_restrict, grid2d(cg.nx, cg.ny), block2d(), 0, st, f, fg, c, cg, nl, kind);
 }
 // refine_vert my_vertex.h:82-105 followed by boundary_level(da) = 0 on the boundary vertices; one thread per FINE vertex
-__global__ void k_n_prolong(const double *__restrict__ c, NatGeom cg, double *f, NatGeom fg, int nl) {
-  VTX(fg, i, j);
+__device__ __forceinline__ void n_prolong_pt(const double *__restrict__ c, const NatGeom &cg, double *f, const NatGeom &fg, int nl, int i, int j) {
   const int n = fg.nx - 1, I = i >> 1, J = j >> 1;
   const bool bnd = i == 0 || j == 0 || i == n || j == n;
   for (int l = 0; l < nl; l++) {
@@ -518,6 +524,71 @@ __global__ void k_n_prolong(const double *__restrict__ c, NatGeom cg, double *f,
     else if (!(i & 1)) v = (c[k] + c[k + cg.pitch]) / 2.;
     else v = (c[k] + c[k + 1] + c[k + cg.pitch] + c[k + 1 + cg.pitch]) / 4.;
     f[nat_idx(fg, l, j, i)] = v;
+  }
+}
+__global__ void k_n_prolong(const double *__restrict__ c, NatGeom cg, double *f, NatGeom fg, int nl) {
+  VTX(fg, i, j);
+  n_prolong_pt(c, cg, f, fg, nl, i, j);
+}
+
+// ---- the coarse levels of one vpoisson cycle in ONE launch (one workgroup, __syncthreads() where the separate launches had
+// kernel boundaries; the per-vertex device functions are the ones of the stand-alone kernels => identical arithmetic):
+// restriction of the residual from lev[0] down (boundary vertices 0), zero first guess on the coarsest level, nrelax
+// red-black sweeps per level, prolongation to the next finer level -- up to and including the sweeps of lev[0].
+// At 2049^2 x 3 the levels <= 33^2 vertices are 6 of 11 and ~80 of the ~140 launches of a cycle, each ~5 us long.
+template <int NL>
+__global__ void __launch_bounds__(NMGC_NT) k_n_mg_coarse(NCoarseArgs a, int nrelax) {
+  const int tid = threadIdx.x;
+  for (int k = 1; k < a.n; k++) {
+    const NCoarseLev &F = a.lev[k - 1], &C = a.lev[k];
+    const int n1 = C.g.nx;
+    for (int t = tid; t < n1 * n1; t += NMGC_NT) n_restrict_pt(F.res, F.g, C.res, C.g, NL, 0, t % n1, t / n1);
+    __syncthreads();
+    for (int t = tid; t < n1 * n1; t += NMGC_NT) {   // boundary_level(res) = 0 on the boundary vertices
+      const int i = t % n1, j = t / n1;
+      if (i == 0 || j == 0 || i == n1 - 1 || j == n1 - 1)
+        for (int l = 0; l < NL; l++) C.res[nat_idx(C.g, l, j, i)] = 0.;
+    }
+    __syncthreads();
+  }
+  {
+    const NCoarseLev &L = a.lev[a.n - 1];
+    for (size_t t = tid; t < L.g.ls * NL; t += NMGC_NT) L.da[t] = 0.;
+    __syncthreads();
+  }
+  for (int k = a.n - 1; k >= 0; k--) {
+    const NCoarseLev &L = a.lev[k];
+    NRelaxArgs p;
+    p.a = L.da; p.b = L.res; p.mk = L.mask; p.S2 = L.S2; p.g = L.g; p.sqD = L.sqD; p.iRd2 = a.iRd2; p.lc = a.lc;
+    const int n = L.g.nx - 1, half = (n + 1) / 2;
+    for (int s = 0; s < nrelax; s++)
+      for (int c = 0; c < 2; c++) {
+        p.color = c;
+        for (int t = tid; t < half * (n - 1); t += NMGC_NT) {
+          const int j = 1 + t / half;
+          n_relax_pt<NL>(p, 1 + 2 * (t % half) + ((j + c + 1) & 1), j);
+        }
+        __syncthreads();
+      }
+    if (k > 0) {
+      const NCoarseLev &Fn = a.lev[k - 1];
+      const int n1 = Fn.g.nx;
+      for (int t = tid; t < n1 * n1; t += NMGC_NT) n_prolong_pt(L.da, L.g, Fn.da, Fn.g, NL, t % n1, t / n1);
+      __syncthreads();
+    }
+  }
+}
+void launch_n_mg_coarse(hipStream_t st, const NCoarseArgs &a, int nrelax, int nl) {
+  switch (nl) {
+    case 1: hipLaunchKernelGGL(k_n_mg_coarse<1>, dim3(1), dim3(NMGC_NT), 0, st, a, nrelax); break;
+    case 2: hipLaunchKernelGGL(k_n_mg_coarse<2>, dim3(1), dim3(NMGC_NT), 0, st, a, nrelax); break;
+    case 3: hipLaunchKernelGGL(k_n_mg_coarse<3>, dim3(1), dim3(NMGC_NT), 0, st, a, nrelax); break;
+    case 4: hipLaunchKernelGGL(k_n_mg_coarse<4>, dim3(1), dim3(NMGC_NT), 0, st, a, nrelax); break;
+    case 5: hipLaunchKernelGGL(k_n_mg_coarse<5>, dim3(1), dim3(NMGC_NT), 0, st, a, nrelax); break;
+    case 6: hipLaunchKernelGGL(k_n_mg_coarse<6>, dim3(1), dim3(NMGC_NT), 0, st, a, nrelax); break;
+    case 7: hipLaunchKernelGGL(k_n_mg_coarse<7>, dim3(1), dim3(NMGC_NT), 0, st, a, nrelax); break;
+    case 8: hipLaunchKernelGGL(k_n_mg_coarse<8>, dim3(1), dim3(NMGC_NT), 0, st, a, nrelax); break;
+    default: break;
   }
 }
 void launch_n_prolong(hipStream_t st, const double *c, const NatGeom &cg, double *f, const NatGeom &fg, int nl) {
