@@ -99,7 +99,8 @@ int msom_destroy(msom_t *m);
  * wide enough), "march_k" [4] half-sweeps per pass, "march_rows" [0 = auto] chunk height, "march_min" [23] log2 of the cell-layers a level needs, "march_prolong" [1] prolongation folded
  * into the first pass, "march_dma" [2] memory side of the pass (0: register-window loads, 1: LDS-DMA prefetch with one strip per
  * workgroup, 2: four strips per workgroup marching in step; PROCESS-WIDE tuning knob like march_rows / march_xcd / march_flip /
- * march_dbg / rhs_dbg / block_variant, which are globals of the library rather than fields of the handle), "march_correct" [1] correction folded into the last pass, "march_xcd" [1] XCD-contiguous block numbering, "march_flip" [1] odd chunks march downwards, "block_sweeps" [0] LDS-tiled blocked smoother, "agglomerate" [1] / "agg_size" [256]
+ * march_dbg / rhs_dbg / block_variant, which are globals of the library rather than fields of the handle), "graph" [0] replay the launches of a multigrid cycle from a captured hipGraph on the launch-bound grids
+ * (measured neutral), "march_partial" [1], "march_correct" [1] correction folded into the last pass, "march_xcd" [1] XCD-contiguous block numbering, "march_flip" [1] odd chunks march downwards, "block_sweeps" [0] LDS-tiled blocked smoother, "agglomerate" [1] / "agg_size" [256]
  * gathered coarse levels of tiled runs, "mg_global_sum" [0]; "rhs_dbg", "block_variant": timing
  * experiments of tools/. */
 int msom_set_option(msom_t *m, const char *key, double value);

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <string>
 #include <utility>
+#include <map>
 #include <vector>
 
 #include "comm.h"
@@ -104,6 +105,11 @@ struct msom {
   int block_small = 0;   // the same kernel on the launch-bound levels only (not marched, <= block_small cells wide): 2 launches per level visit instead of 8
   int march = 1;         // chained half-sweeps in register windows (kernels_march.hip) on wide single-GPU levels
   int march_k = 4;       // at most this many half-sweeps per pass (2..4)
+  // launch-bound grids (no level takes the marching or the blocked smoother, single tile): the launches of one multigrid cycle
+  // are captured once per (nrelax, first_restrict) into a hipGraph and replayed -- the host then issues 1 launch instead of ~45
+  int use_graph = 0;   // measured: 512^2 x 3 0.645 vs 0.647 ms per step, 1024^2 x 3 0.860 vs 0.879, 128^2 x 1 0.316 vs 0.305 -- these grids are
+                       // bound by the duration of their ~5-us kernels on the GPU, not by the host's launch rate: option "graph", off
+  std::map<long, hipGraphExec_t> cyc_graph;
   int march_partial = 1; // a pass that is followed by more half-sweeps stores only the colour of its last half-sweep
   int march_min = 23;    // log2 of the cell-layers a level needs for the chained pass (2^23: 2048^2 x 3 1.83 -> 1.78 ms/step, and the 2048 x 1024 x 6 tiles of BASELINE's 2 x 4 layout qualify; 2^22 loses: 1024^2 x 6 2.76 -> 2.87)
   int march_correct = 1; // the last pass of the finest level writes psi + da instead of da (psi rows by LDS-DMA, deferred write): 7.02 -> 6.86 ms per step at 4096^2 x 6
@@ -584,9 +590,11 @@ extern "C" msom_t *msom_create(const char *path) {
   return msom_create_str(text.c_str());
 }
 
+static void clear_graphs(msom *m);
 extern "C" int msom_destroy(msom_t *m) {
   if (!m) return MSOM_ERR_ARG;
   if (m->st) hipStreamSynchronize(m->st);
+  clear_graphs(m);
   for (int k = 0; k < MSOM_NFIELDS; k++)
     if (m->f[k]) hipFree(m->f[k]);
   for (int k = 0; k < m->nlev; k++) {
@@ -627,8 +635,11 @@ extern "C" int msom_destroy(msom_t *m) {
 static int build_coefs(msom *m);
 static void free_agglomeration(msom *m);
 
+static void clear_graphs(msom *m);
 extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   if (!m || !key) return MSOM_ERR_ARG;
+  clear_graphs(m);   // captured cycles hold kernel arguments by value: any option may change them
+  if (!strcmp(key, "graph")) { m->use_graph = (int)v; return MSOM_OK; }
   if (!strcmp(key, "TOLERANCE")) m->p.tolerance = v;
   else if (!strcmp(key, "NITERMAX")) m->p.nitermax = (int)v;
   else if (!strcmp(key, "NITERMIN")) m->p.nitermin = (int)v;
@@ -902,6 +913,7 @@ static int setup_mg_coarse(msom *m) {
 
 // layer metrics, Ro, S on all levels, column-solver constants, forcing profile
 static int build_coefs(msom *m) {
+  clear_graphs(m);
   const Params &p = m->p;
   const int nl = m->nl;
   // sanity checks :990-1012 (reference: exit(0))
@@ -1212,6 +1224,38 @@ static void mg_cycle_levels(msom *m, int nrelax, int first_restrict) {
   }
 }
 
+static void clear_graphs(msom *m) {
+  for (auto &kv : m->cyc_graph) (void)hipGraphExecDestroy(kv.second);
+  m->cyc_graph.clear();
+}
+// the cycle through a captured graph where that is possible (see use_graph); same launches, same order, same arguments
+static void mg_cycle(msom *m, int nrelax, int first_restrict) {
+  bool ok = m->use_graph && m->nranks == 1 && !m->profile;   // (corr_req only acts inside a marching pass, excluded below)
+  for (int k = 0; ok && k < m->nlev; k++) {
+    Lev L = tile_lev(m, k);
+    if (march_ok(m, L) || block_ok(m, L)) ok = false;   // those passes ping-pong between two buffers: pointers differ from cycle to cycle
+  }
+  if (!ok) { mg_cycle_levels(m, nrelax, first_restrict); return; }
+  const long key = (long)nrelax * 8 + first_restrict;
+  auto it = m->cyc_graph.find(key);
+  if (it == m->cyc_graph.end()) {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ex = nullptr;
+    if (hipStreamBeginCapture(m->st, hipStreamCaptureModeThreadLocal) != hipSuccess) { m->use_graph = 0; mg_cycle_levels(m, nrelax, first_restrict); return; }
+    mg_cycle_levels(m, nrelax, first_restrict);
+    if (hipStreamEndCapture(m->st, &g) != hipSuccess || !g || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+      if (g) (void)hipGraphDestroy(g);
+      (void)hipGetLastError();
+      m->use_graph = 0;                 // nothing was executed during the capture: run the cycle eagerly now
+      mg_cycle_levels(m, nrelax, first_restrict);
+      return;
+    }
+    (void)hipGraphDestroy(g);
+    it = m->cyc_graph.emplace(key, ex).first;
+  }
+  if (hipGraphLaunch(it->second, m->st) != hipSuccess && !m->sticky) m->sticky = MSOM_ERR_HIP;
+}
+
 static void residual(msom *m, const double *a, const double *b, int slot, int want_sum) {
   if (m->profile) prof_begin(m, m->prof_resid);
   launch_residual(m->st, a, b, m->f[MSOM_S], m->g, m->res[0], m->sg[0], m->nl, m->rc[0], m->uniformS, m->d_scal + slot, m->partial, want_sum);
@@ -1278,7 +1322,7 @@ static int mg_solve(msom *m, const double *b, msom_mgstats *s) {
   for (s->i = 0; s->i < p.nitermax && (s->i < p.nitermin || s->resa > p.tolerance); s->i++) {
     m->corr_req = fused && m->march_correct;
     m->corr_done = 0;
-    mg_cycle_levels(m, s->nrelax, fused ? 2 : 1);
+    mg_cycle(m, s->nrelax, fused ? 2 : 1);
     m->corr_req = 0;
     HIPCHK(hipMemsetAsync(m->d_scal + SC_RES1, 0, sizeof(double), m->st));
     if (m->corr_done) {  // a_new = a + da already sits in psi_alt (last smoother pass): boundary(a), then max |res|, max |u|
