@@ -370,10 +370,13 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
   };
   // CORR: with the rows of step t comes psi of the row half-sweep K finished in step t - 1 (the lane's cell pair, natural layout)
   auto request_psi = [&](int t) {
-    const int rk = min(max(ph(t - K), 0), ny - 1);
-    const double *ps = p.psi + nat_idx(p.ng, 0, rk, 2 * min(max(kx, 0), hk - 1));
+    const int rk = ph(t - K);
+    if (rk < y0 || rk >= y1) return;   // wave-uniform: rows of the chunk's halo are never corrected
+    if (own_lane) {                    // nor are the halo lanes (inactive lanes fetch nothing)
+      const double *ps = p.psi + nat_idx(p.ng, 0, rk, 2 * kx);
 #pragma unroll
-    for (int l = 0; l < NL; l++) dma16(ps + l * p.ng.ls, PB + 2 * l);
+      for (int l = 0; l < NL; l++) dma16(ps + l * p.ng.ls, PB + 2 * l);
+    }
   };
   // requests the rows of marching step t
   auto request = [&](int t) {
