@@ -12,6 +12,7 @@
 // vertices with a Thomas solve per column (qg_baroclinic_ms.h:228-291); here the same column
 // solve in red-black order ((i + j) even first), as for the cell-centred model.
 #include "kernels.h"
+#include "rhs_inl.h"
 
 #ifdef MSOM_STRICT
 #define DIVC(x, c, rc) ((x) / (c))
@@ -349,6 +350,120 @@ __global__ void __launch_bounds__(BX *BY) k_n_relax(NRelaxArgs p) {
   const int i = 1 + 2 * (blockIdx.x * BX + threadIdx.x) + ((j + p.color + 1) & 1);  // (i + j) & 1 == color
   n_relax_pt<NL>(p, i, j);
 }
+// ---- K consecutive colour half-sweeps of the vertex smoother in ONE pass (round 2), the marching scheme of kernels_march.hip in
+// the natural layout.  A colour pass of k_n_relax touches every cache line of `a` twice (it reads the other colour and writes
+// its own: half of each line both ways) and half of every line of b / mask / S2: ~1.9 w of line traffic per pass, 10 passes per
+// level visit (5 sweeps).  Here a wavefront (= a workgroup) marches up a strip of 64 columns, lane = column, both colours of
+// a row in the same registers: half-sweep s runs one row behind half-sweep s - 1 and reads its 3-row window of the values
+// after half-sweep s - 1 (N / S: own lane, E / W: whole-wave DPP shifts); lanes of the other colour carry their value
+// through.  Only `a` lives in windows (K x 3 x NL doubles); b, mask and S2 are read by the column solve where it needs them
+// (second and later uses of a row hit L2).  Out of place (a_in -> a_out), K halo lanes per side and K halo rows per chunk
+// re-compute the cone of dependence.  Boundary vertices (and everything outside) are never relaxed and carry their value.
+// Same column solve (n_col_solve) on the same inputs => bit-identical to the pass-per-colour path.
+template <int NL, int K>
+__global__ void __launch_bounds__(64) k_n_relax_march(NRelaxArgs p, const double *__restrict__ a_in, int H) {
+  constexpr int OW = 64 - 2 * K;
+  const int lane = threadIdx.x;
+  const int n = p.g.nx - 1;                      // vertices 0 .. n
+  const int gi = (int)blockIdx.x * OW - K + lane;
+  const int y0 = blockIdx.y * H, y1 = min(n + 1, y0 + H);
+  const int pitch = p.g.pitch;
+  const size_t ls = p.g.ls;
+  const bool col_ok = gi >= 0 && gi <= n;        // a column of the grid (pads beyond: read as they are, never used by valid cells)
+  const int gic = min(max(gi, -1), n + 1);
+  const bool own = lane >= K && lane < 64 - K && gi <= n;
+  auto load_row = [&](int r, double (&dst)[NL]) {
+    const int rc = min(max(r, -1), n + 1);
+    const double *src = a_in + nat_idx(p.g, 0, rc, gic);
+#pragma unroll
+    for (int l = 0; l < NL; l++) dst[l] = src[l * ls];
+  };
+  double W[K][3][NL];
+#pragma unroll
+  for (int s = 0; s < K; s++)
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int l = 0; l < NL; l++) W[s][q][l] = 0.;
+  load_row(y0 - K, W[0][1]);
+  load_row(y0 - K + 1, W[0][2]);
+  for (int t = y0 - K + 1; t <= y1 + K - 2; t++) {
+#pragma unroll
+    for (int s = 0; s < K; s++)
+#pragma unroll
+      for (int l = 0; l < NL; l++) { W[s][0][l] = W[s][1][l]; W[s][1][l] = W[s][2][l]; }
+    load_row(t + 1, W[0][2]);
+#pragma unroll
+    for (int s = 1; s <= K; s++) {
+      const int r = t - (s - 1);                 // row of half-sweep s
+      const int col = (p.color + s - 1) & 1;     // its colour
+      double x[NL];
+#pragma unroll
+      for (int l = 0; l < NL; l++) x[l] = W[s - 1][1][l];   // carried unless this vertex is relaxed now
+      double ew[NL], ns[NL];
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        const double a = W[s - 1][1][l];
+        ew[l] = lane_above(a) + lane_below(a);   // a_E + a_W (k_n_relax: p.a[k + 1] + p.a[k - 1])
+        ns[l] = W[s - 1][2][l] + W[s - 1][0][l]; // a_N + a_S
+      }
+      if (r >= 1 && r <= n - 1 && col_ok && gi >= 1 && gi <= n - 1 && ((gi + r) & 1) == col) {
+        double xn[NL];
+        n_col_solve<NL>(p, nat_idx(p.g, 0, r, gi), ew, ns, xn);
+#pragma unroll
+        for (int l = 0; l < NL; l++) x[l] = xn[l];
+      }
+      if (s < K) {
+#pragma unroll
+        for (int l = 0; l < NL; l++) W[s][2][l] = x[l];
+      } else if (r >= y0 && r < y1 && own) {
+        double *dst = p.a + nat_idx(p.g, 0, r, gi);
+#pragma unroll
+        for (int l = 0; l < NL; l++) dst[l * ls] = x[l];
+      }
+    }
+  }
+}
+int g_node_march_rows = 0;  // tuning knob (option node_march_rows)
+template <int NL>
+static int n_relax_march_dispatch(hipStream_t st, const NRelaxArgs &p, const double *a_in, int K) {
+  const int n1 = p.g.nx;
+  // chunk height: about 2 rounds of the resident wavefronts, never below 16 rows (2 K of them are re-computed)
+  auto launch = [&](auto kern, int ow) {
+    const int strips = (n1 + ow - 1) / ow;
+    extern int g_node_march_rows;
+    int chunks = 2 * 256 * 8 / strips;
+    if (chunks < 1) chunks = 1;
+    int H = (n1 + chunks - 1) / chunks;
+    if (H < 16) H = 16;
+    if (g_node_march_rows > 0) H = g_node_march_rows;
+    hipLaunchKernelGGL(kern, dim3(strips, (n1 + H - 1) / H), dim3(64), 0, st, p, a_in, H);
+  };
+  switch (K) {
+    case 2: launch(k_n_relax_march<NL, 2>, 60); return 0;
+    case 3: launch(k_n_relax_march<NL, 3>, 58); return 0;
+    case 4: launch(k_n_relax_march<NL, 4>, 56); return 0;
+  }
+  return -1;
+}
+// K (2..4) half-sweeps starting with colour `color`, a_in -> a_out; returns -1 if K is not supported
+int launch_n_relax_march(hipStream_t st, const double *a_in, double *a_out, const double *b, const double *mk, const double *S2, const NatGeom &g, int nl,
+                         int color, int K, double D, double iRd2, const LayerCoef &lc) {
+  NRelaxArgs p;
+  p.a = a_out; p.b = b; p.mk = mk; p.S2 = S2; p.g = g; p.color = color; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc;
+  switch (nl) {
+    case 1: return n_relax_march_dispatch<1>(st, p, a_in, K);
+    case 2: return n_relax_march_dispatch<2>(st, p, a_in, K);
+    case 3: return n_relax_march_dispatch<3>(st, p, a_in, K);
+    case 4: return n_relax_march_dispatch<4>(st, p, a_in, K);
+    case 5: return n_relax_march_dispatch<5>(st, p, a_in, K);
+    case 6: return n_relax_march_dispatch<6>(st, p, a_in, K);
+    case 7: return n_relax_march_dispatch<7>(st, p, a_in, K);
+    case 8: return n_relax_march_dispatch<8>(st, p, a_in, K);
+  }
+  return -1;
+}
+
 // NS full red-black sweeps in ONE pass over HBM, out of place (a_in -> a_out; neighbouring workgroups read each
 // other's tiles): a 64 x TH tile of the correction with a 2 NS halo goes to LDS, half-sweep h updates the
 // cells of colour h & 1 inside the region tile +- (2 NS - 1 - h) -- a cell is updated only when its four

@@ -54,6 +54,10 @@ struct msomn {
   std::vector<NatGeom> cg;
   std::vector<double *> cs, cr, csig;  // cs[0] = n_stoch
   int mg_coarse = 32;   // the levels of <= (mg_coarse + 1)^2 vertices of a cycle in one launch (k_n_mg_coarse); 0: off
+  int node_march = 0;   // levels of >= node_march vertices per side: K = 4 chained colour half-sweeps per pass (k_n_relax_march).  Measured at
+                        // 2049^2 x 3: a K = 4 pass (2 sweeps) ~320 us on the finest level against 4 x 70 us of colour passes -- half the
+                        // bytes, but plain loads consumed in the step that issues them and the b / mask / S2 loads inside the column
+                        // solve leave the wavefront latency-bound (the cell-centred pass needed LDS-DMA prefetch for the same reason): off
   int tiled_relax = 0;  // option: LDS-tiled smoother passes (1-2 sweeps per pass) on the wide levels; measured 3 % faster at 4097^2 x 3, 7 % slower at 2049^2 x 3
   NatGeom g;
   double *f[MSOMN_NFIELDS] = {nullptr};
@@ -232,6 +236,8 @@ extern "C" int msomn_set_option(msomn_t *m, const char *key, double v) {
   else if (!strcmp(key, "DT")) m->p.DT = v;
   else if (!strcmp(key, "quiet")) m->quiet = (int)v;
   else if (!strcmp(key, "tiled_relax")) m->tiled_relax = (int)v;
+  else if (!strcmp(key, "node_march")) m->node_march = (int)v;
+  else if (!strcmp(key, "node_march_rows")) { extern int g_node_march_rows; g_node_march_rows = (int)v; }
   else if (!strcmp(key, "mg_coarse")) m->mg_coarse = (int)v;
   else if (!strcmp(key, "stochastic")) m->stochastic = (int)v;
   else if (!strcmp(key, "seed")) srand((unsigned)v);
@@ -340,6 +346,19 @@ static void relax_level(msomn *m, int k, double *da, const double *res) {
 // (L.da <-> L.da2 swap, L.da always the current one); narrow levels: one launch per colour.
 static void relax_sweeps(msomn *m, int k, int nsweeps) {
   NLevel &L = m->lev[k];
+  if (m->node_march && L.n + 1 >= m->node_march && L.n + 1 >= 64) {
+    // 2 nsweeps colour half-sweeps (red, black, red, ...) in passes of up to 4, ping-ponging between the two correction buffers
+    int nh = 2 * nsweeps, c = 0;
+    while (nh >= 2) {
+      int K = nh < 4 ? nh : 4;
+      if (nh - K == 1) K--;            // never leave a single half-sweep behind
+      launch_n_relax_march(m->st, L.da, L.da2, L.res, L.mask, L.S2, L.g, m->nl, c, K, L.D, m->iRd2_low, m->lc);
+      std::swap(L.da, L.da2);
+      nh -= K; c = (c + K) & 1;
+    }
+    if (nh == 1) launch_n_relax(m->st, L.da, L.res, L.mask, L.S2, L.g, m->nl, c, L.D, m->iRd2_low, m->lc);
+    return;
+  }
   if (!m->tiled_relax || L.n + 1 < 64) {
     for (int s = 0; s < nsweeps; s++) relax_level(m, k, L.da, L.res);
     return;

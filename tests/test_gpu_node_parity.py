@@ -297,3 +297,26 @@ def test_randomised_configurations_strict_vs_oracle(seed):
     desc = f"nl={nl} N={N} {par[-120:]!r}"
     assert (g.t, g.dt) == (o.t, o.dt), desc
     assert np.array_equal(g.get("PSI"), o.get(orn.PSI)) and np.array_equal(g.get("Q"), o.get(orn.Q)), desc
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nl,N", [(1, 128), (3, 256), (6, 128), (8, 64), (2, 512)])
+def test_chained_half_sweep_smoother(nl, N, strict):
+    """k_n_relax_march (K = 2..4 colour half-sweeps per pass, register windows, out of place) on the wide levels: 1, 2, 3 and
+    5 sweeps (2, 4, 4 + 2, 4 + 4 + 2 half-sweeps) against the oracle's colour-by-colour sweeps and against the per-colour kernels"""
+    if nl not in orn.NODE_LAYERS:
+        orn.NODE_LAYERS[nl] = ("[" + ",".join(["%.3f" % (1.0 / nl)] * nl) + "]", "[" + ",".join(["%d." % (9000 - 900 * l) for l in range(nl - 1)]) + "]")
+    o, g = make_pair(N, nl, strict, mask=True, extra="gp_low = 0.02\n")
+    rng = np.random.default_rng(12)
+    for k in (0, 1):
+        n1 = (N >> k) + 1
+        if n1 < 64:
+            continue
+        da, res = rng.standard_normal((nl, n1, n1)), rng.standard_normal((nl, n1, n1))
+        for ns in (1, 2, 3, 5):
+            g.set_option("node_march", 64)
+            got, ref = g.dbg_relax(k, da, res, ns), o.relax(k, da, res, ns)
+            same(got, ref, strict, 1e-10)
+            g.set_option("node_march", 0)
+            plain = g.dbg_relax(k, da, res, ns)
+            assert np.array_equal(got, plain) or not strict
