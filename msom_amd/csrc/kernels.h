@@ -125,7 +125,7 @@ struct MarchCorrect { const double *psi; double *psi_out; NatGeom g; };
 struct MarchHalo { const double *in_s, *in_n, *res_s, *res_n; size_t ls; int rows; };
 int launch_relax_march(hipStream_t st, const double *in, double *out, const double *res, const SplitGeom &sg, int nl, const RelaxCoef &rc, int c1,
                        int K, int walls, int chunk_rows = 0, const MarchHalo *h = nullptr, const double *coarse = nullptr, const SplitGeom *cg = nullptr,
-                       const MarchCorrect *mc = nullptr, int more_follow = 0);
+                       const MarchCorrect *mc = nullptr, int more_follow = 0, const MarchHalo *coarse_halo = nullptr);
 
 // ---- kernels_wavelet.hip
 void launch_wv_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl);

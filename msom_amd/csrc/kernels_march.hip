@@ -36,6 +36,11 @@ struct MarchArgs {
   // (mspg/elliptic.h:74-86), interpolated on the fly and never stored; `in` is not read
   const double *coarse;
   SplitGeom cg;
+  // tiles: the cKR nearest rows of the coarse correction beyond a tile edge that is not a wall (same layout, chls doubles per
+  // layer); the columns beyond W / E edges sit in the row pads of `coarse` (deep halo exchange of the coarse level)
+  const double *coarse_s, *coarse_n;
+  size_t chls;
+  int cKR;
   // CORR variant (last pass of the finest level): the correction a += da (mspg/elliptic.h:92-98) rides in the pass:
   // psi_out = psi + (value after the last update of each colour), natural layout, wall ghosts included; da is not stored
   const double *psi;
@@ -363,10 +368,19 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
   auto coarse_rows = [&](int r, bool &neg, int &J, int &cy) {
     neg = false;
     int rr = r;
-    if (r < 0) { rr = 0; neg = wallS; }
-    if (r >= ny) { rr = ny - 1; neg = wallN; }
-    J = rr >> 1;
+    // beyond a wall: the ghost row mirrors the wall row; beyond a tile edge the rows are the neighbour's (coarse halo arrays)
+    if (r < 0 && !p.coarse_s) { rr = 0; neg = wallS; }
+    if (r >= ny && !p.coarse_n) { rr = ny - 1; neg = wallN; }
+    J = rr >> 1;                      // arithmetic shift: rows -1, -2 -> coarse row -1
     cy = (rr & 1) ? 1 : -1;
+  };
+  // wave-uniform base of coarse row J (without the column offset); lstride = doubles per layer
+  const int cny = p.cg.ny;
+  auto crow = [&](int J, size_t &lstride) -> const double * {
+    if (J < 0 && p.coarse_s) { lstride = p.chls; return p.coarse_s + (ptrdiff_t)(max(J, -p.cKR) + p.cKR + 1) * crp; }
+    if (J >= cny && p.coarse_n) { lstride = p.chls; return p.coarse_n + (ptrdiff_t)(min(J - cny, p.cKR - 1) + 1) * crp; }
+    lstride = cls;
+    return p.coarse + (ptrdiff_t)(min(max(J, -1), cny) + 1) * crp;
   };
   // CORR: with the rows of step t comes psi of the row half-sweep K finished in step t - 1 (the lane's cell pair, natural layout)
   auto request_psi = [&](int t) {
@@ -410,12 +424,13 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
         const int Jn = q ? second : first;
         if (Jn == cjA || Jn == cjB) continue;
         cjB = cjA; cjA = Jn;
-        const double *cb = p.coarse + (ptrdiff_t)(Jn + 1) * crp + cpc;
-        const int slot = (Jn + 4) & 3;
+        size_t cst;
+        const double *cb = crow(Jn, cst) + cpc;
+        const int slot = (Jn + 8) & 3;
 #pragma unroll
         for (int d = 0; d < NLE / 2; d++) {
           const int la = min(2 * d + sub, NL - 1);
-          dma16(cb + (size_t)la * cls, CB + slot * NLE + 2 * d);
+          dma16(cb + (size_t)la * cst, CB + slot * NLE + 2 * d);
         }
       }
     }
@@ -484,12 +499,13 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
       bool neg;
       int J, cy;
       coarse_rows(r, neg, J, cy);
-      const int Ic = min(max(kx, -1), p.cg.nx);
+      const int Ic = min(max(kx, -8), p.cg.nx + 7);   // ghosts / halo columns included (row pads)
       const ptrdiff_t coff = (Ic & 1) * chp + MSOM_SP + (Ic >> 1);
-      const double *c0p = p.coarse + (ptrdiff_t)(J + 1) * crp + coff, *c1p = p.coarse + (ptrdiff_t)(J + cy + 1) * crp + coff;
+      size_t s0, s1;
+      const double *c0p = crow(J, s0) + coff, *c1p = crow(J + cy, s1) + coff;
       double A0[NL], A1[NL];
 #pragma unroll
-      for (int l = 0; l < NL; l++) { A0[l] = c0p[l * cls]; A1[l] = c1p[l * cls]; }
+      for (int l = 0; l < NL; l++) { A0[l] = c0p[l * s0]; A1[l] = c1p[l * s1]; }
       prolong_vals(r, (r + c0) & 1, A0, A1, W[0][q + 1]);
     } else {
       size_t st;
@@ -519,7 +535,7 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
       bool neg;
       int J, cy;
       coarse_rows(ph(t + 1), neg, J, cy);
-      sJ0 = (J + 4) & 3; sJ1 = (J + cy + 4) & 3;
+      sJ0 = (J + 8) & 3; sJ1 = (J + cy + 8) & 3;
     }
 #pragma unroll
     for (int l = 0; l < NL; l++) {
@@ -731,14 +747,15 @@ static int march_dispatch(hipStream_t st, const MarchArgs &a, int K, int rows) {
 
 // K (2..4) half-sweeps starting with colour c1, in -> out; returns -1 if (nl, K) has no instantiation
 int launch_relax_march(hipStream_t st, const double *in, double *out, const double *res, const SplitGeom &sg, int nl, const RelaxCoef &rc, int c1,
-                       int K, int walls, int chunk_rows, const MarchHalo *h, const double *coarse, const SplitGeom *cg, const MarchCorrect *mc, int more_follow) {
+                       int K, int walls, int chunk_rows, const MarchHalo *h, const double *coarse, const SplitGeom *cg, const MarchCorrect *mc, int more_follow, const MarchHalo *ch) {
   MarchArgs a;
+  a.coarse_s = ch ? ch->in_s : nullptr; a.coarse_n = ch ? ch->in_n : nullptr; a.chls = ch ? ch->ls : 0; a.cKR = ch ? ch->rows : 0;
   a.partial = more_follow != 0;
   a.psi = mc ? mc->psi : nullptr; a.psi_out = mc ? mc->psi_out : nullptr;
   if (mc) a.ng = mc->g;
   if (mc && coarse) return -1;
   a.coarse = coarse; a.cg = cg ? *cg : sg;
-  if (coarse && (K < 3 || h)) return -1;  // the prolongation variant exists for K = 3, 4 on whole (untiled) levels
+  if (coarse && (K < 3 || (h && !ch))) return -1;  // the prolongation variant exists for K = 3, 4; on tiles it needs the coarse halo
   a.in_s = h ? h->in_s : nullptr; a.in_n = h ? h->in_n : nullptr; a.res_s = h ? h->res_s : nullptr; a.res_n = h ? h->res_n : nullptr;
   a.hls = h ? h->ls : 0; a.KR = h ? h->rows : 0;
   extern int g_march_remap;

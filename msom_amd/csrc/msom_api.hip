@@ -1093,13 +1093,30 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
       STICKY(m, exch_split_deep(m, L.res, *L.sg, m->mh_res_s[k], m->mh_res_n[k], hg, nl));  // constant during the sweeps
     }
     const int kmax = nl >= 7 && m->march_k > 3 ? 3 : m->march_k;
-    if (coarse && n >= 3 && kmax >= 3 && !L.tiled && m->march_prolong) {
+    // tiles: the pass then needs MARCH_HALO cells / rows of the COARSE correction beyond the tile edges too (LDS-DMA kernel, nl <= 6)
+    const bool pl_tiled = L.tiled && coarse && coarse->k >= 0 && nl <= 6 && m->march_prolong >= 1 && coarse->sg->nx >= 2 * MARCH_HALO && coarse->sg->ny >= 2 * MARCH_HALO;
+    if (coarse && n >= 3 && kmax >= 3 && (!L.tiled || pl_tiled) && m->march_prolong) {
       // whole levels: the prolongation rides in the first PASS (its input is interpolated from the coarse level on
       // the fly), so the 2 nrelax half-sweeps are 4 + 4 instead of (red + prolongation) + 4 + 3
       int K = n < kmax ? n : kmax;
       if (n - K == 1 && K > 3) K--;
+      MarchHalo ch{nullptr, nullptr, nullptr, nullptr, 0, MARCH_HALO};
+      if (L.tiled) {   // deep halo of the coarse correction: pads W / E, halo arrays S / N (those of the coarse level's own passes)
+        const int ck = coarse->k;
+        SplitGeom chg = make_split(coarse->sg->nx, MARCH_HALO);
+        if (!m->mh_da_s[ck]) {
+          for (auto *v : {&m->mh_da_s, &m->mh_da_n, &m->mh_res_s, &m->mh_res_n}) {
+            if (hipMalloc(&(*v)[ck], chg.ls * nl * sizeof(double)) != hipSuccess) { m->sticky = MSOM_ERR_HIP; return; }
+            hipMemsetAsync((*v)[ck], 0, chg.ls * nl * sizeof(double), m->st);
+          }
+        }
+        STICKY(m, exch_split_deep(m, *coarse->da, *coarse->sg, m->mh_da_s[ck], m->mh_da_n[ck], chg, nl));
+        ch.ls = chg.ls;
+        ch.in_s = m->nb[DIR_S] >= 0 ? m->mh_da_s[ck] : nullptr; ch.in_n = m->nb[DIR_N] >= 0 ? m->mh_da_n[ck] : nullptr;
+      }
       if (prof) prof_begin(m, m->prof_march_pl);
-      if (launch_relax_march(m->st, nullptr, *L.da_alt, L.res, *L.sg, nl, *L.rc, 0, K, L.walls, g_march_rows, nullptr, *coarse->da, coarse->sg, nullptr, m->march_partial && n - K >= 1))
+      if (launch_relax_march(m->st, nullptr, *L.da_alt, L.res, *L.sg, nl, *L.rc, 0, K, L.walls, g_march_rows, L.tiled ? &mh : nullptr, *coarse->da, coarse->sg, nullptr,
+                             m->march_partial && n - K >= 1, L.tiled ? &ch : nullptr))
         m->sticky = MSOM_ERR_ARG;
       if (prof) prof_end(m, m->prof_march_pl);
       std::swap(*L.da, *L.da_alt);
