@@ -703,13 +703,13 @@ static int march_dispatch(hipStream_t st, const MarchArgs &a, int K, int rows) {
     constexpr int NLS = NL;
     const bool four = a.coarse ? g_march_dma >= 3 : g_march_dma >= 2;
 #define MARCH_DMA_K(KK)                                                                                                      \
-    if (a.coarse) {                                                                                                          \
-      if (four) march_launch(st, k_relax_march_dma<NLS, KK, 4, 4, true>, a, 56 * 4, rows, 256);                                \
-      else march_launch(st, k_relax_march_dma<NLS, KK, 4, 1, true>, a, 56, rows, 64);                                          \
-    } else if (a.psi_out) {                                                                                                  \
-      if (four) march_launch(st, k_relax_march_dma<NLS, KK, 2, 4, false, true>, a, 60 * 4, rows, 256);                         \
-      else march_launch(st, k_relax_march_dma<NLS, KK, 2, 1, false, true>, a, 60, rows, 64);                                   \
-    } else if (four) march_launch(st, k_relax_march_dma<NLS, KK, 2, 4, false>, a, 60 * 4, rows, 256);                          \
+    if constexpr (NL <= 6) {   /* four strips per workgroup: 4 x the LDS ring; at nl = 7, 8 that leaves one workgroup per CU */   \
+      if (a.coarse && four) { march_launch(st, k_relax_march_dma<NLS, KK, 4, 4, true>, a, 56 * 4, rows, 256); return 0; }        \
+      if (a.psi_out && four) { march_launch(st, k_relax_march_dma<NLS, KK, 2, 4, false, true>, a, 60 * 4, rows, 256); return 0; } \
+      if (!a.coarse && !a.psi_out && four) { march_launch(st, k_relax_march_dma<NLS, KK, 2, 4, false>, a, 60 * 4, rows, 256); return 0; } \
+    }                                                                                                                        \
+    if (a.coarse) march_launch(st, k_relax_march_dma<NLS, KK, 4, 1, true>, a, 56, rows, 64);                                   \
+    else if (a.psi_out) march_launch(st, k_relax_march_dma<NLS, KK, 2, 1, false, true>, a, 60, rows, 64);                      \
     else march_launch(st, k_relax_march_dma<NLS, KK, 2, 1, false>, a, 60, rows, 64);                                           \
     return 0;
     if constexpr (NL <= 6) {
@@ -720,7 +720,7 @@ static int march_dispatch(hipStream_t st, const MarchArgs &a, int K, int rows) {
       }
     } else {
       switch (K) {
-        case 2: { MARCH_DMA_K(2) }
+        case 2: if (!a.coarse) { MARCH_DMA_K(2) } break;
         case 3: { MARCH_DMA_K(3) }
       }
     }
