@@ -282,12 +282,13 @@ struct NRelaxArgs {
 // one colour of relax_baroclinic (qg_baroclinic_ms.h:228-291) / relax_barotropic (qg_barotropic.h:57-76)
 // on the interior vertices; boundary vertices of the correction stay 0 (homogeneous psi BC).
 // column solve of one vertex: ew[l] = a_E + a_W, ns[l] = a_N + a_S of layer l; c = index of the vertex in layer 0
+// bv[l] = b of layer l, m = mask, sv[l] = S2 of layer l (l < NL - 1) at the vertex
 template <int NL>
-__device__ __forceinline__ void n_col_solve(const NRelaxArgs &p, size_t c, const double (&ew)[NL], const double (&ns)[NL], double (&x)[NL]) {
-  const size_t ls = p.g.ls;
-  const double sq = p.sqD, m = p.mk[c];
+__device__ __forceinline__ void n_col_solve_vals(const NRelaxArgs &p, const double (&bv)[NL], double m, const double (&sv)[NL], const double (&ew)[NL],
+                                                 const double (&ns)[NL], double (&x)[NL]) {
+  const double sq = p.sqD;
   if (NL == 1) {
-    double d = -(-p.iRd2) * sq, v = -p.b[c] * sq;
+    double d = -(-p.iRd2) * sq, v = -bv[0] * sq;
     v += ew[0] * m; d += 2.;
     v += ns[0] * m; d += 2.;
     x[0] = v / d;
@@ -296,10 +297,9 @@ __device__ __forceinline__ void n_col_solve(const NRelaxArgs &p, size_t c, const
   double t0[NL], t1[NL], t2[NL], rhs[NL];
 #pragma unroll
   for (int l = 0; l < NL; l++) {
-    const size_t k = c + l * ls;
-    rhs[l] = -sq * p.b[k] * m;
-    t0[l] = l == 0 ? 0. : (l < NL - 1 ? -sq * p.S2[k - ls] * p.lc.idh0[l] * m : -sq * p.S2[k - ls] * p.lc.idh0[l]);  // bottom t0 not masked, :267
-    t2[l] = l < NL - 1 ? -sq * p.S2[k] * p.lc.idh1[l] * m : 0.;
+    rhs[l] = -sq * bv[l] * m;
+    t0[l] = l == 0 ? 0. : (l < NL - 1 ? -sq * sv[l - 1] * p.lc.idh0[l] * m : -sq * sv[l - 1] * p.lc.idh0[l]);  // bottom t0 not masked, :267
+    t2[l] = l < NL - 1 ? -sq * sv[l] * p.lc.idh1[l] * m : 0.;
     t1[l] = l == 0 ? -t2[l] : (l < NL - 1 ? -t0[l] - t2[l] : -t0[l]);
     rhs[l] += ew[l] * m; t1[l] += 2;
     rhs[l] += ns[l] * m; t1[l] += 2;
@@ -326,6 +326,17 @@ __device__ __forceinline__ void n_col_solve(const NRelaxArgs &p, size_t c, const
 #pragma unroll
   for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - t2[l] * x[l + 1]) * r[l];
 #endif
+}
+template <int NL>
+__device__ __forceinline__ void n_col_solve(const NRelaxArgs &p, size_t c, const double (&ew)[NL], const double (&ns)[NL], double (&x)[NL]) {
+  const size_t ls = p.g.ls;
+  double bv[NL], sv[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    bv[l] = p.b[c + l * ls];
+    sv[l] = (NL > 1 && l < NL - 1) ? p.S2[c + l * ls] : 0.;
+  }
+  n_col_solve_vals<NL>(p, bv, p.mk[c], sv, ew, ns, x);
 }
 template <int NL>
 __device__ __forceinline__ void n_relax_pt(const NRelaxArgs &p, int i, int j) {
@@ -367,17 +378,11 @@ __global__ void __launch_bounds__(64) k_n_relax_march(NRelaxArgs p, const double
   const int n = p.g.nx - 1;                      // vertices 0 .. n
   const int gi = (int)blockIdx.x * OW - K + lane;
   const int y0 = blockIdx.y * H, y1 = min(n + 1, y0 + H);
-  const int pitch = p.g.pitch;
   const size_t ls = p.g.ls;
-  const bool col_ok = gi >= 0 && gi <= n;        // a column of the grid (pads beyond: read as they are, never used by valid cells)
-  const int gic = min(max(gi, -1), n + 1);
+  const int gic = min(max(gi, -1), n + 1);       // pads beyond the grid: read as they are, never used by valid vertices
   const bool own = lane >= K && lane < 64 - K && gi <= n;
-  auto load_row = [&](int r, double (&dst)[NL]) {
-    const int rc = min(max(r, -1), n + 1);
-    const double *src = a_in + nat_idx(p.g, 0, rc, gic);
-#pragma unroll
-    for (int l = 0; l < NL; l++) dst[l] = src[l * ls];
-  };
+  const bool col_in = gi >= 1 && gi <= n - 1;    // an inner column
+  auto rowp = [&](const double *f, int r) -> const double * { return f + nat_idx(p.g, 0, min(max(r, -1), n + 1), gic); };
   double W[K][3][NL];
 #pragma unroll
   for (int s = 0; s < K; s++)
@@ -385,31 +390,52 @@ __global__ void __launch_bounds__(64) k_n_relax_march(NRelaxArgs p, const double
     for (int q = 0; q < 3; q++)
 #pragma unroll
       for (int l = 0; l < NL; l++) W[s][q][l] = 0.;
-  load_row(y0 - K, W[0][1]);
-  load_row(y0 - K + 1, W[0][2]);
+  // software pipeline: the rows of step t + 1 (input row t + 2; b, mask, S2 of row t + 1 for the first half-sweep) are
+  // requested at the top of step t into `n*` and move to the working registers at the top of step t + 1
+  double na[NL], nb[NL], ns2[NL], nm;
+  {
+    const double *pa = rowp(a_in, y0 - K), *pb = rowp(a_in, y0 - K + 1);
+#pragma unroll
+    for (int l = 0; l < NL; l++) { W[0][1][l] = pa[l * ls]; W[0][2][l] = pb[l * ls]; }
+    const int t = y0 - K + 1;
+    const double *qa = rowp(a_in, t + 1), *qb = rowp(p.b, t);
+    const double *qs = NL > 1 ? rowp(p.S2, t) : qb;
+#pragma unroll
+    for (int l = 0; l < NL; l++) { na[l] = qa[l * ls]; nb[l] = qb[l * ls]; ns2[l] = (NL > 1 && l < NL - 1) ? qs[l * ls] : 0.; }
+    nm = *rowp(p.mk, t);
+  }
   for (int t = y0 - K + 1; t <= y1 + K - 2; t++) {
 #pragma unroll
     for (int s = 0; s < K; s++)
 #pragma unroll
       for (int l = 0; l < NL; l++) { W[s][0][l] = W[s][1][l]; W[s][1][l] = W[s][2][l]; }
-    load_row(t + 1, W[0][2]);
+    double cb[NL], cs2[NL];
+    const double cm = nm;
+#pragma unroll
+    for (int l = 0; l < NL; l++) { W[0][2][l] = na[l]; cb[l] = nb[l]; cs2[l] = ns2[l]; }
+    {
+      const double *qa = rowp(a_in, t + 2), *qb = rowp(p.b, t + 1);
+      const double *qs = NL > 1 ? rowp(p.S2, t + 1) : qb;
+#pragma unroll
+      for (int l = 0; l < NL; l++) { na[l] = qa[l * ls]; nb[l] = qb[l * ls]; ns2[l] = (NL > 1 && l < NL - 1) ? qs[l * ls] : 0.; }
+      nm = *rowp(p.mk, t + 1);
+    }
 #pragma unroll
     for (int s = 1; s <= K; s++) {
       const int r = t - (s - 1);                 // row of half-sweep s
       const int col = (p.color + s - 1) & 1;     // its colour
-      double x[NL];
-#pragma unroll
-      for (int l = 0; l < NL; l++) x[l] = W[s - 1][1][l];   // carried unless this vertex is relaxed now
-      double ew[NL], ns[NL];
+      double x[NL], ew[NL], ns[NL];
 #pragma unroll
       for (int l = 0; l < NL; l++) {
         const double a = W[s - 1][1][l];
+        x[l] = a;                                // carried unless this vertex is relaxed now
         ew[l] = lane_above(a) + lane_below(a);   // a_E + a_W (k_n_relax: p.a[k + 1] + p.a[k - 1])
         ns[l] = W[s - 1][2][l] + W[s - 1][0][l]; // a_N + a_S
       }
-      if (r >= 1 && r <= n - 1 && col_ok && gi >= 1 && gi <= n - 1 && ((gi + r) & 1) == col) {
+      if (r >= 1 && r <= n - 1 && col_in && ((gi + r) & 1) == col) {
         double xn[NL];
-        n_col_solve<NL>(p, nat_idx(p.g, 0, r, gi), ew, ns, xn);
+        if (s == 1) n_col_solve_vals<NL>(p, cb, cm, cs2, ew, ns, xn);           // row t: prefetched one step ago
+        else n_col_solve<NL>(p, nat_idx(p.g, 0, r, gi), ew, ns, xn);            // rows t - 1 ...: second use, L2
 #pragma unroll
         for (int l = 0; l < NL; l++) x[l] = xn[l];
       }

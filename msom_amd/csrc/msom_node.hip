@@ -54,10 +54,10 @@ struct msomn {
   std::vector<NatGeom> cg;
   std::vector<double *> cs, cr, csig;  // cs[0] = n_stoch
   int mg_coarse = 32;   // the levels of <= (mg_coarse + 1)^2 vertices of a cycle in one launch (k_n_mg_coarse); 0: off
-  int node_march = 0;   // levels of >= node_march vertices per side: K = 4 chained colour half-sweeps per pass (k_n_relax_march).  Measured at
-                        // 2049^2 x 3: a K = 4 pass (2 sweeps) ~320 us on the finest level against 4 x 70 us of colour passes -- half the
-                        // bytes, but plain loads consumed in the step that issues them and the b / mask / S2 loads inside the column
-                        // solve leave the wavefront latency-bound (the cell-centred pass needed LDS-DMA prefetch for the same reason): off
+  int node_march = 0;   // levels of >= node_march vertices per side: K = 4 chained colour half-sweeps per pass (k_n_relax_march, rows
+                        // software-prefetched one step ahead).  Measured at 2049^2 x 3: 27.1 vs 26.6 ms per step, 513^2 x 3: 4.2 vs 3.1 --
+                        // half the bytes, but in the natural layout half of the lanes idle in every half-sweep and the vertex column
+                        // solve (vertex-dependent coefficients, one reciprocal per layer) is arithmetic-bound: off
   int tiled_relax = 0;  // option: LDS-tiled smoother passes (1-2 sweeps per pass) on the wide levels; measured 3 % faster at 4097^2 x 3, 7 % slower at 2049^2 x 3
   NatGeom g;
   double *f[MSOMN_NFIELDS] = {nullptr};
