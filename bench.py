@@ -264,7 +264,7 @@ def vertex_sqg_leg(N=2048, nl=3, steps=6):
     return out
 
 
-def roofline(leg, world):
+def roofline(leg, world, leg_steps=1):
     ks, w, plain_bytes, uniform = leg.kernels()
     nl = leg.nl
     dom = next((k for k in ("march_corr", "march4", "march3", "march2") if k in ks), "sweep" if "sweep" in ks else None)
@@ -298,6 +298,11 @@ def roofline(leg, world):
         "effective_bw_in_survey_sweep_units": {"GBs": eff, "per_unit_bytes": 2.0 * plain_bytes, "units_per_launch": K / 2.0,
                                                "note": "K half-sweeps = K/2 sweeps of (3+sigma) w each if run one by one; values between chained half-sweeps stay in registers"},
         "smoother_that_ran": dom,
+        # all finest-level kernels together: compulsory bytes of every timed launch / their summed durations
+        "finest_level_kernels_together": (lambda b, t: {"GBs": b / t / 1e9 if t > 0 else 0.0, "frac_hbm": b / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0,
+                                                       "compulsory_GB_per_step": b / 1e9 / max(1, leg_steps), "kernel_ms_per_step": t * 1e3 / max(1, leg_steps)})(
+            sum(v["compulsory_bytes_per_launch"] * v["launches_timed"] for v in ks.values()),
+            sum(v["avg_launch_ms"] * 1e-3 * v["launches_timed"] for v in ks.values())),
         "kernels": ks,
     }
 
@@ -349,7 +354,7 @@ def main():
         leg.g.option(k, float(v))
     elapsed = leg.run(args.steps, args.warmup)
     main_sum = leg.summary(args.steps, elapsed)
-    roof = roofline(leg, world) if rank == 0 else None
+    roof = roofline(leg, world, args.steps) if rank == 0 else None
     uniform = leg.g.param("uniform_S") == 1.0
     leg.g.close()
 
