@@ -91,7 +91,8 @@ int msom_destroy(msom_t *m);
  * the host, 1: counter-based Philox on the device), "flag_topo", "uniform_S" (0 forces the general
  * S-field kernels), "profile" (HIP-event timing of the finest-level smoother and residual launches).
  * Implementation switches, all result-preserving in the strict build (defaults in brackets):
- * "fused" [1] one-pass tendency kernel, "adv_fused" [1] advance folded into it, "rhs_variant" [6: one layer per
+ * "fused" [1] one-pass tendency kernel, "adv_fused" [1] advance folded into it, "stoch_fused" [1] (product build only) the
+ * stochastic variant rides in that kernel too: -q/tau and the noise are folded into q_in by a one-read pre-pass, "rhs_variant" [6: one layer per
  * wavefront with register windows; 1: LDS tiles],
  * "rhs_resid" [0] first residual of the next inversion as its by-product, "mg_fused" [1] fused
  * residual/restriction and correction/residual passes, "prolong_fused" [1], "mg_coarse" [1] coarse levels

@@ -43,7 +43,8 @@ struct LpwArgs {
 
 // UNI: uniform S (constants), QF: 3-D forcing present, ADV: advance fused.  Compile-time so that the unrolled row body
 // is straight-line code: s_waitcnt counters stay exact and a wave never waits for a prefetch it does not need yet
-template <int R, bool UNI, bool QF, bool ADV>
+// STOCH (msqg/qg_stochastic.h:36-63): the top layer drops J(psi, zeta), no layer has the interface Jacobian
+template <int R, bool UNI, bool QF, bool ADV, bool STOCH = false>
 __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
   __shared__ double ring[2][LPW_MAXW][R][LPW_NV][64];
   const int lane = threadIdx.x & 63;
@@ -168,9 +169,9 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
       zz[k][0] = ZL[k]; zz[k][1] = Z[k]; zz[k][2] = ZR[k];
       p1[k][0] = QL[k]; p1[k][1] = Q[k]; p1[k][2] = QR[k];
     }
-    const double adv = mjac9(p, zz, D12, rD12);
+    const double adv = (STOCH && l == 0) ? 0. : mjac9(p, zz, D12, rD12);
     const double be = DIVC(a.beta * (p[1][0] - p[1][2]), D2x, rD2x);
-    const double jd = lower ? mjac9(p, p1, D12, rD12) : 0.;
+    const double jd = (lower && !STOCH) ? mjac9(p, p1, D12, rD12) : 0.;
     const double zc = Z[1], tc = T[1];
     const double lapT = DIVC(TR[0] + TL[0] + T[2] + T[0] - 4 * tc, D2, rD2);
 #ifdef MSOM_STRICT
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
 
 void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq, const NatGeom &g,
                     int nl, int walls, int uniformS, const double *Su, int have_qforc, double D, double beta, double iRe, double iRe4, double cs,
-                    double cb, double slip_c, const LayerCoef &lc, const double *q_in, double *q_out, double dt, int chunk_rows) {
+                    double cb, double slip_c, const LayerCoef &lc, const double *q_in, double *q_out, double dt, int chunk_rows, int stoch) {
   LpwArgs a;
   a.psi = psi; a.S = S; a.qforc = qforc; a.wind = wind; a.q_in = q_in; a.dq = dq; a.q_out = q_out; a.dt = dt;
   a.g = g; a.nl = nl; a.walls = walls; a.uniformS = uniformS; a.have_qforc = have_qforc;
@@ -329,6 +330,16 @@ void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const do
   if (a.NS > strips) a.NS = strips;
   const dim3 gr((strips + a.NS - 1) / a.NS, (g.ny + H - 1) / H), bl(64 * nl * a.NS);
   const int sel = (uniformS ? 4 : 0) | (have_qforc ? 2 : 0) | (q_out ? 1 : 0);
+  if (stoch) {  // only with the advance fused (the caller folds -q/tau and the noise into q_in)
+    switch (sel) {
+      case 1: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, false, false, true, true>), gr, bl, 0, st, a); break;
+      case 3: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, false, true, true, true>), gr, bl, 0, st, a); break;
+      case 5: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, true, false, true, true>), gr, bl, 0, st, a); break;
+      case 7: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, true, true, true, true>), gr, bl, 0, st, a); break;
+      default: fprintf(stderr, "msom: launch_rhs_lpw: stochastic variant needs q_out\n"); abort();
+    }
+    return;
+  }
   switch (sel) {
     case 0: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, false, false, false>), gr, bl, 0, st, a); break;
     case 1: hipLaunchKernelGGL((k_rhs_lpw<LPW_R, false, false, true>), gr, bl, 0, st, a); break;

@@ -99,7 +99,7 @@ struct msom {
   // flags
   int const_set = 0, flag_topo = 0, have_pg = 0, have_zpg = 0, have_qforc = 0;
   int fr_uniform = 1, uniformS = 0, uniform_opt = -1 /* auto */;
-  int stochastic = 0, corrector_step = 0, noise_mode = 0;
+  int stochastic = 0, corrector_step = 0, noise_mode = 0, stoch_fused = 1;
   int prolong_fused = 1;  // first red half-sweep of a level interpolates its neighbours from the coarser level
   int block_sweeps = 0;  // experimental temporally blocked smoother (2 sweeps per pass); measured not faster at nl = 6
   int block_small = 0;   // the same kernel on the launch-bound levels only (not marched, <= block_small cells wide): 2 launches per level visit instead of 8
@@ -680,6 +680,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "rhs_resid")) { m->rhs_resid = (int)v; m->res_ready = -1; }
   else if (!strcmp(key, "seed")) { m->seed = (unsigned)v; srand(m->seed); }
   else if (!strcmp(key, "noise_mode")) m->noise_mode = (int)v;
+  else if (!strcmp(key, "stoch_fused")) m->stoch_fused = (int)v;
   else if (!strcmp(key, "stochastic")) {
     m->stochastic = (int)v;
     if (m->stochastic && !m->f[MSOM_NOISE]) {
@@ -1421,13 +1422,23 @@ static void comp_stretch(msom *m, int in, int out, double add, double fac) {
 // surface_forcing, [qforcing], [bottom_topography]   (msqg/qg.h:622-630 / qg_bfn.h:67-76)
 // adv_out >= 0 asks for q[adv_out] = q[adv_in] + adv_dt * dq in the same pass (the corrector's
 // advance_qg); *advanced tells the caller whether that happened (fused path) or not.
+static int stoch_prepare(msom *m, double dt, double *dts);
 static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double iRe, double iRe4, double Eks, double Ekb, int adv_out = -1,
                      int adv_in = -1, double adv_dt = 0., int *advanced = nullptr) {
   if (advanced) *advanced = 0;
   const Params &p = m->p;
   const double D = p.L0 / m->gnx;
   const int nl = m->nl;
-  if (m->fused && !m->have_pg && !m->have_zpg && !m->flag_topo && !m->stochastic && (m->nranks == 1 || (m->nx >= 4 && m->ny >= 4))) {
+  // stochastic runs (msqg/qg_stochastic.h) ride in the same kernel when the advance does: the relaxation -q/tau and the
+  // noise are linear in fields that exist before the pass, so a one-read pre-pass folds them into q_in.  The validation
+  // build keeps the reference's operation order (separate kernels) instead.
+#ifdef MSOM_STRICT
+  const bool stoch_fused = false;
+#else
+  const bool stoch_fused = m->stochastic && m->stoch_fused && m->adv_fused && adv_out >= 0 && m->rhs_variant == 6 && !m->rhs_resid;
+#endif
+  if (m->fused && !m->have_pg && !m->have_zpg && !m->flag_topo && (!m->stochastic || stoch_fused) &&
+      (m->nranks == 1 || (m->nx >= 4 && m->ny >= 4))) {
     // tiles: the fused kernel needs psi on a 3-cell halo (zeta on 2, lap(zeta) on 1)
     if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], nl, m->bc, 3));
     if (m->bc == BC_PERIODIC && m->nranks == 1) launch_fill_periodic(m->st, m->f[MSOM_PSI], m->g, nl, 3);
@@ -1442,6 +1453,23 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
       rr.sg = m->sg[0]; rr.cg = m->sg[1];
     }
     // one pass over psi: zeta, Jacobians, beta, dissipation, drag, forcing, max|u| (kernels_fused.hip)
+    if (stoch_fused) {
+      extern int g_rhs_dbg;
+      double dts;
+      int r = stoch_prepare(m, adv_dt, &dts);
+      if (r) return r;
+      m->res_ready = -1;
+      // DQ is free (the fused advance never stores the tendency): DQ = q_in - (dt / tau) q_stage + dts * noise
+      launch_advance(m->st, m->f[dqfield], m->f[adv_in], m->f[qfield], m->f[MSOM_NOISE], m->g, nl, -adv_dt * p.itr_stoch, dts);
+      prof_begin(m, m->prof_rhs);
+      launch_rhs_lpw(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, nullptr, m->g, nl, m->walls & WALL_ALL, m->uniformS,
+                     m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe, iRe4, Eks / (p.Rom * 2 * m->dhf[0]),
+                     Ekb / (p.Rom * 2 * m->dhf[nl - 1]), p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, m->f[dqfield],
+                     m->f[adv_out], adv_dt, g_rhs_dbg >> 8, 1);
+      prof_end(m, m->prof_rhs);
+      if (advanced) *advanced = 1;
+      return MSOM_OK;
+    }
     prof_begin(m, m->prof_rhs);
     launch_rhs_fused(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, m->f[dqfield], nullptr,
                      nullptr, m->g, nl, m->walls & WALL_ALL, m->uniformS, m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe,
@@ -1520,24 +1548,32 @@ static int generate_noise_host(msom *m) {
   return upload(m, MSOM_NOISE, n.data());
 }
 
+// the stochastic part of advance_qg (msqg/qg_stochastic.h:128-138): every other call draws new noise and uses
+// sqrt(dt)/sqrt(2), computed in float as the reference does
+static int stoch_prepare(msom *m, double dt, double *dts) {
+  m->corrector_step = (m->corrector_step + 1) % 2;
+  float fdts = sqrt(dt);
+  if (m->corrector_step) {
+    if (m->noise_mode == 0) {  // reference-exact serial rand() stream
+      int r = generate_noise_host(m);
+      if (r) return r;
+    } else  // counter-based device generator
+      launch_noise(m->st, m->f[MSOM_NOISE], m->f[MSOM_SIGMA], m->g, m->nl, m->p.amp_stoch, m->seed, m->noise_draw++, m->ix * m->nx,
+                   m->iy * m->ny, m->gnx);
+    fdts = fdts / sqrt(2);
+  }
+  *dts = fdts;
+  return MSOM_OK;
+}
+
 // advance_qg, msqg/qg.h:594-606 / msqg/qg_stochastic.h:128-149
 static int advance_qg(msom *m, int out, int in, int dq, double dt) {
   m->res_ready = -1;
   const double *noise = nullptr;
   double dts = 0;
   if (m->stochastic) {
-    m->corrector_step = (m->corrector_step + 1) % 2;
-    float fdts = sqrt(dt);
-    if (m->corrector_step) {
-      if (m->noise_mode == 0) {  // reference-exact serial rand() stream
-        int r = generate_noise_host(m);
-        if (r) return r;
-      } else  // counter-based device generator
-        launch_noise(m->st, m->f[MSOM_NOISE], m->f[MSOM_SIGMA], m->g, m->nl, m->p.amp_stoch, m->seed, m->noise_draw++, m->ix * m->nx,
-                     m->iy * m->ny, m->gnx);
-      fdts = fdts / sqrt(2);
-    }
-    dts = fdts;
+    int r = stoch_prepare(m, dt, &dts);
+    if (r) return r;
     noise = m->f[MSOM_NOISE];
   }
   launch_advance(m->st, m->f[out], m->f[in], m->f[dq], noise, m->g, m->nl, dt, dts);

@@ -189,6 +189,33 @@ def test_strict_stochastic_variant_bit_exact():
 
 # ------------------------------------------------------------------ fast (product) build: tolerances
 
+@pytest.mark.parametrize("nx,ny,nl,extra", [(64, 64, 3, ""), (128, 64, 6, ""), (64, 64, 2, "sbc = -1\n")])
+def test_fast_stochastic_rides_in_the_tendency_pass(nx, ny, nl, extra):
+    """Product build, -D_STOCHASTIC (msqg/qg_stochastic.h:36-63, 128-149): relaxation and noise are folded into q_in by
+    a pre-pass and the advance rides in the tendency kernel (stoch_fused = 1); against the separate kernels
+    (stoch_fused = 0) and against the oracle on the same serial rand() stream."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    ex = extra + "tr_stoch = 50\namp_stoch = 1e-5\n"
+    sig = np.abs(rand_field(12, (nl, ny, nx)))
+    res = []
+    for which in ("oracle", 1, 0):
+        o, g = make_pair(nx, ny, nl, strict=False, extra=ex, stochastic=1, TOLERANCE=1e-12)
+        if extra:
+            o.remove_mean(orc.PSI); g.remove_mean(F["PSI"])
+        m = o if which == "oracle" else g
+        if which != "oracle":
+            g.option("stoch_fused", which)
+        m.set(orc.SIGMA if m is o else F["SIGMA"], sig)
+        libc.srand(7)
+        m.set_tnext(float("inf"))
+        for _ in range(4):
+            m.step()
+        res.append(m.get(orc.Q if m is o else F["Q"]))
+    assert rel(res[1], res[0]) <= 1e-10 and rel(res[2], res[0]) <= 1e-10
+    assert rel(res[1], res[2]) <= 1e-11 and not np.array_equal(res[1], res[2])   # the two paths are different code
+
+
 @pytest.mark.parametrize("nx,ny,nl", CASES)
 def test_fast_operators_within_tolerance(nx, ny, nl):
     o, g = make_pair(nx, ny, nl, strict=False)

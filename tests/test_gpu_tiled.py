@@ -437,3 +437,35 @@ def test_wavelet_filter_on_tiles(px, py, tile, nl, extra, strict):
     for k in range(4):
         got = np.concatenate([np.concatenate([out[iy * px + ix]["extra"][k] for ix in range(px)], axis=2) for iy in range(py)], axis=1)
         assert np.array_equal(got, ref[k]), k
+
+
+@pytest.mark.parametrize("px,py,tile,nl", [(2, 2, 32, 3), (2, 1, 64, 2)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_stochastic_steps_on_tiles(px, py, tile, nl, strict):
+    """-D_STOCHASTIC (msqg/qg_stochastic.h) with the counter-based device noise on tiles: the same fields as one tile,
+    bit for bit (product build: relaxation + noise folded into the tendency pass; validation build: separate kernels)."""
+    gnx, gny = tile * px, tile * py
+    extra = (f"Ny = {gny}\n" if gny != gnx else "") + f"MGLEVELS = {int(np.log2(tile))}\ntr_stoch = 50\namp_stoch = 1e-5\n"
+    params = orc.double_gyre_params(gnx, nl, extra=extra)
+    psi = orc.synthetic_psi(nl, gny, gnx)
+    sig = np.abs(np.random.default_rng(5).standard_normal((nl, gny, gnx)))
+    opts = {"stochastic": 1, "noise_mode": 1, "seed": 3}
+    tx, ty = gnx // px, gny // py
+
+    def pre(g, r):
+        ix, iy = r % px, r // px
+        g.set(F["SIGMA"], np.ascontiguousarray(sig[:, iy * ty:(iy + 1) * ty, ix * tx:(ix + 1) * tx]))
+
+    out = run_tiled(params, px, py, psi, nsteps=4, strict=strict, opts=opts, pre=pre)
+    g = QG(params, strict=strict)
+    g.option("quiet", 1)
+    for k, v in opts.items():
+        g.option(k, v)
+    g.set(F["PSI"], psi)
+    g.set_const()
+    g.set(F["SIGMA"], sig)
+    g.set_tnext(float("inf"))
+    for _ in range(4):
+        g.step()
+    assert np.array_equal(assemble(out, "q", px, py), g.get(F["Q"]))
+    assert np.array_equal(assemble(out, "psi", px, py), g.get(F["PSI"]))
