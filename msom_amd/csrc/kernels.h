@@ -142,7 +142,7 @@ void launch_wv_qof(hipStream_t st, double *qof, double *q, const double *tmp, co
 
 // ---- kernels_node.hip (vertex-grid variant, qg-node/)
 void launch_n_bnd_from(hipStream_t st, double *f, const double *g, const NatGeom &ge, int nl, double c, int use_g_bnd, double gbc);
-void launch_n_bnd_const(hipStream_t st, double *f, const NatGeom &ge, int nl, double v);
+void launch_n_bnd_const(hipStream_t st, double *f, const NatGeom &ge, int nl, double v, int sp = 0);
 void launch_n_mul_mask(hipStream_t st, double *a, double *b, const double *mk, const NatGeom &g, int nl);
 void launch_n_del2(hipStream_t st, const double *in, double *out, const NatGeom &g, int nl, double add, double fac, double D);
 void launch_n_stretch(hipStream_t st, const double *in, double *out, const double *S2, const NatGeom &g, int nl, double add, double fac,
@@ -159,23 +159,27 @@ void launch_n_rhs_barotropic(hipStream_t st, const double *psi, const double *q,
                              double drag, double nu);
 void launch_n_helm(hipStream_t st, const double *psi, double *q, const NatGeom &g, double D, double iRd2);
 void launch_n_rowfill(hipStream_t st, double *f, const double *row, const NatGeom &g);
+// sp = 1: a, b, mk, S2 in the x-parity split layout (g = their geometry)
 void launch_n_relax(hipStream_t st, double *a, const double *b, const double *mk, const double *S2, const NatGeom &g, int nl, int color, double D,
-                    double iRd2, const LayerCoef &lc);
+                    double iRd2, const LayerCoef &lc, int sp = 0, const double *S2row = nullptr);
 int launch_n_relax_march(hipStream_t st, const double *a_in, double *a_out, const double *b, const double *mk, const double *S2, const NatGeom &g, int nl,
                          int color, int K, double D, double iRd2, const LayerCoef &lc);
 int launch_n_relax_tile(hipStream_t st, const double *a_in, double *a_out, const double *b, const double *mk, const double *S2, const NatGeom &g,
                         int nl, int ns, double D, double iRd2, const LayerCoef &lc);
 void launch_n_residual(hipStream_t st, const double *a, const double *b, const double *mk, const double *S2, double *res, double *maxres,
-                       const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc);
+                       const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc, const NatGeom *gres = nullptr,
+                       const double *S2row = nullptr);  // gres: res in the split layout; S2row: row table of an x-independent S2
 // coarse levels of a vpoisson cycle in one launch (k_n_mg_coarse): lev[0] = finest of the group
 #define NMGC_MAXLEV 8
 #define NMGC_NT 1024
 struct NCoarseLev { double *da, *res; const double *mask, *S2; NatGeom g; double sqD; };
 struct NCoarseArgs { NCoarseLev lev[NMGC_MAXLEV]; int n; double iRd2; LayerCoef lc; };
 void launch_n_mg_coarse(hipStream_t st, const NCoarseArgs &a, int nrelax, int nl);
-void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind);
-void launch_n_prolong(hipStream_t st, const double *c, const NatGeom &cg, double *f, const NatGeom &fg, int nl);
-void launch_n_correct(hipStream_t st, double *a, const double *da, const NatGeom &g, int nl, double bcv);
+void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind, int fsp = 0, int csp = 0);
+void launch_n_prolong(hipStream_t st, const double *c, const NatGeom &cg, double *f, const NatGeom &fg, int nl, int csp = 0, int fsp = 0);
+void launch_n_correct(hipStream_t st, double *a, const double *da, const NatGeom &g, int nl, double bcv, const NatGeom *gda = nullptr);
+void launch_n_row_table(hipStream_t st, const double *f, const NatGeom &g, int nl, double *out);
+void launch_n_relayout(hipStream_t st, const double *src, const NatGeom &sg, int ssp, double *dst, const NatGeom &dg, int dsp, int nl);
 void launch_n_umax(hipStream_t st, const double *psi, double *out, const NatGeom &g, int nl, double D);
 void launch_n_add_noise(hipStream_t st, double *q, const double *n, const NatGeom &g, const NatGeom &cg, double dts);
 void launch_n_diag1d(hipStream_t st, const double *psi, const double *q, const double *qf, double *partial, double *out3, const NatGeom &g, double nu, double D);

@@ -31,6 +31,15 @@ static inline dim3 grid_capped(int nx, int ny) {
 }
 #define VTX(g, i, j) const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y; if (i >= (g).nx || j >= (g).ny) return
 
+// Wide multigrid levels keep the correction, the residual and copies of mask / S2 in an x-parity split layout (round 2): a row is
+// stored as [even-i half | odd-i half], hp = (pitch - 2 XP) / 2 doubles each, so the vertices of one red-black colour are contiguous
+// in every row and a colour pass moves the bytes it uses (natural layout: whole lines, half used).  i = -1 and i = n + 1 land in
+// the pad of a half.  sp = 0: natural layout.
+__host__ __device__ __forceinline__ size_t gidx(const NatGeom &g, int sp, int l, int j, int i) {
+  const size_t row = (size_t)l * g.ls + (size_t)(j + MSOM_YP) * g.pitch + MSOM_XP;
+  return sp ? row + (size_t)((i & 1) * ((g.pitch - 2 * MSOM_XP) >> 1) + (i >> 1)) : row + i;
+}
+
 __device__ __forceinline__ double wave_max_n(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64)); return v; }
 __device__ __forceinline__ double wave_sum_n(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; }
 
@@ -74,18 +83,18 @@ void launch_n_bnd_from(hipStream_t st, double *f, const double *g, const NatGeom
   const int n = 4 * (ge.nx - 1) * nl;
   hipLaunchKernelGGL(k_n_bnd_from, dim3((n + 255) / 256), dim3(256), 0, st, f, g, ge, nl, c, use_g_bnd, gbc);
 }
-__global__ void k_n_bnd_const(double *f, NatGeom ge, int nl, double v) {
+__global__ void k_n_bnd_const(double *f, NatGeom ge, int nl, double v, int sp) {
   const int n = ge.nx - 1, per = 4 * n;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= per * nl) return;
   const int l = t / per, r = t % per;
   int i, j;
   if (r < 2 * (n + 1)) { i = r >> 1; j = (r & 1) ? n : 0; } else { const int q = r - 2 * (n + 1); j = 1 + (q >> 1); i = (q & 1) ? n : 0; }
-  f[nat_idx(ge, l, j, i)] = v;
+  f[gidx(ge, sp, l, j, i)] = v;
 }
-void launch_n_bnd_const(hipStream_t st, double *f, const NatGeom &ge, int nl, double v) {
+void launch_n_bnd_const(hipStream_t st, double *f, const NatGeom &ge, int nl, double v, int sp) {
   const int n = 4 * (ge.nx - 1) * nl;
-  hipLaunchKernelGGL(k_n_bnd_const, dim3((n + 255) / 256), dim3(256), 0, st, f, ge, nl, v);
+  hipLaunchKernelGGL(k_n_bnd_const, dim3((n + 255) / 256), dim3(256), 0, st, f, ge, nl, v, sp);
 }
 
 // ---------------------------------------------------------------- pointwise / stencil operators
@@ -278,6 +287,9 @@ struct NRelaxArgs {
   int color;
   double sqD, iRd2;
   LayerCoef lc;
+  // S2 independent of x (always so in the reference: S2 = f(y)^2 / N2[l], qg_baroclinic_ms.h:471-476, 501-505): S2row[l * g.ny + j]
+  // replaces the field read (a third of the bytes of a colour pass at nl = 3)
+  const double *S2row = nullptr;
 };
 // one colour of relax_baroclinic (qg_baroclinic_ms.h:228-291) / relax_barotropic (qg_barotropic.h:57-76)
 // on the interior vertices; boundary vertices of the correction stay 0 (homogeneous psi BC).
@@ -328,13 +340,14 @@ __device__ __forceinline__ void n_col_solve_vals(const NRelaxArgs &p, const doub
 #endif
 }
 template <int NL>
-__device__ __forceinline__ void n_col_solve(const NRelaxArgs &p, size_t c, const double (&ew)[NL], const double (&ns)[NL], double (&x)[NL]) {
+__device__ __forceinline__ void n_col_solve(const NRelaxArgs &p, size_t c, const double (&ew)[NL], const double (&ns)[NL], double (&x)[NL], int j = -1) {
   const size_t ls = p.g.ls;
   double bv[NL], sv[NL];
+  const bool rowS = p.S2row != nullptr && j >= 0;
 #pragma unroll
   for (int l = 0; l < NL; l++) {
     bv[l] = p.b[c + l * ls];
-    sv[l] = (NL > 1 && l < NL - 1) ? p.S2[c + l * ls] : 0.;
+    sv[l] = (NL > 1 && l < NL - 1) ? (rowS ? p.S2row[l * p.g.ny + j] : p.S2[c + l * ls]) : 0.;
   }
   n_col_solve_vals<NL>(p, bv, p.mk[c], sv, ew, ns, x);
 }
@@ -351,7 +364,7 @@ __device__ __forceinline__ void n_relax_pt(const NRelaxArgs &p, int i, int j) {
     ew[l] = p.a[k + 1] + p.a[k - 1];
     ns[l] = p.a[k + pitch] + p.a[k - pitch];
   }
-  n_col_solve<NL>(p, c, ew, ns, x);
+  n_col_solve<NL>(p, c, ew, ns, x, j);
 #pragma unroll
   for (int l = 0; l < NL; l++) p.a[c + l * ls] = x[l];
 }
@@ -360,6 +373,25 @@ __global__ void __launch_bounds__(BX *BY) k_n_relax(NRelaxArgs p) {
   const int j = 1 + blockIdx.y * BY + threadIdx.y;
   const int i = 1 + 2 * (blockIdx.x * BX + threadIdx.x) + ((j + p.color + 1) & 1);  // (i + j) & 1 == color
   n_relax_pt<NL>(p, i, j);
+}
+// the same colour pass with a, b, mask and S2 in the split layout: own colour and both x neighbours are contiguous runs
+template <int NL>
+__global__ void __launch_bounds__(BX *BY) k_n_relax_s(NRelaxArgs p) {
+  const int j = 1 + blockIdx.y * BY + threadIdx.y;
+  const int i = 1 + 2 * (blockIdx.x * BX + threadIdx.x) + ((j + p.color + 1) & 1);
+  const int n = p.g.nx - 1;
+  if (i >= n || j >= n) return;
+  const int pitch = p.g.pitch;
+  const size_t ls = p.g.ls, c = gidx(p.g, 1, 0, j, i), e = gidx(p.g, 1, 0, j, i + 1), w = gidx(p.g, 1, 0, j, i - 1);
+  double ew[NL], ns[NL], x[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    ew[l] = p.a[e + l * ls] + p.a[w + l * ls];
+    ns[l] = p.a[c + l * ls + pitch] + p.a[c + l * ls - pitch];
+  }
+  n_col_solve<NL>(p, c, ew, ns, x, j);
+#pragma unroll
+  for (int l = 0; l < NL; l++) p.a[c + l * ls] = x[l];
 }
 // ---- K consecutive colour half-sweeps of the vertex smoother in ONE pass (round 2), the marching scheme of kernels_march.hip in
 // the natural layout.  A colour pass of k_n_relax touches every cache line of `a` twice (it reads the other colour and writes
@@ -567,11 +599,25 @@ int launch_n_relax_tile(hipStream_t st, const double *a_in, double *a_out, const
   return ns;
 }
 void launch_n_relax(hipStream_t st, double *a, const double *b, const double *mk, const double *S2, const NatGeom &g, int nl, int color, double D,
-                    double iRd2, const LayerCoef &lc) {
+                    double iRd2, const LayerCoef &lc, int sp, const double *S2row) {
   NRelaxArgs p;
-  p.a = a; p.b = b; p.mk = mk; p.S2 = S2; p.g = g; p.color = color; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc;
+  p.a = a; p.b = b; p.mk = mk; p.S2 = S2; p.g = g; p.color = color; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc; p.S2row = S2row;
   const int n = g.nx - 1;
   dim3 gr = grid2d((n + 1) / 2, n - 1);
+  if (sp) {
+    switch (nl) {
+      case 1: hipLaunchKernelGGL(k_n_relax_s<1>, gr, block2d(), 0, st, p); break;
+      case 2: hipLaunchKernelGGL(k_n_relax_s<2>, gr, block2d(), 0, st, p); break;
+      case 3: hipLaunchKernelGGL(k_n_relax_s<3>, gr, block2d(), 0, st, p); break;
+      case 4: hipLaunchKernelGGL(k_n_relax_s<4>, gr, block2d(), 0, st, p); break;
+      case 5: hipLaunchKernelGGL(k_n_relax_s<5>, gr, block2d(), 0, st, p); break;
+      case 6: hipLaunchKernelGGL(k_n_relax_s<6>, gr, block2d(), 0, st, p); break;
+      case 7: hipLaunchKernelGGL(k_n_relax_s<7>, gr, block2d(), 0, st, p); break;
+      case 8: hipLaunchKernelGGL(k_n_relax_s<8>, gr, block2d(), 0, st, p); break;
+      default: break;
+    }
+    return;
+  }
   switch (nl) {
     case 1: hipLaunchKernelGGL(k_n_relax<1>, gr, block2d(), 0, st, p); break;
     case 2: hipLaunchKernelGGL(k_n_relax<2>, gr, block2d(), 0, st, p); break;
@@ -588,8 +634,9 @@ void launch_n_relax(hipStream_t st, double *a, const double *b, const double *mk
 struct NResArgs {
   const double *a, *b, *mk, *S2;
   double *res, *maxres;
-  NatGeom g;
-  int nl;
+  NatGeom g, gr;  // gr, sp: geometry and layout of res
+  const double *S2row;  // S2 independent of x: [l * g.ny + j], else null
+  int nl, sp;
   double sqD, iRd2;
   LayerCoef lc;
 };
@@ -606,13 +653,15 @@ __global__ void k_n_residual(NResArgs p) {
       const size_t c = c0 + l * ls;
       const double a1 = p.a[c];
       double r;
+      const double s2m = (nl > 1 && l > 0) ? (p.S2row ? p.S2row[(l - 1) * p.g.ny + j] : p.S2[c - ls]) : 0.;
+      const double s2c = (nl > 1 && l < nl - 1) ? (p.S2row ? p.S2row[l * p.g.ny + j] : p.S2[c]) : 0.;
       if (nl == 1) r = (p.b[c] - (-p.iRd2 * a1)) * m;
-      else if (l == 0) r = (p.b[c] + p.S2[c] * (a1 - p.a[c + ls]) * p.lc.idh1[l]) * m;
-      else if (l < nl - 1) r = (p.b[c] + p.S2[c - ls] * (a1 - p.a[c - ls]) * p.lc.idh0[l] - p.S2[c] * (p.a[c + ls] - a1) * p.lc.idh1[l]) * m;
-      else r = (p.b[c] + p.S2[c - ls] * (a1 - p.a[c - ls]) * p.lc.idh0[l]) * m;
+      else if (l == 0) r = (p.b[c] + s2c * (a1 - p.a[c + ls]) * p.lc.idh1[l]) * m;
+      else if (l < nl - 1) r = (p.b[c] + s2m * (a1 - p.a[c - ls]) * p.lc.idh0[l] - s2c * (p.a[c + ls] - a1) * p.lc.idh1[l]) * m;
+      else r = (p.b[c] + s2m * (a1 - p.a[c - ls]) * p.lc.idh0[l]) * m;
       r -= DIVC(p.a[c - 1] - 2. * a1 + p.a[c + 1], sq, rsq) * m;
       r -= DIVC(p.a[c - pitch] - 2. * a1 + p.a[c + pitch], sq, rsq) * m;
-      p.res[c] = r;
+      p.res[p.sp ? gidx(p.gr, 1, l, j, i) : c] = r;
       mx = fmax(mx, fabs(r));
     }
   }
@@ -627,9 +676,11 @@ __global__ void k_n_residual(NResArgs p) {
   }
 }
 void launch_n_residual(hipStream_t st, const double *a, const double *b, const double *mk, const double *S2, double *res, double *maxres,
-                       const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc) {
+                       const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc, const NatGeom *gres, const double *S2row) {
   NResArgs p;
+  p.S2row = S2row;
   p.a = a; p.b = b; p.mk = mk; p.S2 = S2; p.res = res; p.maxres = maxres; p.g = g; p.nl = nl; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc;
+  p.sp = gres != nullptr; p.gr = gres ? *gres : g;
   hipLaunchKernelGGL(k_n_residual, grid_capped(g.nx, g.ny), block2d(), 0, st, p);
 }
 // restriction_coarsen_vert (residual), restriction_coarsen_vert2 (mask), restriction_vert (injection), my_vertex.h:49-75
@@ -649,7 +700,22 @@ __global__ void k_n_restrict(const double *__restrict__ f, NatGeom fg, double *c
   VTX(cg, I, J);
   n_restrict_pt(f, fg, c, cg, nl, kind, I, J);
 }
-void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind) {
+// residual restriction (kind 0) with either side in the split layout: the five fine vertices of a coarse one are unit-stride
+// runs of the even half (2I) and of the odd half (2I +- 1)
+__global__ void k_n_restrict_s(const double *__restrict__ f, NatGeom fg, int fsp, double *c, NatGeom cg, int csp, int nl) {
+  VTX(cg, I, J);
+  for (int l = 0; l < nl; l++) {
+    const double v = (f[gidx(fg, fsp, l, 2 * J, 2 * I + 1)] + 2 * f[gidx(fg, fsp, l, 2 * J, 2 * I)] + f[gidx(fg, fsp, l, 2 * J, 2 * I - 1)] +
+                      f[gidx(fg, fsp, l, 2 * J + 1, 2 * I)] + f[gidx(fg, fsp, l, 2 * J - 1, 2 * I)]) / 6.;
+    c[gidx(cg, csp, l, J, I)] = v;
+  }
+}
+void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind, int fsp, int csp) {
+  if (fsp || csp) {
+    if (kind != 0) { fprintf(stderr, "msom: launch_n_restrict: split layout only for the residual\n"); abort(); }
+    hipLaunchKernelGGL(k_n_restrict_s, grid2d(cg.nx, cg.ny), block2d(), 0, st, f, fg, fsp, c, cg, csp, nl);
+    return;
+  }
   hipLaunchKernelGGL(k_n_restrict, grid2d(cg.nx, cg.ny), block2d(), 0, st, f, fg, c, cg, nl, kind);
 }
 // refine_vert my_vertex.h:82-105 followed by boundary_level(da) = 0 on the boundary vertices; one thread per FINE vertex
@@ -670,6 +736,37 @@ __device__ __forceinline__ void n_prolong_pt(const double *__restrict__ c, const
 __global__ void k_n_prolong(const double *__restrict__ c, NatGeom cg, double *f, NatGeom fg, int nl) {
   VTX(fg, i, j);
   n_prolong_pt(c, cg, f, fg, nl, i, j);
+}
+__global__ void k_n_prolong_s(const double *__restrict__ c, NatGeom cg, int csp, double *f, NatGeom fg, int fsp, int nl) {
+  VTX(fg, i, j);
+  const int n = fg.nx - 1, I = i >> 1, J = j >> 1;
+  const bool bnd = i == 0 || j == 0 || i == n || j == n;
+  for (int l = 0; l < nl; l++) {
+    double v;
+    if (bnd) v = 0.;
+    else if (!(i & 1) && !(j & 1)) v = c[gidx(cg, csp, l, J, I)];
+    else if ((i & 1) && !(j & 1)) v = (c[gidx(cg, csp, l, J, I)] + c[gidx(cg, csp, l, J, I + 1)]) / 2.;
+    else if (!(i & 1)) v = (c[gidx(cg, csp, l, J, I)] + c[gidx(cg, csp, l, J + 1, I)]) / 2.;
+    else v = (c[gidx(cg, csp, l, J, I)] + c[gidx(cg, csp, l, J, I + 1)] + c[gidx(cg, csp, l, J + 1, I)] + c[gidx(cg, csp, l, J + 1, I + 1)]) / 4.;
+    f[gidx(fg, fsp, l, j, i)] = v;
+  }
+}
+// natural <-> split copy of a level array (mask / S2 copies of the wide levels, the parity tests' upload / download)
+__global__ void k_n_relayout(const double *__restrict__ src, NatGeom sg, int ssp, double *dst, NatGeom dg, int dsp, int nl) {
+  VTX(dg, i, j);
+  for (int l = 0; l < nl; l++) dst[gidx(dg, dsp, l, j, i)] = src[gidx(sg, ssp, l, j, i)];
+}
+// out[l * ny + j] = f(l, j, i = 1): the row table of a field that does not depend on x
+__global__ void k_n_row_table(const double *__restrict__ f, NatGeom g, int nl, double *out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nl * g.ny) return;
+  out[t] = f[nat_idx(g, t / g.ny, t % g.ny, 1)];
+}
+void launch_n_row_table(hipStream_t st, const double *f, const NatGeom &g, int nl, double *out) {
+  hipLaunchKernelGGL(k_n_row_table, dim3((nl * g.ny + 255) / 256), dim3(256), 0, st, f, g, nl, out);
+}
+void launch_n_relayout(hipStream_t st, const double *src, const NatGeom &sg, int ssp, double *dst, const NatGeom &dg, int dsp, int nl) {
+  hipLaunchKernelGGL(k_n_relayout, grid2d(dg.nx, dg.ny), block2d(), 0, st, src, sg, ssp, dst, dg, dsp, nl);
 }
 
 // ---- the coarse levels of one vpoisson cycle in ONE launch (one workgroup, __syncthreads() where the separate launches had
@@ -732,19 +829,20 @@ void launch_n_mg_coarse(hipStream_t st, const NCoarseArgs &a, int nrelax, int nl
     default: break;
   }
 }
-void launch_n_prolong(hipStream_t st, const double *c, const NatGeom &cg, double *f, const NatGeom &fg, int nl) {
-  hipLaunchKernelGGL(k_n_prolong, grid2d(fg.nx, fg.ny), block2d(), 0, st, c, cg, f, fg, nl);
+void launch_n_prolong(hipStream_t st, const double *c, const NatGeom &cg, double *f, const NatGeom &fg, int nl, int csp, int fsp) {
+  if (csp || fsp) hipLaunchKernelGGL(k_n_prolong_s, grid2d(fg.nx, fg.ny), block2d(), 0, st, c, cg, csp, f, fg, fsp, nl);
+  else hipLaunchKernelGGL(k_n_prolong, grid2d(fg.nx, fg.ny), block2d(), 0, st, c, cg, f, fg, nl);
 }
 // a += da, then boundary(a): psi_bc on the boundary vertices (nodal-poisson.h:119-128)
-__global__ void k_n_correct(double *a, const double *__restrict__ da, NatGeom g, int nl, double bcv) {
+__global__ void k_n_correct(double *a, const double *__restrict__ da, NatGeom g, NatGeom gd, int sp, int nl, double bcv) {
   VTX(g, i, j);
   const int n = g.nx - 1;
   const bool bnd = i == 0 || j == 0 || i == n || j == n;
-  size_t k = nat_idx(g, 0, j, i);
-  for (int l = 0; l < nl; l++, k += g.ls) a[k] = bnd ? bcv : a[k] + da[k];
+  size_t k = nat_idx(g, 0, j, i), kd = gidx(gd, sp, 0, j, i);
+  for (int l = 0; l < nl; l++, k += g.ls, kd += gd.ls) a[k] = bnd ? bcv : a[k] + da[kd];
 }
-void launch_n_correct(hipStream_t st, double *a, const double *da, const NatGeom &g, int nl, double bcv) {
-  hipLaunchKernelGGL(k_n_correct, grid2d(g.nx, g.ny), block2d(), 0, st, a, da, g, nl, bcv);
+void launch_n_correct(hipStream_t st, double *a, const double *da, const NatGeom &g, int nl, double bcv, const NatGeom *gda) {
+  hipLaunchKernelGGL(k_n_correct, grid2d(g.nx, g.ny), block2d(), 0, st, a, da, g, gda ? *gda : g, gda != nullptr, nl, bcv);
 }
 // adjust_dt qg-node/qg.h:258-284: max |psi[0,1] - psi[]| / D and |psi[1,0] - psi[]| / D over faces and layers
 __global__ void k_n_umax(const double *__restrict__ psi, double *out, NatGeom g, int nl, double D) {

@@ -32,6 +32,12 @@ struct NLevel {
   NatGeom g;
   double *da, *res, *mask, *S2;  // level 0: mask and S2 alias the model fields
   double *da2;                   // second correction buffer (the tiled smoother works out of place)
+  // wide levels (option node_split): da and res in the x-parity split layout of geometry ga, with split copies of mask and S2
+  int sp = 0;
+  NatGeom ga;                    // geometry of da / res: g, or the split geometry
+  double *mask_s = nullptr, *S2_s = nullptr;
+  double *S2row_buf = nullptr;   // allocation behind S2row
+  double *S2row = nullptr;       // [nlm][n + 1] when S2 does not depend on x (and the option s2_rows is on), else null
 };
 enum { NSC_RES = 0, NSC_UMAX = 1, NSC_KE = 2, NSC_DIAG = 3 /* 3 slots */, NSC_COUNT = 8 };
 
@@ -58,6 +64,9 @@ struct msomn {
                         // software-prefetched one step ahead).  Measured at 2049^2 x 3: 27.1 vs 26.6 ms per step, 513^2 x 3: 4.2 vs 3.1 --
                         // half the bytes, but in the natural layout half of the lanes idle in every half-sweep and the vertex column
                         // solve (vertex-dependent coefficients, one reciprocal per layer) is arithmetic-bound: off
+  int s2_xuniform = 0;   // set_const: S2 does not depend on x
+  int s2_rows = 1;       // option: use row tables of S2 in the smoother and the residual when S2 does not depend on x
+  int node_split = 65;   // option: levels of >= node_split vertices per side keep da / res / mask / S2 copies in the x-parity split layout (0: off)
   int tiled_relax = 0;  // option: LDS-tiled smoother passes (1-2 sweeps per pass) on the wide levels; measured 3 % faster at 4097^2 x 3, 7 % slower at 2049^2 x 3
   NatGeom g;
   double *f[MSOMN_NFIELDS] = {nullptr};
@@ -77,6 +86,16 @@ static NatGeom node_geom(int n) {
   NatGeom g;
   g.nx = g.ny = n + 1;
   g.pitch = ((n + 1 + 15) / 16) * 16 + 2 * MSOM_XP;
+  g.rows = n + 1 + 2 * MSOM_YP;
+  g.ls = (size_t)g.pitch * g.rows;
+  return g;
+}
+// x-parity split rows [even-i half | odd-i half]: n / 2 + 1 and n / 2 vertices, one pad slot at least after each half
+static NatGeom node_geom_split(int n) {
+  NatGeom g;
+  g.nx = g.ny = n + 1;
+  const int hp = ((n / 2 + 2 + 15) / 16) * 16;
+  g.pitch = 2 * hp + 2 * MSOM_XP;
   g.rows = n + 1 + 2 * MSOM_YP;
   g.ls = (size_t)g.pitch * g.rows;
   return g;
@@ -116,6 +135,9 @@ extern "C" void msomn_destroy(msomn_t *m) {
     if (m->lev[k].da) (void)hipFree(m->lev[k].da);
     if (m->lev[k].da2) (void)hipFree(m->lev[k].da2);
     if (m->lev[k].res) (void)hipFree(m->lev[k].res);
+    if (m->lev[k].mask_s) (void)hipFree(m->lev[k].mask_s);
+    if (m->lev[k].S2_s) (void)hipFree(m->lev[k].S2_s);
+    if (m->lev[k].S2row_buf) (void)hipFree(m->lev[k].S2row_buf);
     if (k > 0 && m->lev[k].mask) (void)hipFree(m->lev[k].mask);
     if (k > 0 && m->lev[k].S2) (void)hipFree(m->lev[k].S2);
   }
@@ -151,8 +173,11 @@ static int node_alloc(msomn *m) {
     L.D = m->p.L0 / L.n;
     L.g = node_geom(L.n);
     L.da = L.da2 = L.res = L.mask = L.S2 = nullptr;
+    L.ga = L.g;
     int r;
-    if ((r = dalloc(&L.da, L.g.ls * m->nl)) || (r = dalloc(&L.da2, L.g.ls * m->nl)) || (r = dalloc(&L.res, L.g.ls * m->nl))) return r;
+    // da and res are sized for either layout (the layout is chosen in build_levels from the option node_split)
+    const size_t lsa = std::max(L.g.ls, node_geom_split(L.n).ls);
+    if ((r = dalloc(&L.da, lsa * m->nl)) || (r = dalloc(&L.da2, L.g.ls * m->nl)) || (r = dalloc(&L.res, lsa * m->nl))) return r;
     if (k == 0) { L.mask = m->f[MSOMN_MASK]; L.S2 = m->f[MSOMN_S2]; }
     else if ((r = dalloc(&L.mask, L.g.ls)) || (r = dalloc(&L.S2, L.g.ls * m->nlm))) return r;
   }
@@ -228,6 +253,7 @@ extern "C" msomn_t *msomn_create(const char *path) {
   return node_create(p, text.c_str());
 }
 
+static int choose_layouts(msomn *m);
 extern "C" int msomn_set_option(msomn_t *m, const char *key, double v) {
   if (!m || !key) return MSOM_ERR_ARG;
   if (!strcmp(key, "TOLERANCE")) m->tolerance = v;
@@ -236,9 +262,11 @@ extern "C" int msomn_set_option(msomn_t *m, const char *key, double v) {
   else if (!strcmp(key, "DT")) m->p.DT = v;
   else if (!strcmp(key, "quiet")) m->quiet = (int)v;
   else if (!strcmp(key, "tiled_relax")) m->tiled_relax = (int)v;
+  else if (!strcmp(key, "s2_rows")) { m->s2_rows = (int)v; if (m->const_set) return choose_layouts(m); }
+  else if (!strcmp(key, "node_split")) { m->node_split = (int)v; if (m->const_set) return choose_layouts(m); }
   else if (!strcmp(key, "node_march")) m->node_march = (int)v;
   else if (!strcmp(key, "node_march_rows")) { extern int g_node_march_rows; g_node_march_rows = (int)v; }
-  else if (!strcmp(key, "mg_coarse")) m->mg_coarse = (int)v;
+  else if (!strcmp(key, "mg_coarse")) { m->mg_coarse = (int)v; if (m->const_set) return choose_layouts(m); }
   else if (!strcmp(key, "stochastic")) m->stochastic = (int)v;
   else if (!strcmp(key, "seed")) srand((unsigned)v);
   else { msom_set_error("unknown option %s", key); return MSOM_ERR_ARG; }
@@ -256,6 +284,8 @@ extern "C" double msomn_get_param(msomn_t *m, const char *k) {
   if (!strcmp(k, "iRd2_low")) return m->iRd2_low;
   if (!strcmp(k, "bc_fac")) return m->p.bc_fac;
   if (!strcmp(k, "sqg")) return m->sqg;
+  if (!strcmp(k, "s2_xuniform")) return m->s2_xuniform;
+  if (!strncmp(k, "split_", 6)) { int l = atoi(k + 6); return l >= 0 && l < m->nlev ? m->lev[l].sp : NAN; }
   if (!strncmp(k, "idh0_", 5)) { int l = atoi(k + 5); return l >= 0 && l < MSOM_MAXNL ? m->lc.idh0[l] : NAN; }
   if (!strncmp(k, "idh1_", 5)) { int l = atoi(k + 5); return l >= 0 && l < MSOM_MAXNL ? m->lc.idh1[l] : NAN; }
   return NAN;
@@ -340,12 +370,19 @@ static int rhs_pv(msomn *m, double *q, double *dq) {
 // ---- nodal multigrid
 static void relax_level(msomn *m, int k, double *da, const double *res) {
   NLevel &L = m->lev[k];
-  for (int c = 0; c < 2; c++) launch_n_relax(m->st, da, res, L.mask, L.S2, L.g, m->nl, c, L.D, m->iRd2_low, m->lc);
+  for (int c = 0; c < 2; c++) {
+    if (L.sp) launch_n_relax(m->st, da, res, L.mask_s, L.S2_s, L.ga, m->nl, c, L.D, m->iRd2_low, m->lc, 1, L.S2row);
+    else launch_n_relax(m->st, da, res, L.mask, L.S2, L.g, m->nl, c, L.D, m->iRd2_low, m->lc, 0, L.S2row);
+  }
 }
 // nsweeps red-black sweeps of level k on L.da.  Wide levels: LDS-tiled passes of 2 (or 1) sweeps, out of place
 // (L.da <-> L.da2 swap, L.da always the current one); narrow levels: one launch per colour.
 static void relax_sweeps(msomn *m, int k, int nsweeps) {
   NLevel &L = m->lev[k];
+  if (L.sp) {  // split layout: a colour pass already moves only the bytes it uses
+    for (int s = 0; s < nsweeps; s++) relax_level(m, k, L.da, L.res);
+    return;
+  }
   if (m->node_march && L.n + 1 >= m->node_march && L.n + 1 >= 64) {
     // 2 nsweeps colour half-sweeps (red, black, red, ...) in passes of up to 4, ping-ponging between the two correction buffers
     int nh = 2 * nsweeps, c = 0;
@@ -369,6 +406,32 @@ static void relax_sweeps(msomn *m, int k, int nsweeps) {
     std::swap(L.da, L.da2);
   }
 }
+// layout of the correction / residual of every level (option node_split; da and res hold nothing between cycles, so the choice
+// may change at any time); the levels one workgroup handles (mg_coarse) stay natural
+static int choose_layouts(msomn *m) {
+  for (int k = 0; k < m->nlev; k++) {   // row tables of an x-independent S2 (levels: injection keeps it x-independent)
+    NLevel &L = m->lev[k];
+    L.S2row = nullptr;
+    if (m->nl > 1 && m->s2_xuniform && m->s2_rows) {
+      int r;
+      if (!L.S2row_buf && (r = dalloc(&L.S2row_buf, (size_t)m->nlm * (L.n + 1)))) return r;
+      launch_n_row_table(m->st, L.S2, L.g, m->nlm, L.S2row_buf);
+      L.S2row = L.S2row_buf;
+    }
+  }
+  for (int k = 0; k < m->nlev; k++) {
+    NLevel &L = m->lev[k];
+    L.sp = m->node_split > 0 && L.n + 1 >= m->node_split && L.n >= 64 && L.n > m->mg_coarse;
+    L.ga = L.sp ? node_geom_split(L.n) : L.g;
+    if (!L.sp) continue;
+    int r;
+    if (!L.mask_s && ((r = dalloc(&L.mask_s, L.ga.ls)) || (m->nl > 1 && (r = dalloc(&L.S2_s, L.ga.ls * m->nlm))))) return r;
+    launch_n_relayout(m->st, L.mask, L.g, 0, L.mask_s, L.ga, 1, 1);
+    if (m->nl > 1) launch_n_relayout(m->st, L.S2, L.g, 0, L.S2_s, L.ga, 1, m->nlm);
+  }
+  HIPCHK(hipGetLastError());
+  return MSOM_OK;
+}
 static int build_levels(msomn *m) {
   launch_n_bnd_const(m->st, m->f[MSOMN_MASK], m->g, 1, 0.);
   for (int k = 1; k < m->nlev; k++) {
@@ -376,8 +439,20 @@ static int build_levels(msomn *m) {
     launch_n_bnd_const(m->st, m->lev[k].mask, m->lev[k].g, 1, 0.);
     if (m->nl > 1) launch_n_restrict(m->st, m->lev[k - 1].S2, m->lev[k - 1].g, m->lev[k].S2, m->lev[k].g, m->nlm, 2);
   }
-  HIPCHK(hipGetLastError());
+  return choose_layouts(m);
+}
+// host array <-> a level's da / res in whatever layout the level uses (parity tests); da2 is the natural staging buffer
+static int upload_lev(msomn *m, NLevel &L, double *dst, const double *a) {
+  if (!L.sp) return upload_g(m, dst, L.g, m->nl, a);
+  int r = upload_g(m, L.da2, L.g, m->nl, a);
+  if (r) return r;
+  launch_n_relayout(m->st, L.da2, L.g, 0, dst, L.ga, 1, m->nl);
   return MSOM_OK;
+}
+static int download_lev(msomn *m, NLevel &L, const double *src, double *a) {
+  if (!L.sp) return download_g(m, src, L.g, m->nl, a);
+  launch_n_relayout(m->st, src, L.ga, 1, L.da2, L.g, 0, m->nl);
+  return download_g(m, L.da2, L.g, m->nl, a);
 }
 // vpoisson, nodal-poisson.h:19-143: residual first, then (unless converged) one cycle
 static int vpoisson(msomn *m, double *a, const double *b) {
@@ -386,14 +461,15 @@ static int vpoisson(msomn *m, double *a, const double *b) {
   const int nl = m->nl, nlev = m->nlev;
   for (mg.i = 0; mg.i < m->nitermax; mg.i++) {
     HIPCHK(hipMemsetAsync(m->d_scal + NSC_RES, 0, sizeof(double), m->st));
-    launch_n_residual(m->st, a, b, m->lev[0].mask, m->lev[0].S2, m->lev[0].res, m->d_scal + NSC_RES, m->g, nl, m->D, m->iRd2_low, m->lc);
+    launch_n_residual(m->st, a, b, m->lev[0].mask, m->lev[0].S2, m->lev[0].res, m->d_scal + NSC_RES, m->g, nl, m->D, m->iRd2_low, m->lc,
+                      m->lev[0].sp ? &m->lev[0].ga : nullptr, m->lev[0].S2row);
     double max;
     int r = read_scalar(m, NSC_RES, &max);
     if (r) return r;
     mg.resa = max;
     if (mg.i == 0) mg.resb = max;
     if (max < m->tolerance && mg.i >= m->nitermin) break;
-    launch_n_bnd_const(m->st, m->lev[0].res, m->g, nl, 0.);
+    launch_n_bnd_const(m->st, m->lev[0].res, m->lev[0].ga, nl, 0., m->lev[0].sp);
     // kc: first level of the group that one workgroup handles in one launch (<= 33^2 vertices, at least two levels)
     int kc = nlev;
     if (m->mg_coarse) {
@@ -402,8 +478,8 @@ static int vpoisson(msomn *m, double *a, const double *b) {
       if (nlev - k0 >= 2 && nlev - k0 <= NMGC_MAXLEV) kc = k0;
     }
     for (int k = 1; k < nlev && k <= kc; k++) {  // the boundary vertices of every level end up 0 (boundary_level)
-      launch_n_restrict(m->st, m->lev[k - 1].res, m->lev[k - 1].g, m->lev[k].res, m->lev[k].g, nl, 0);
-      launch_n_bnd_const(m->st, m->lev[k].res, m->lev[k].g, nl, 0.);
+      launch_n_restrict(m->st, m->lev[k - 1].res, m->lev[k - 1].ga, m->lev[k].res, m->lev[k].ga, nl, 0, m->lev[k - 1].sp, m->lev[k].sp);
+      launch_n_bnd_const(m->st, m->lev[k].res, m->lev[k].ga, nl, 0., m->lev[k].sp);
     }
     if (kc < nlev) {
       NCoarseArgs ca;
@@ -413,13 +489,13 @@ static int vpoisson(msomn *m, double *a, const double *b) {
         ca.lev[k - kc] = NCoarseLev{L.da, L.res, L.mask, L.S2, L.g, L.D * L.D};
       }
       launch_n_mg_coarse(m->st, ca, mg.nrelax, nl);
-      if (kc > 0) launch_n_prolong(m->st, m->lev[kc].da, m->lev[kc].g, m->lev[kc - 1].da, m->lev[kc - 1].g, nl);
+      if (kc > 0) launch_n_prolong(m->st, m->lev[kc].da, m->lev[kc].ga, m->lev[kc - 1].da, m->lev[kc - 1].ga, nl, m->lev[kc].sp, m->lev[kc - 1].sp);
     } else HIPCHK(hipMemsetAsync(m->lev[nlev - 1].da, 0, m->lev[nlev - 1].g.ls * nl * sizeof(double), m->st));
     for (int k = (kc < nlev ? kc : nlev) - 1; k >= 0; k--) {
       relax_sweeps(m, k, mg.nrelax);
-      if (k > 0) launch_n_prolong(m->st, m->lev[k].da, m->lev[k].g, m->lev[k - 1].da, m->lev[k - 1].g, nl);
+      if (k > 0) launch_n_prolong(m->st, m->lev[k].da, m->lev[k].ga, m->lev[k - 1].da, m->lev[k - 1].ga, nl, m->lev[k].sp, m->lev[k - 1].sp);
     }
-    launch_n_correct(m->st, a, m->lev[0].da, m->g, nl, m->psi_bc);
+    launch_n_correct(m->st, a, m->lev[0].da, m->g, nl, m->psi_bc, m->lev[0].sp ? &m->lev[0].ga : nullptr);
   }
   HIPCHK(hipGetLastError());
   if (mg.resa > m->tolerance && !m->quiet)
@@ -722,6 +798,9 @@ extern "C" int msomn_set_const(msomn_t *m) {
       for (size_t i = 0; i < n1; i++) { double &s = h[(l * n1 + j) * n1 + i]; s = f * f / s; }
     }
     if ((r = upload_g(m, m->f[MSOMN_S2], m->g, m->nlm, h.data()))) return r;
+    m->s2_xuniform = 1;
+    for (size_t r0 = 0; r0 < (size_t)(nl - 1) * n1 && m->s2_xuniform; r0++)
+      for (size_t i = 1; i < n1; i++) if (h[r0 * n1 + i] != h[r0 * n1]) { m->s2_xuniform = 0; break; }
     if (m->sqg) {  // :545 surface layer: f / N^2 (f, not f^2)
       std::vector<double> hs(n1 * n1);
       if ((r = download_g(m, m->f[MSOMN_S2S], m->g, 1, hs.data()))) return r;
@@ -870,11 +949,11 @@ extern "C" int msomn_dbg_relax(msomn_t *m, int k, double *da, const double *res,
   NEED_NCONST(m); NEED_LEVEL(m, k);
   NLevel &L = m->lev[k];
   int r;
-  if ((r = upload_g(m, L.da, L.g, m->nl, da)) || (r = upload_g(m, L.res, L.g, m->nl, res))) return r;
-  launch_n_bnd_const(m->st, L.da, L.g, m->nl, 0.);
+  if ((r = upload_lev(m, L, L.da, da)) || (r = upload_lev(m, L, L.res, res))) return r;
+  launch_n_bnd_const(m->st, L.da, L.ga, m->nl, 0., L.sp);
   relax_sweeps(m, k, nsweeps);
   HIPCHK(hipGetLastError());
-  return download_g(m, L.da, L.g, m->nl, da);
+  return download_lev(m, L, L.da, da);
 }
 extern "C" int msomn_dbg_residual(msomn_t *m, const double *a, const double *b, double *res, double *maxres) {
   NEED_NCONST(m);
@@ -882,28 +961,30 @@ extern "C" int msomn_dbg_residual(msomn_t *m, const double *a, const double *b, 
   if ((r = upload_g(m, m->f[MSOMN_TMP], m->g, m->nl, a)) || (r = upload_g(m, m->f[MSOMN_DQ], m->g, m->nl, b))) return r;
   HIPCHK(hipMemsetAsync(m->d_scal + NSC_RES, 0, sizeof(double), m->st));
   launch_n_residual(m->st, m->f[MSOMN_TMP], m->f[MSOMN_DQ], m->lev[0].mask, m->lev[0].S2, m->lev[0].res, m->d_scal + NSC_RES, m->g, m->nl, m->D, m->iRd2_low,
-                    m->lc);
+                    m->lc, m->lev[0].sp ? &m->lev[0].ga : nullptr, m->lev[0].S2row);
   double mx;
   if ((r = read_scalar(m, NSC_RES, &mx))) return r;
   if (maxres) *maxres = mx;
-  return download_g(m, m->lev[0].res, m->g, m->nl, res);
+  return download_lev(m, m->lev[0], m->lev[0].res, res);
 }
 extern "C" int msomn_dbg_restrict(msomn_t *m, int k, const double *fine, double *coarse) {
   NEED_NCONST(m); NEED_LEVEL(m, k); NEED_LEVEL(m, k + 1);
   int r;
-  if ((r = upload_g(m, m->lev[k].res, m->lev[k].g, m->nl, fine))) return r;
-  launch_n_bnd_const(m->st, m->lev[k].res, m->lev[k].g, m->nl, 0.);
-  launch_n_restrict(m->st, m->lev[k].res, m->lev[k].g, m->lev[k + 1].res, m->lev[k + 1].g, m->nl, 0);
-  launch_n_bnd_const(m->st, m->lev[k + 1].res, m->lev[k + 1].g, m->nl, 0.);
-  return download_g(m, m->lev[k + 1].res, m->lev[k + 1].g, m->nl, coarse);
+  NLevel &Lf = m->lev[k], &Lc = m->lev[k + 1];
+  if ((r = upload_lev(m, Lf, Lf.res, fine))) return r;
+  launch_n_bnd_const(m->st, Lf.res, Lf.ga, m->nl, 0., Lf.sp);
+  launch_n_restrict(m->st, Lf.res, Lf.ga, Lc.res, Lc.ga, m->nl, 0, Lf.sp, Lc.sp);
+  launch_n_bnd_const(m->st, Lc.res, Lc.ga, m->nl, 0., Lc.sp);
+  return download_lev(m, Lc, Lc.res, coarse);
 }
 extern "C" int msomn_dbg_prolong(msomn_t *m, int k, const double *coarse, double *fine) {
   NEED_NCONST(m); NEED_LEVEL(m, k); NEED_LEVEL(m, k - 1);
   int r;
-  if ((r = upload_g(m, m->lev[k].da, m->lev[k].g, m->nl, coarse))) return r;
-  launch_n_bnd_const(m->st, m->lev[k].da, m->lev[k].g, m->nl, 0.);
-  launch_n_prolong(m->st, m->lev[k].da, m->lev[k].g, m->lev[k - 1].da, m->lev[k - 1].g, m->nl);
-  return download_g(m, m->lev[k - 1].da, m->lev[k - 1].g, m->nl, fine);
+  NLevel &Lc = m->lev[k], &Lf = m->lev[k - 1];
+  if ((r = upload_lev(m, Lc, Lc.da, coarse))) return r;
+  launch_n_bnd_const(m->st, Lc.da, Lc.ga, m->nl, 0., Lc.sp);
+  launch_n_prolong(m->st, Lc.da, Lc.ga, Lf.da, Lf.ga, m->nl, Lc.sp, Lf.sp);
+  return download_lev(m, Lf, Lf.da, fine);
 }
 extern "C" int msomn_dbg_level_mask(msomn_t *m, int k, double *out) {
   NEED_NCONST(m); NEED_LEVEL(m, k);

@@ -27,7 +27,7 @@ def topo_field(N):
     return 0.05 * np.outer(np.cos(2 * np.pi * x), np.sin(np.pi * x))[None]
 
 
-def make_pair(N, nl, strict, bc_fac=0.0, nu4=0.0, mask=False, topo=False, pg=False, extra="", **opts):
+def make_pair(N, nl, strict, bc_fac=0.0, nu4=0.0, mask=False, topo=False, pg=False, extra="", s2x=False, **opts):
     par = orn.node_params(N, nl, bc_fac=bc_fac, nu4=nu4, extra=extra)
     o = orn.NodeOracle(par, smoother=orn.GS_RB, quiet=1, **opts)
     g = NodeQG(par, strict=strict)
@@ -45,6 +45,10 @@ def make_pair(N, nl, strict, bc_fac=0.0, nu4=0.0, mask=False, topo=False, pg=Fal
     if pg and nl > 1:
         pgf = 0.3 * orn.node_psi(nl, N)[::-1].copy()
         o.set(orn.PSIPG, pgf); g.set("PSIPG", pgf)
+    if s2x and nl > 1:      # N2 that varies in x (the reference's is one number per interface): no row tables
+        n2 = o.get(orn.S2)
+        n2 *= 1.0 + 0.3 * np.cos(np.linspace(0, 5, N + 1))[None, None, :]
+        o.set(orn.S2, n2); g.set("S2", n2)
     o.set(orn.PSI, psi); g.set("PSI", psi)
     o.set_const(); g.set_const()
     return o, g
@@ -106,6 +110,7 @@ def test_tiled_smoother_passes(nl, N, strict):
     if nl not in orn.NODE_LAYERS:
         orn.NODE_LAYERS[nl] = ("[" + ",".join(["%.3f" % (1.0 / nl)] * nl) + "]", "[" + ",".join(["%d." % (9000 - 900 * l) for l in range(nl - 1)]) + "]")
     o, g = make_pair(N, nl, strict, mask=True, extra="gp_low = 0.02\n")
+    g.set_option("node_split", 0)       # the split layout has its own colour passes
     g.set_option("tiled_relax", 1)
     rng = np.random.default_rng(11)
     for k in (0, 1):
@@ -307,6 +312,7 @@ def test_chained_half_sweep_smoother(nl, N, strict):
     if nl not in orn.NODE_LAYERS:
         orn.NODE_LAYERS[nl] = ("[" + ",".join(["%.3f" % (1.0 / nl)] * nl) + "]", "[" + ",".join(["%d." % (9000 - 900 * l) for l in range(nl - 1)]) + "]")
     o, g = make_pair(N, nl, strict, mask=True, extra="gp_low = 0.02\n")
+    g.set_option("node_split", 0)
     rng = np.random.default_rng(12)
     for k in (0, 1):
         n1 = (N >> k) + 1
@@ -320,3 +326,46 @@ def test_chained_half_sweep_smoother(nl, N, strict):
             g.set_option("node_march", 0)
             plain = g.dbg_relax(k, da, res, ns)
             assert np.array_equal(got, plain) or not strict
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nl,N,split,s2x", [(1, 128, 65, False), (3, 256, 65, False), (6, 128, 129, False), (2, 512, 129, True), (3, 64, 65, False),
+                                             (3, 128, 65, True), (4, 128, 0, True)])
+def test_split_layout_levels(nl, N, split, s2x, strict):
+    """Wide levels keep da / res / mask / S2 in the x-parity split layout (option node_split): every multigrid piece on every
+    level against the oracle, then inversion and RK2 steps against the oracle and against the natural layout (identical:
+    the layout changes no arithmetic)."""
+    if nl not in orn.NODE_LAYERS:
+        orn.NODE_LAYERS[nl] = ("[" + ",".join(["%.3f" % (1.0 / nl)] * nl) + "]", "[" + ",".join(["%d." % (9000 - 900 * l) for l in range(nl - 1)]) + "]")
+    o, g = make_pair(N, nl, strict, mask=True, bc_fac=0.5, extra="gp_low = 0.02\n", s2x=s2x)
+    assert g.param("s2_xuniform") == (0.0 if s2x or nl == 1 else 1.0)
+    g.set_option("node_split", split)
+    rng = np.random.default_rng(21)
+    for k in range(g.nlevels):
+        n1 = (N >> k) + 1
+        da, res = rng.standard_normal((nl, n1, n1)), rng.standard_normal((nl, n1, n1))
+        same(g.dbg_relax(k, da, res, 2), o.relax(k, da, res, 2), strict, 1e-11)
+        if k + 1 < g.nlevels:
+            same(g.dbg_restrict(k, res), o.restrict(k, res), strict, 1e-13)
+        if k > 0:
+            same(g.dbg_prolong(k, da), o.prolong(k, da), strict, 1e-13)
+    a, b = rng.standard_normal((nl, N + 1, N + 1)), rng.standard_normal((nl, N + 1, N + 1))
+    rg, mg = g.dbg_residual(a, b)
+    ro, mo = o.residual(a, b)
+    same(rg, ro, strict, 1e-12)
+    assert mg == np.abs(rg).max()
+    o.set_tnext(float("inf")); g.set_tnext(float("inf"))
+    for _ in range(3):
+        o.step(True); g.step(True)
+    for name, idx in FIELDS:
+        same(g.get(name), o.get(idx), strict, 1e-6)
+    # natural layout from the same start: the same numbers in both builds
+    o2, g2 = make_pair(N, nl, strict, mask=True, bc_fac=0.5, extra="gp_low = 0.02\n", s2x=s2x)
+    g2.set_option("node_split", 0)
+    g2.set_option("s2_rows", 0)
+    g2.set_tnext(float("inf"))
+    for _ in range(3):
+        g2.step(True)
+    for name, _ in FIELDS:
+        assert np.array_equal(g2.get(name), g.get(name))
+    assert (g2.mgstats().i, g2.mgstats().resa) == (g.mgstats().i, g.mgstats().resa)

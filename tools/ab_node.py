@@ -1,4 +1,4 @@
-"""vertex variant: step time with option toggles (same process, same GPU)"""
+"""vertex variant: step time with option toggles (same process, same GPU).  Usage: python tools/ab_node.py [N [option [values ...]]]"""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, orn
@@ -13,7 +13,9 @@ def run(n=6):
     t0 = time.perf_counter()
     for _ in range(n): g.step(True)
     return (time.perf_counter() - t0) / n * 1e3
+key = sys.argv[2] if len(sys.argv) > 2 else "node_split"
+vals = [float(v) for v in sys.argv[3:]] or [0, 129, 65]
 for rep in range(2):
-    for opt in (1, 0):
-        g.set_option("tiled_relax", opt); run(1)
-        print(f"tiled_relax={opt}  {run():8.3f} ms/step  cycles {g.mgstats().i}", flush=True)
+    for opt in vals:
+        g.set_option(key, opt); run(1)
+        print(f"{key}={opt:g}  {run():8.3f} ms/step  cycles {g.mgstats().i}", flush=True)
