@@ -2072,7 +2072,6 @@ static int de_terms(msom *m, double dt, double ediag) {
 }
 extern "C" int msom_energy_tend(msom_t *m, double dt) {
   NEED_CONST(m);
-  if (m->nranks > 1) { msom_set_error("energy diagnostics need a single-tile grid"); return MSOM_ERR_STATE; }
   int r;
   if ((r = ensure_de_fields(m))) return r;
   comp_del2(m, MSOM_PSI, MSOM_ZETA, 0., 1.0);
@@ -2349,10 +2348,6 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
   // tiled runs (one process / thread per tile): every call below that moves field data is collective; rank 0 alone
   // creates the directory, prints and writes (the reference's pid() == 0 branches, msqg/qg.h:766-780)
   const bool root = m->rank == 0;
-  if (m->nranks > 1 && p.ediag > -1) {
-    msom_set_error("msom_run: the energy budgets need a single-tile grid");
-    return MSOM_ERR_STATE;
-  }
   char dpath[600] = "", name[700];
   const char *wd = workdir ? workdir : ".";
   // create_outdir, msqg/qg.h:766-776
@@ -2409,13 +2404,14 @@ extern "C" int msom_run(msom_t *m, const char *workdir, long nsteps_max) {
       }
       if (p.ediag > -1) {  // msqg/qg.c:139-160: budgets scaled by 1/dtout, written, reset
         const char *tags[6] = {"de_bf", "de_vd", "de_j1", "de_j2", "de_j3", "de_ft"};
-        std::vector<double> h((size_t)m->nl * m->nx * m->ny);
+        std::vector<double> h;
         const double idtout = 1 / p.dtout;
         for (int k = 0; k < 6; k++) {
-          if ((r = msom_get_field(m, MSOM_DE_BF + k, h.data()))) return r;
+          if ((r = gather_global(m, MSOM_DE_BF + k, h))) return r;   // collective on tiles; rank 0 writes
+          if (!root) continue;
           for (double &v : h) v *= idtout;
           snprintf(name, sizeof name, "%s%s%09d.bas", dpath, tags[k], m->iter);
-          if (msom_bas_write(name, h.data(), m->nl, m->nx, p.L0)) return MSOM_ERR_IO;
+          if (msom_bas_write(name, h.data(), m->nl, m->gnx, p.L0)) return MSOM_ERR_IO;
         }
         if ((r = msom_reset_de(m))) return r;
       }

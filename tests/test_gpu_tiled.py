@@ -112,13 +112,15 @@ def test_large_tiles_default_agglomeration(strict):
     assert np.array_equal(assemble(out, "psi", px, py), g.get(F["PSI"]))
 
 
-def test_tiled_driver_loop_writes_the_same_files(tmp_path):
+@pytest.mark.parametrize("extra", ["", "ediag = 0\nafilt = 4\ndtflt = 0.02\n"])
+def test_tiled_driver_loop_writes_the_same_files(tmp_path, extra):
     """msom_run on 2 x 2 tiles (collective gathers, rank 0 writes): po / qo .bas files, backup of the constant fields
-    and NetCDF output identical to the single-tile run; restart from the written file on the tiles"""
+    and NetCDF output identical to the single-tile run; restart from the written file on the tiles.  Second case: the
+    wavelet filter and the energy budgets in the loop (pf / de_* files, msqg/qg.c:124-160)"""
     px = py = 2
     tile, nl = 32, 3
     gn = tile * px
-    params = orc.double_gyre_params(gn, nl, extra="MGLEVELS = 5\n").replace("tend  = 500.", "tend = 0.04").replace("dtout = 1.", "dtout = 0.02")
+    params = orc.double_gyre_params(gn, nl, extra="MGLEVELS = 5\n" + extra).replace("tend  = 500.", "tend = 0.04").replace("dtout = 1.", "dtout = 0.02")
     psi = orc.synthetic_psi(nl, gn, gn)
     d1, d4 = tmp_path / "single", tmp_path / "tiled"
     d1.mkdir(); d4.mkdir()
@@ -137,6 +139,7 @@ def test_tiled_driver_loop_writes_the_same_files(tmp_path):
     out = run_tiled(params, px, py, psi, nsteps=0, strict=False, fn=run)
     names = sorted(os.listdir(d1 / "outdir_0001"))
     assert names == sorted(os.listdir(d4 / "outdir_0001")) and any(n.startswith("po") for n in names) and len(names) >= 12
+    assert not extra or (any(n.startswith("de_ft") for n in names) and any(n.startswith("pf") for n in names))
     for n in names:
         assert (d1 / "outdir_0001" / n).read_bytes() == (d4 / "outdir_0001" / n).read_bytes(), n
     assert (d1 / "vars.nc").read_bytes() == (d4 / "vars.nc").read_bytes()
@@ -469,3 +472,36 @@ def test_stochastic_steps_on_tiles(px, py, tile, nl, strict):
         g.step()
     assert np.array_equal(assemble(out, "q", px, py), g.get(F["Q"]))
     assert np.array_equal(assemble(out, "psi", px, py), g.get(F["PSI"]))
+
+
+@pytest.mark.parametrize("px,py,tile,nl,extra", [(2, 2, 32, 3, "Re = 800\nEks = 0.003\n"), (2, 1, 32, 2, ""), (1, 2, 32, 3, "sbc = -1\n")])
+@pytest.mark.parametrize("strict", [True, False])
+def test_energy_budgets_on_tiles(px, py, tile, nl, extra, strict):
+    """energy_tend / filter_de (msqg/qg_energy.h:28-242) on tiles: the budget fields of every tile equal the blocks of the
+    single-tile fields bit for bit (1-cell stencils on exchanged halos, the tiled wavelet filter for de_ft)."""
+    gnx, gny = tile * px, tile * py
+    ex = (f"Ny = {gny}\n" if gny != gnx else "") + f"MGLEVELS = {int(np.log2(tile))}\nediag = 0\nafilt = 4\ndtflt = 0.25\n" + extra
+    params = orc.double_gyre_params(gnx, nl, extra=ex)
+    psi = orc.synthetic_psi(nl, gny, gnx)
+    names = ("DE_BF", "DE_VD", "DE_J1", "DE_J2", "DE_J3", "DE_FT", "PO_MFT")
+
+    def budget_run(g, rank=None):
+        for _ in range(3):
+            g.energy_tend(0.02)
+            g.step()
+        before = {k: g.get(F[k]) for k in names}
+        g.filter_de(F["PO_MFT"], 0.25)
+        return before, {k: g.get(F[k]) for k in names}
+
+    out = run_tiled(params, px, py, psi, nsteps=0, strict=strict, fn=budget_run)
+    g = QG(params, strict=strict)
+    g.option("quiet", 1)
+    g.set(F["PSI"], psi)
+    g.set_const()
+    g.set_tnext(float("inf"))
+    ref = budget_run(g)
+    for stage in (0, 1):
+        for k in names:
+            got = np.concatenate([np.concatenate([out[iy * px + ix]["extra"][stage][k] for ix in range(px)], axis=2) for iy in range(py)], axis=1)
+            assert np.array_equal(got, ref[stage][k]), (stage, k, np.abs(got - ref[stage][k]).max())
+    assert np.abs(ref[0]["DE_J1"]).max() > 0 and np.abs(ref[1]["DE_FT"]).max() > 0

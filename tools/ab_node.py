@@ -13,6 +13,9 @@ def run(n=6):
     t0 = time.perf_counter()
     for _ in range(n): g.step(True)
     return (time.perf_counter() - t0) / n * 1e3
+import os
+for kv in filter(None, os.environ.get("EXTRA", "").split(",")):     # EXTRA=tiled_relax=1,node_march=0: fixed options of the run
+    g.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 key = sys.argv[2] if len(sys.argv) > 2 else "node_split"
 vals = [float(v) for v in sys.argv[3:]] or [0, 129, 65]
 for rep in range(2):
