@@ -25,7 +25,7 @@ struct RelaxCoef {
 void launch_fill_ghost(hipStream_t st, double *f, const NatGeom &g, int nl, int bc, int walls, int depth = 1);
 void launch_fill_periodic(hipStream_t st, double *f, const NatGeom &g, int nl, int depth);
 void launch_fill_lin_dirichlet(hipStream_t st, double *f, const NatGeom &g, int nl, const double *upg, const double *vpg, double D, double Lx,
-                               double Ly);
+                               double Ly, int ox = 0, int oy = 0, int sides = WALL_ALL);
 void launch_slip_bc(hipStream_t st, const double *po, double *zeta, const NatGeom &g, int nl, double c, int walls);
 void launch_pack(hipStream_t st, const double *src, double *dst, const NatGeom &g, int nl);
 void launch_unpack(hipStream_t st, const double *src, double *dst, const NatGeom &g, int nl);

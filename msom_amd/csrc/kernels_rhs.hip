@@ -126,34 +126,41 @@ void launch_fill_periodic(hipStream_t st, double *f, const NatGeom &g, int nl, i
 // faces (msqg/qg.h:1105-1114): ghost = 2 * value(face centre) - interior; corners = y-BC of
 // the x-ghost column
 struct LinBC { double u[MSOM_MAXNL], v[MSOM_MAXNL]; };
-__global__ void k_fill_lin_dirichlet(double *f, NatGeom g, int nl, LinBC b, double D, double x0, double y0, double Lx, double Ly) {
-  const int per = 2 * g.ny + 2 * (g.nx + 2);
+// Tiles (ox, oy = global index of the tile's first cell, sides = which tile edges lie on the domain boundary): the other ghosts
+// were filled by the halo exchange and act as interior values here, so that ghost cell (i, j) gets the same number on every tile
+// that holds it: an x-side ghost of the rows j = -1, ny (ghost rows of a neighbour tile, not of the domain) from the exchanged
+// value next to it, a y-side ghost of the columns i = -1, nx from the exchanged value when that x side is not a domain edge.
+__global__ void k_fill_lin_dirichlet(double *f, NatGeom g, int nl, LinBC b, double D, int ox, int oy, double Lx, double Ly, int sides) {
+  const int per = 2 * (g.ny + 2) + 2 * (g.nx + 2);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= per * nl) return;
   const int l = t / per, r = t % per;
   const double u = b.u[l], v = b.v[l];
-  if (r < 2 * g.ny) {
-    const int j = r >> 1, east = r & 1;
-    const double y = y0 + (j + 0.5) * D;
+  if (r < 2 * (g.ny + 2)) {
+    const int j = (r >> 1) - 1, east = r & 1;
+    if (!(sides & (east ? WALL_E : WALL_W))) return;
+    if ((j == -1 && (sides & WALL_S)) || (j == g.ny && (sides & WALL_N))) return;  // corner of the domain: the y rule below
+    const double y = (oy + j + 0.5) * D;
     if (east) f[nat_idx(g, l, j, g.nx)] = 2. * (v * Lx - u * y) - f[nat_idx(g, l, j, g.nx - 1)];
     else f[nat_idx(g, l, j, -1)] = 2. * (v * 0. - u * y) - f[nat_idx(g, l, j, 0)];
   } else {
-    const int q = r - 2 * g.ny, i = (q >> 1) - 1, north = q & 1;
+    const int q = r - 2 * (g.ny + 2), i = (q >> 1) - 1, north = q & 1;
+    if (!(sides & (north ? WALL_N : WALL_S))) return;
     const int jsrc = north ? g.ny - 1 : 0;
-    const double x = x0 + (i + 0.5) * D;
+    const double x = (ox + i + 0.5) * D;
     double inner;  // value of the x-extended row next to the wall
-    if (i == -1) inner = 2. * (v * 0. - u * (y0 + (jsrc + 0.5) * D)) - f[nat_idx(g, l, jsrc, 0)];
-    else if (i == g.nx) inner = 2. * (v * Lx - u * (y0 + (jsrc + 0.5) * D)) - f[nat_idx(g, l, jsrc, g.nx - 1)];
+    if (i == -1 && (sides & WALL_W)) inner = 2. * (v * 0. - u * ((oy + jsrc + 0.5) * D)) - f[nat_idx(g, l, jsrc, 0)];
+    else if (i == g.nx && (sides & WALL_E)) inner = 2. * (v * Lx - u * ((oy + jsrc + 0.5) * D)) - f[nat_idx(g, l, jsrc, g.nx - 1)];
     else inner = f[nat_idx(g, l, jsrc, i)];
     f[nat_idx(g, l, north ? g.ny : -1, i)] = 2. * (v * x - u * (north ? Ly : 0.)) - inner;
   }
 }
 void launch_fill_lin_dirichlet(hipStream_t st, double *f, const NatGeom &g, int nl, const double *upg, const double *vpg, double D, double Lx,
-                               double Ly) {
+                               double Ly, int ox, int oy, int sides) {
   LinBC b;
   for (int l = 0; l < MSOM_MAXNL; l++) { b.u[l] = l < nl ? upg[l] : 0.; b.v[l] = l < nl ? vpg[l] : 0.; }
-  const int n = (2 * g.ny + 2 * (g.nx + 2)) * nl;
-  hipLaunchKernelGGL(k_fill_lin_dirichlet, dim3((n + 255) / 256), dim3(256), 0, st, f, g, nl, b, D, 0., 0., Lx, Ly);
+  const int n = (2 * (g.ny + 2) + 2 * (g.nx + 2)) * nl;
+  hipLaunchKernelGGL(k_fill_lin_dirichlet, dim3((n + 255) / 256), dim3(256), 0, st, f, g, nl, b, D, ox, oy, Lx, Ly, sides);
 }
 
 // partial-slip override of the zeta ghosts, msqg/qg.h:185-198

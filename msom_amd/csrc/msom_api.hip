@@ -512,14 +512,6 @@ static msom *create_common(const Params &p0, int px, int py, int rank, const voi
     msom_set_error("nptr = %d outside 0..%d", p.nptr, MSOM_MAXNL);
     return nullptr;
   }
-  if (p.sbc == -1 && px * py > 1) {  // periodic(right); periodic(top) under MPI, msqg/qg.h:842-846: the tile neighbours wrap around
-    bool pg = false;
-    for (int l = 0; l < p.nl; l++) pg = pg || p.upg[l] != 0. || p.vpg[l] != 0.;
-    if (pg) {
-      msom_set_error("sbc = -1 on tiles: the large-scale flow upg / vpg (linear-Dirichlet stream function, msqg/qg.h:1105-1114) is supported on a single tile only");
-      return nullptr;
-    }
-  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
     msom_set_error("no HIP device available: libmsomhip has no CPU fallback");
@@ -743,8 +735,15 @@ static int check_field(msom *m, int field) {
 // predictor are never read (b enters the solver at cell centres only), so those fields skip
 // the exchange.
 static int fill_bc(msom *m, int field) {
-  if (m->nranks > 1 && field != MSOM_Q && field != MSOM_DQ && field != MSOM_QPRED && field != MSOM_NOISE && field != MSOM_SIGMA)
-    return exch_nat(m, m->f[field], m->flayers[field], m->fbc[field], 1);
+  if (m->nranks > 1 && field != MSOM_Q && field != MSOM_DQ && field != MSOM_QPRED && field != MSOM_NOISE && field != MSOM_SIGMA) {
+    int r = exch_nat(m, m->f[field], m->flayers[field], m->fbc[field], 1);
+    if (!r && m->fbc[field] == BC_DIRICHLET_LIN) {  // the wrapped ghosts on the domain edges give way to dirichlet(vpg x - upg y)
+      const int sides = (m->ix == 0 ? WALL_W : 0) | (m->ix == m->px - 1 ? WALL_E : 0) | (m->iy == 0 ? WALL_S : 0) | (m->iy == m->py - 1 ? WALL_N : 0);
+      launch_fill_lin_dirichlet(m->st, m->f[field], m->g, m->flayers[field], m->p.upg, m->p.vpg, m->p.L0 / m->gnx, m->p.L0,
+                                m->p.L0 * m->gny / m->gnx, m->ix * m->nx, m->iy * m->ny, sides);
+    }
+    return r;
+  }
   if (m->fbc[field] == BC_PERIODIC) launch_fill_periodic(m->st, m->f[field], m->g, m->flayers[field], 1);
   else if (m->fbc[field] == BC_DIRICHLET_LIN)
     launch_fill_lin_dirichlet(m->st, m->f[field], m->g, m->flayers[field], m->p.upg, m->p.vpg, m->p.L0 / m->gnx, m->p.L0,

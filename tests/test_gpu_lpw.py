@@ -43,7 +43,7 @@ def test_lpw_chunk_heights(rows):
     assert np.array_equal(dq, o.get(orc.DQ))
 
 
-@pytest.mark.parametrize("nx,ny,nl,extra", [(64, 64, 3, ""), (128, 64, 6, SLIP), (32, 32, 1, ""), (64, 32, 2, PER), (256, 64, 4, "Eks = 0.01\n")])
+@pytest.mark.parametrize("nx,ny,nl,extra", [(64, 64, 3, ""), (128, 64, 6, SLIP), (32, 32, 1, ""), (64, 32, 2, PER + "tau0 = 0\n"), (256, 64, 4, "Eks = 0.01\n")])
 def test_lpw_three_steps_bit_exact(nx, ny, nl, extra):
     """RK2 steps with the corrector's advance fused in the pass (q_out = q_in + dt dq)"""
     o, g = make_pair(nx, ny, nl, strict=True, extra=extra, TOLERANCE=1e-8)
