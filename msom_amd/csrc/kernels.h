@@ -91,7 +91,7 @@ void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const do
 #define MGC_MAXDIM 32
 #define MGC_NT 512
 struct CoarseLev { double *da, *res; const double *S; SplitGeom g; RelaxCoef rc; };
-struct CoarseArgs { CoarseLev lev[MGC_MAXLEV]; int n, walls, prolong_fused; };
+struct CoarseArgs { CoarseLev lev[MGC_MAXLEV]; int n, walls, prolong_fused, lds; };
 void launch_mg_coarse(hipStream_t st, const CoarseArgs *d_args, int nrelax, int nl, int uniformS);
 void launch_nat_to_split(hipStream_t st, const double *nat, const NatGeom &g, double *sp, const SplitGeom &sg, int nl);
 void launch_split_to_nat(hipStream_t st, const double *sp, const SplitGeom &sg, double *nat, const NatGeom &g, int nl);
@@ -102,7 +102,8 @@ void launch_residual(hipStream_t st, const double *a, const double *b, const dou
 int residual2_blocks(const NatGeom &g);
 void launch_residual2(hipStream_t st, int mode, const double *a, const double *da, double *a_out, const double *b, const double *S,
                       const NatGeom &g, double *res, const SplitGeom &sg, double *res_c, const SplitGeom &cg, int nl, const RelaxCoef &rc,
-                      int uniformS, int walls, double *maxres, double *sum_partial, int want_sum, double *umax_partial, double *umax_out);
+                      int uniformS, int walls, double *maxres, double *sum_partial, int want_sum, double *umax_partial, double *umax_out,
+                      int umax_clean = 0);
 void launch_restrict(hipStream_t st, const double *fine, const SplitGeom &fg, double *coarse, const SplitGeom &cg, int nl);
 void launch_prolong(hipStream_t st, const double *coarse, const SplitGeom &cg, double *fine, const SplitGeom &fg, int nl, int walls);
 void launch_relax_color(hipStream_t st, double *da, const double *res, const double *S, const SplitGeom &sg, int nl, const RelaxCoef &rc,

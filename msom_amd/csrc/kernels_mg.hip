@@ -479,7 +479,7 @@ int residual2_blocks(const NatGeom &g) {
 // mode bits: 1 = CORRECT, 2 = WRITE, 4 = RESTRICT
 void launch_residual2(hipStream_t st, int mode, const double *a, const double *da, double *a_out, const double *b, const double *S,
                       const NatGeom &g, double *res, const SplitGeom &sg, double *res_c, const SplitGeom &cg, int nl, const RelaxCoef &rc,
-                      int uniformS, int walls, double *maxres, double *sum_partial, int want_sum, double *umax_partial, double *umax_out) {
+                      int uniformS, int walls, double *maxres, double *sum_partial, int want_sum, double *umax_partial, double *umax_out, int umax_clean) {
   Res2Args p;
   extern int g_rhs_dbg;
   p.dbg = g_rhs_dbg;
@@ -495,7 +495,7 @@ void launch_residual2(hipStream_t st, int mode, const double *a, const double *d
         else hipLaunchKernelGGL((k_correct_residual<false, true>), gr, block2d(), 0, st, p);
       } else
         hipLaunchKernelGGL((k_residual2<true, false, false>), gr, block2d(), 0, st, p);
-      (void)hipMemsetAsync(umax_out, 0, nl * sizeof(double), st);
+      if (!umax_clean) (void)hipMemsetAsync(umax_out, 0, nl * sizeof(double), st);  // else zeroed with the solve's other accumulators
       hipLaunchKernelGGL(k_max_final_mg, dim3(64), dim3(256), 0, st, umax_partial, umax_out, (int)(gr.x * gr.y), nl);
       break;
     case 2: hipLaunchKernelGGL((k_residual2<false, true, false>), gr, block2d(), 0, st, p); break;
@@ -508,7 +508,7 @@ void launch_residual2(hipStream_t st, int mode, const double *a, const double *d
         else hipLaunchKernelGGL((k_correct_residual<false, false>), gr, block2d(), 0, st, p);
       } else
         hipLaunchKernelGGL((k_residual2<false, false, false, true>), gr, block2d(), 0, st, p);
-      (void)hipMemsetAsync(umax_out, 0, nl * sizeof(double), st);
+      if (!umax_clean) (void)hipMemsetAsync(umax_out, 0, nl * sizeof(double), st);  // else zeroed with the solve's other accumulators
       hipLaunchKernelGGL(k_max_final_mg, dim3(64), dim3(256), 0, st, umax_partial, umax_out, (int)(gr.x * gr.y), nl);
       break;
     default: break;
@@ -1049,23 +1049,68 @@ __global__ void __launch_bounds__(BX *BY) k_relax_red_prolong3(RelaxPArgs p) {
 // level, prolongation folded into the first red half-sweep on the way up -- with __syncthreads() where
 // the separate launches had kernel boundaries.  The per-point device functions are the ones of the
 // stand-alone kernels, so the arithmetic is identical.
+// LDS residency (round 2, lds = 1 and uniform S): a phase of a coarse level is one dependent round trip -- read the neighbours the previous
+// phase wrote, solve the column, write, barrier -- and through global memory that round trip costs ~3.5 us however small the level
+// (165 us for the 45 phases of 32^2 ... 2^2 at nl = 6).  The correction and the residual of as many levels as fit, from the coarsest
+// up, therefore live in a 150-KB LDS pool for the whole kernel, in the same x-parity split layout with one pad slot per half instead
+// of 16 (the per-point functions take (pointer, geometry) pairs: the pool pointer is shifted by MSOM_SP - 1 so that split_idx lands
+// on the compact rows).  Only the group's finest residual comes in from global memory and only its correction (ghosts included)
+// goes back.  Levels that do not fit (32^2 at nl >= 5) keep their global arrays.  Same per-point functions, same values.
+#define MGC_POOL 19200  // doubles: 150 KB
+__device__ __forceinline__ SplitGeom mgc_compact(const SplitGeom &g) {
+  SplitGeom c = g;
+  c.hp = g.hk + 2; c.rp = 2 * c.hp; c.rows = g.ny + 2; c.ls = (size_t)c.rp * c.rows;
+  return c;
+}
 template <int NL, bool UNIFORM>
 __global__ void __launch_bounds__(MGC_NT) k_mg_coarse(const CoarseArgs *pa, int nrelax) {
+  __shared__ double pool[MGC_POOL];
+  __shared__ CoarseLev slev[MGC_MAXLEV];
+  __shared__ int s_first_lds;  // levels >= s_first_lds (coarser) are LDS-resident; n: none
   const CoarseArgs &a = *pa;
   const int tid = threadIdx.x, n = a.n;
+  if (tid == 0) {
+    size_t used = MSOM_SP;  // slack: the shifted pointers stay inside the pool
+    int first = n;
+    for (int k = n - 1; k >= 0; k--) {
+      slev[k] = a.lev[k];
+      const SplitGeom cg = mgc_compact(a.lev[k].g);
+      const size_t need = 2 * cg.ls * NL;
+      if (UNIFORM && a.lds && first == k + 1 && used + need <= MGC_POOL) {
+        slev[k].g = cg;
+        slev[k].da = pool + used - (MSOM_SP - 1);
+        slev[k].res = pool + used + cg.ls * NL - (MSOM_SP - 1);
+        used += need;
+        first = k;
+      }
+    }
+    s_first_lds = first;
+  }
+  for (int t = tid; t < MGC_POOL; t += MGC_NT) pool[t] = 0.;
+  __syncthreads();
+  const int first_lds = s_first_lds;
+  if (first_lds == 0) {  // the residual of the group's finest level: global -> LDS (interior cells)
+    const CoarseLev &G = a.lev[0], &L = slev[0];
+    for (int t = tid; t < G.g.nx * G.g.ny * NL; t += MGC_NT) {
+      const int i = t % G.g.nx, j = (t / G.g.nx) % G.g.ny, l = t / (G.g.nx * G.g.ny);
+      L.res[split_idx(L.g, l, j, i)] = G.res[split_idx(G.g, l, j, i)];
+    }
+    __syncthreads();
+  }
   for (int k = 1; k < n; k++) {  // restriction of the residual, level by level
-    const CoarseLev &F = a.lev[k - 1], &C = a.lev[k];
+    const CoarseLev &F = slev[k - 1], &C = slev[k];
     for (int t = tid; t < C.g.nx * C.g.ny; t += MGC_NT) restrict_pt(F.res, F.g, C.res, C.g, NL, t % C.g.nx, t / C.g.nx);
     __syncthreads();
   }
   for (int k = n - 1; k >= 0; k--) {
-    const CoarseLev &L = a.lev[k];
+    const CoarseLev &L = slev[k];
     bool fused = false;
-    if (k == n - 1) {  // first guess 0 (ghosts included)
-      for (size_t t = tid; t < L.g.ls * NL; t += MGC_NT) L.da[t] = 0.;
+    if (k == n - 1) {  // first guess 0 (ghosts included); an LDS-resident level was zeroed with the pool
+      if (k < first_lds)
+        for (size_t t = tid; t < L.g.ls * NL; t += MGC_NT) L.da[t] = 0.;
     } else if (a.prolong_fused && nrelax >= 1 && L.g.nx >= 4 && L.g.ny >= 4) fused = true;
     else {
-      const CoarseLev &C = a.lev[k + 1];
+      const CoarseLev &C = slev[k + 1];
       for (int t = tid; t < L.g.nx * L.g.ny; t += MGC_NT) prolong_pt(C.da, C.g, L.da, L.g, NL, a.walls, t % L.g.nx, t / L.g.nx);
     }
     __syncthreads();
@@ -1073,7 +1118,7 @@ __global__ void __launch_bounds__(MGC_NT) k_mg_coarse(const CoarseArgs *pa, int 
       for (int c = 0; c < 2; c++) {
         if (fused && it == 0 && c == 0) {
           RelaxPArgs p;
-          p.da = L.da; p.res = L.res; p.S = L.S; p.coarse = a.lev[k + 1].da; p.g = L.g; p.cg = a.lev[k + 1].g; p.walls = a.walls; p.rc = L.rc;
+          p.da = L.da; p.res = L.res; p.S = L.S; p.coarse = slev[k + 1].da; p.g = L.g; p.cg = slev[k + 1].g; p.walls = a.walls; p.rc = L.rc;
           const int nj = (L.g.ny + 1) / 2;
           for (int t = tid; t < L.g.hk * nj; t += MGC_NT) red_prolong2_pt<NL, UNIFORM>(p, t % L.g.hk, t / L.g.hk);
         } else {
@@ -1083,6 +1128,14 @@ __global__ void __launch_bounds__(MGC_NT) k_mg_coarse(const CoarseArgs *pa, int 
         }
         __syncthreads();
       }
+  }
+  if (first_lds == 0) {  // the correction of the group's finest level, ghosts included: LDS -> global
+    const CoarseLev &G = a.lev[0], &L = slev[0];
+    const int w = G.g.nx + 2, h = G.g.ny + 2;
+    for (int t = tid; t < w * h * NL; t += MGC_NT) {
+      const int i = t % w - 1, j = (t / w) % h - 1, l = t / (w * h);
+      G.da[split_idx(G.g, l, j, i)] = L.da[split_idx(L.g, l, j, i)];
+    }
   }
 }
 template <int NL>

@@ -132,7 +132,8 @@ struct msom {
   // coarse levels (<= MGC_MAXDIM cells a side) solved by ONE launch (k_mg_coarse)
   CoarseArgs *d_cargs = nullptr;
   int mgc_dim = MGC_MAXDIM;  // widest level of that group
-  int mgc_first = -1, mgc_opt = 1;  // first (finest) level of the group, -1: none; option "mg_coarse"
+  int umax_clean = 0;  // the max|u| accumulators were zeroed with the solve's scalars and not used since
+  int mgc_first = -1, mgc_opt = 2;  // first (finest) level of the group, -1: none; option "mg_coarse" (1: through global memory, 2: levels resident in LDS)
   int res_ready = -1;  // field id whose first multigrid residual (levels 0, 1; SC_RESF; partial sums) the last tendency pass already produced
   int adv_fused = 1;   // fold q_out = q_in + dt dq into the tendency pass
   int rhs_resid = 0;   // let the fused tendency + advance pass produce it: measured slower (23 spilled VGPRs in the 256-VGPR kernel: 2.21 ms vs 1.63 + 0.50 ms), kept as an option
@@ -192,8 +193,14 @@ static int sync_stream(msom *m) {
     if (r__ && !(m)->sticky) (m)->sticky = r__;          \
   } while (0)
 
+// profile = 1: every slot; 2: only the chained smoother passes (the dominant kernel of the bench line) -- an event pair costs
+// ~10 us of stream time, 1.4 % of a 4096^2 x 6 step and 20 % of a 512^2 x 3 step with every slot on
+static bool prof_on(const msom *m, const ProfSlot &ps) {
+  if (m->profile == 2) return &ps == &m->prof_march_corr || (&ps >= &m->prof_march[0] && &ps <= &m->prof_march[4]);
+  return m->profile != 0;
+}
 static void prof_begin(msom *m, ProfSlot &ps) {
-  if (!m->profile) return;
+  if (!prof_on(m, ps)) return;
   if (ps.used + 2 > ps.ev.size()) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
@@ -202,7 +209,7 @@ static void prof_begin(msom *m, ProfSlot &ps) {
   hipEventRecord(ps.ev[ps.used], m->st);
 }
 static void prof_end(msom *m, ProfSlot &ps) {
-  if (!m->profile) return;
+  if (!prof_on(m, ps)) return;
   hipEventRecord(ps.ev[ps.used + 1], m->st);
   ps.used += 2;
 }
@@ -898,6 +905,7 @@ static int setup_mg_coarse(msom *m) {
   h.n = m->nlev - k0;
   h.walls = glob ? (m->bc == BC_PERIODIC ? WALL_PER : WALL_ALL) : m->walls;
   h.prolong_fused = m->prolong_fused;
+  h.lds = m->mgc_opt >= 2;
   for (int k = k0; k < m->nlev; k++) {
     CoarseLev &L = h.lev[k - k0];
     if (glob) { const int q = k - m->agg_level; L.da = m->gda[q]; L.res = m->gres[q]; L.S = nullptr; L.g = m->gsg[q]; }
@@ -1284,7 +1292,8 @@ static void residual2(msom *m, int mode, const double *b, int slot, int want_sum
   if (m->profile) { prof_begin(m, m->prof_resid); prof_begin(m, which); }
   launch_residual2(m->st, mode, m->f[MSOM_PSI], m->da[0], m->psi_alt, b, m->f[MSOM_S], m->g, m->res[0], m->sg[0],
                    m->nlev > 1 ? m->res[1] : nullptr, m->sg[m->nlev > 1 ? 1 : 0], m->nl, m->rc[0], m->uniformS, m->walls, m->d_scal + slot,
-                   m->partial, want_sum, m->partial_umax, m->d_scal + SC_UMAX);
+                   m->partial, want_sum, m->partial_umax, m->d_scal + SC_UMAX, m->umax_clean);
+  if (mode & (1 | 8)) m->umax_clean = 0;
   if (m->profile) { prof_end(m, m->prof_resid); prof_end(m, which); }
 }
 
@@ -1313,7 +1322,9 @@ static int mg_solve(msom *m, const double *b, msom_mgstats *s) {
   const Params &p = m->p;
   const bool fused = m->mg_fused && m->nlev > 1;
   s->i = 0; s->nrelax = 4;
-  HIPCHK(hipMemsetAsync(m->d_scal, 0, 8 * sizeof(double), m->st));
+  // one fill for every accumulator of the solve: sums, max|res| before / after the first cycle, max|u| per layer
+  HIPCHK(hipMemsetAsync(m->d_scal, 0, (SC_UMAX + MSOM_MAXNL) * sizeof(double), m->st));
+  m->umax_clean = 1;
   m->umax_ready = 0;
   const bool have_res = fused && m->res_ready >= 0 && b == m->f[m->res_ready];
   m->res_ready = -1;
@@ -1341,7 +1352,7 @@ static int mg_solve(msom *m, const double *b, msom_mgstats *s) {
     m->corr_done = 0;
     mg_cycle(m, s->nrelax, fused ? 2 : 1);
     m->corr_req = 0;
-    HIPCHK(hipMemsetAsync(m->d_scal + SC_RES1, 0, sizeof(double), m->st));
+    if (s->i > 0) HIPCHK(hipMemsetAsync(m->d_scal + SC_RES1, 0, sizeof(double), m->st));
     if (m->corr_done) {  // a_new = a + da already sits in psi_alt (last smoother pass): boundary(a), then max |res|, max |u|
       std::swap(m->f[MSOM_PSI], m->psi_alt);
       if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], m->nl, m->bc, 1));
