@@ -1050,93 +1050,138 @@ __global__ void __launch_bounds__(BX *BY) k_relax_red_prolong3(RelaxPArgs p) {
 // the separate launches had kernel boundaries.  The per-point device functions are the ones of the
 // stand-alone kernels, so the arithmetic is identical.
 // LDS residency (round 2, lds = 1 and uniform S): a phase of a coarse level is one dependent round trip -- read the neighbours the previous
-// phase wrote, solve the column, write, barrier -- and through global memory that round trip costs ~3.5 us however small the level
-// (165 us for the 45 phases of 32^2 ... 2^2 at nl = 6).  The correction and the residual of as many levels as fit, from the coarsest
-// up, therefore live in a 150-KB LDS pool for the whole kernel, in the same x-parity split layout with one pad slot per half instead
-// of 16 (the per-point functions take (pointer, geometry) pairs: the pool pointer is shifted by MSOM_SP - 1 so that split_idx lands
-// on the compact rows).  Only the group's finest residual comes in from global memory and only its correction (ghosts included)
-// goes back.  Levels that do not fit (32^2 at nl >= 5) keep their global arrays.  Same per-point functions, same values.
+// phase wrote, solve the column, write, barrier -- and through global memory that round trip costs 2 - 3.7 us however small the level
+// (measured with wall_clock64: 165 us for the 45 phases of 32^2 ... 2^2 at nl = 6).  The correction and the residual of the levels
+// therefore live in a 150-KB LDS pool, in the same x-parity split layout with one pad slot per half instead of 16 (the per-point
+// functions take (pointer, geometry) pairs: the pool pointer is shifted by MSOM_SP - 1 so that split_idx lands on the compact
+// rows).  The pointers are formed as pool + offset under compile-time flags, so the inlined per-point code uses ds_read / ds_write
+// (a generic pointer would go through the flat path: 1.4 us per phase instead of ~0.6 at nl = 3).
+// The group's finest level is materialised late: its residual is restricted straight from global memory on the way down and
+// copied in only when the cycle comes back up, over the residuals of the coarser levels (dead by then), which is what lets
+// 32^2 x 6 layers fit.  Only that level's correction (ghosts included) goes back to global memory.  Same per-point functions,
+// same values as the separate launches.
 #define MGC_POOL 19200  // doubles: 150 KB
 __device__ __forceinline__ SplitGeom mgc_compact(const SplitGeom &g) {
   SplitGeom c = g;
   c.hp = g.hk + 2; c.rp = 2 * c.hp; c.rows = g.ny + 2; c.ls = (size_t)c.rp * c.rows;
   return c;
 }
+struct MgcShared {
+  CoarseLev lev[MGC_MAXLEV];          // geometry compact for the LDS-resident levels
+  int da[MGC_MAXLEV], res[MGC_MAXLEV];  // pool offsets of the shifted array bases; < 0: the level's global arrays
+};
+template <int NL, bool FL, bool CL>
+__device__ __forceinline__ void mgc_restrict(double *pool, const MgcShared &sh, const CoarseArgs &a, int kf, int tid) {
+  // a global array goes with the global geometry (sh.lev[0].g is already the compact one when level 0 comes in late)
+  const SplitGeom &fg = FL ? sh.lev[kf].g : a.lev[kf].g, &cg = CL ? sh.lev[kf + 1].g : a.lev[kf + 1].g;
+  const double *fr = FL ? pool + sh.res[kf] : a.lev[kf].res;
+  double *cr = CL ? pool + sh.res[kf + 1] : a.lev[kf + 1].res;
+  for (int t = tid; t < cg.nx * cg.ny; t += MGC_NT) restrict_pt(fr, fg, cr, cg, NL, t % cg.nx, t / cg.nx);
+  __syncthreads();
+}
+// first guess (prolongation, fused into the first red half-sweep where possible) and the nrelax sweeps of level k
+template <int NL, bool UNIFORM, bool LL, bool CL>
+__device__ __forceinline__ void mgc_level(double *pool, const MgcShared &sh, const CoarseArgs &a, int k, int nrelax, int tid) {
+  const CoarseLev &L = sh.lev[k];
+  double *da = LL ? pool + sh.da[k] : L.da;
+  const double *res = LL ? pool + sh.res[k] : L.res;
+  const bool coarsest = k == a.n - 1;
+  const CoarseLev &C = sh.lev[coarsest ? k : k + 1];
+  const double *cda = coarsest ? nullptr : (CL ? pool + sh.da[k + 1] : C.da);
+  bool fused = false;
+  if (coarsest) {  // first guess 0 (ghosts included)
+    for (size_t t = tid; t < L.g.ls * NL; t += MGC_NT) da[(LL ? MSOM_SP - 1 : 0) + t] = 0.;
+  } else if (a.prolong_fused && nrelax >= 1 && L.g.nx >= 4 && L.g.ny >= 4) fused = true;
+  else
+    for (int t = tid; t < L.g.nx * L.g.ny; t += MGC_NT) prolong_pt(cda, C.g, da, L.g, NL, a.walls, t % L.g.nx, t / L.g.nx);
+  __syncthreads();
+  for (int it = 0; it < nrelax; it++)
+    for (int c = 0; c < 2; c++) {
+      if (fused && it == 0 && c == 0) {
+        RelaxPArgs p;
+        p.da = da; p.res = res; p.S = L.S; p.coarse = cda; p.g = L.g; p.cg = C.g; p.walls = a.walls; p.rc = L.rc;
+        const int nj = (L.g.ny + 1) / 2;
+        for (int t = tid; t < L.g.hk * nj; t += MGC_NT) red_prolong2_pt<NL, UNIFORM>(p, t % L.g.hk, t / L.g.hk);
+      } else {
+        RelaxArgs p;
+        p.da = da; p.res = res; p.S = L.S; p.g = L.g; p.color = c; p.walls = a.walls; p.rc = L.rc; p.region = 0;
+        for (int t = tid; t < L.g.hk * L.g.ny; t += MGC_NT) relax_color_pt<NL, UNIFORM>(p, t % L.g.hk, t / L.g.hk);
+      }
+      __syncthreads();
+    }
+}
 template <int NL, bool UNIFORM>
 __global__ void __launch_bounds__(MGC_NT) k_mg_coarse(const CoarseArgs *pa, int nrelax) {
   __shared__ double pool[MGC_POOL];
-  __shared__ CoarseLev slev[MGC_MAXLEV];
-  __shared__ int s_first_lds;  // levels >= s_first_lds (coarser) are LDS-resident; n: none
+  __shared__ MgcShared sh;
+  __shared__ int s_lds_from, s_top_late;  // levels >= s_lds_from are resident from the start; s_top_late: level 0 comes in on the way up
   const CoarseArgs &a = *pa;
   const int tid = threadIdx.x, n = a.n;
+  {  // the level table: copied by all threads, patched by one
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.lev);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(sh.lev);
+    for (int t = tid; t < (int)(n * sizeof(CoarseLev) / 8); t += MGC_NT) dst[t] = src[t];
+  }
+  __syncthreads();
   if (tid == 0) {
-    size_t used = MSOM_SP;  // slack: the shifted pointers stay inside the pool
-    int first = n;
-    for (int k = n - 1; k >= 0; k--) {
-      slev[k] = a.lev[k];
-      const SplitGeom cg = mgc_compact(a.lev[k].g);
-      const size_t need = 2 * cg.ls * NL;
-      if (UNIFORM && a.lds && first == k + 1 && used + need <= MGC_POOL) {
-        slev[k].g = cg;
-        slev[k].da = pool + used - (MSOM_SP - 1);
-        slev[k].res = pool + used + cg.ls * NL - (MSOM_SP - 1);
-        used += need;
-        first = k;
+    int from = n, late = 0;
+    for (int k = 0; k < n; k++) sh.da[k] = sh.res[k] = -1;
+    if (UNIFORM && a.lds) {
+      size_t sum = 0, top = 2 * mgc_compact(a.lev[0].g).ls * NL;
+      for (int k = 1; k < n; k++) sum += mgc_compact(a.lev[k].g).ls * NL;
+      if (MSOM_SP + 2 * sum <= MGC_POOL) {  // da of levels n-1 .. 1, then their residuals
+        from = n > 1 ? 1 : n;
+        size_t o = MSOM_SP;
+        for (int k = n - 1; k >= 1; k--) { sh.lev[k].g = mgc_compact(a.lev[k].g); sh.da[k] = (int)(o - (MSOM_SP - 1)); o += sh.lev[k].g.ls * NL; }
+        const size_t r0 = o;
+        for (int k = n - 1; k >= 1; k--) { sh.res[k] = (int)(o - (MSOM_SP - 1)); o += sh.lev[k].g.ls * NL; }
+        if (r0 + top <= MGC_POOL) {  // level 0 over the residual region
+          late = 1;
+          sh.lev[0].g = mgc_compact(a.lev[0].g);
+          sh.da[0] = (int)(r0 - (MSOM_SP - 1));
+          sh.res[0] = (int)(r0 + top / 2 - (MSOM_SP - 1));
+        }
       }
     }
-    s_first_lds = first;
+    s_lds_from = from; s_top_late = late;
   }
-  for (int t = tid; t < MGC_POOL; t += MGC_NT) pool[t] = 0.;
   __syncthreads();
-  const int first_lds = s_first_lds;
-  if (first_lds == 0) {  // the residual of the group's finest level: global -> LDS (interior cells)
-    const CoarseLev &G = a.lev[0], &L = slev[0];
+  const int lds_from = s_lds_from, late = s_top_late;
+  // nothing in the pool is read before this launch wrote it, so it is not cleared; lds = 2 (option mg_coarse = 3) fills it with
+  // NaN first, which the parity tests use to prove exactly that
+  if (a.lds == 2) {
+    for (int t = tid; t < MGC_POOL; t += MGC_NT) pool[t] = __longlong_as_double(0x7ff8000000000000LL);
+    __syncthreads();
+  }
+  // restrictions of the residual, level by level (level 0 always from global memory)
+  if (n > 1) {
+    if (lds_from <= 1) mgc_restrict<NL, false, true>(pool, sh, a, 0, tid);
+    else mgc_restrict<NL, false, false>(pool, sh, a, 0, tid);
+  }
+  for (int k = 2; k < n; k++) {
+    if (lds_from <= 1) mgc_restrict<NL, true, true>(pool, sh, a, k - 1, tid);
+    else mgc_restrict<NL, false, false>(pool, sh, a, k - 1, tid);
+  }
+  for (int k = n - 1; k >= 1; k--) {
+    if (lds_from <= 1) mgc_level<NL, UNIFORM, true, true>(pool, sh, a, k, nrelax, tid);
+    else mgc_level<NL, UNIFORM, false, false>(pool, sh, a, k, nrelax, tid);
+  }
+  if (late) {  // the finest level of the group: residual in (interior cells), sweeps, correction out (ghosts included)
+    const CoarseLev &G = a.lev[0], &L = sh.lev[0];
+    double *lres = pool + sh.res[0], *lda = pool + sh.da[0];
     for (int t = tid; t < G.g.nx * G.g.ny * NL; t += MGC_NT) {
       const int i = t % G.g.nx, j = (t / G.g.nx) % G.g.ny, l = t / (G.g.nx * G.g.ny);
-      L.res[split_idx(L.g, l, j, i)] = G.res[split_idx(G.g, l, j, i)];
+      lres[split_idx(L.g, l, j, i)] = G.res[split_idx(G.g, l, j, i)];
     }
     __syncthreads();
-  }
-  for (int k = 1; k < n; k++) {  // restriction of the residual, level by level
-    const CoarseLev &F = slev[k - 1], &C = slev[k];
-    for (int t = tid; t < C.g.nx * C.g.ny; t += MGC_NT) restrict_pt(F.res, F.g, C.res, C.g, NL, t % C.g.nx, t / C.g.nx);
-    __syncthreads();
-  }
-  for (int k = n - 1; k >= 0; k--) {
-    const CoarseLev &L = slev[k];
-    bool fused = false;
-    if (k == n - 1) {  // first guess 0 (ghosts included); an LDS-resident level was zeroed with the pool
-      if (k < first_lds)
-        for (size_t t = tid; t < L.g.ls * NL; t += MGC_NT) L.da[t] = 0.;
-    } else if (a.prolong_fused && nrelax >= 1 && L.g.nx >= 4 && L.g.ny >= 4) fused = true;
-    else {
-      const CoarseLev &C = slev[k + 1];
-      for (int t = tid; t < L.g.nx * L.g.ny; t += MGC_NT) prolong_pt(C.da, C.g, L.da, L.g, NL, a.walls, t % L.g.nx, t / L.g.nx);
-    }
-    __syncthreads();
-    for (int it = 0; it < nrelax; it++)
-      for (int c = 0; c < 2; c++) {
-        if (fused && it == 0 && c == 0) {
-          RelaxPArgs p;
-          p.da = L.da; p.res = L.res; p.S = L.S; p.coarse = slev[k + 1].da; p.g = L.g; p.cg = slev[k + 1].g; p.walls = a.walls; p.rc = L.rc;
-          const int nj = (L.g.ny + 1) / 2;
-          for (int t = tid; t < L.g.hk * nj; t += MGC_NT) red_prolong2_pt<NL, UNIFORM>(p, t % L.g.hk, t / L.g.hk);
-        } else {
-          RelaxArgs p;
-          p.da = L.da; p.res = L.res; p.S = L.S; p.g = L.g; p.color = c; p.walls = a.walls; p.rc = L.rc; p.region = 0;
-          for (int t = tid; t < L.g.hk * L.g.ny; t += MGC_NT) relax_color_pt<NL, UNIFORM>(p, t % L.g.hk, t / L.g.hk);
-        }
-        __syncthreads();
-      }
-  }
-  if (first_lds == 0) {  // the correction of the group's finest level, ghosts included: LDS -> global
-    const CoarseLev &G = a.lev[0], &L = slev[0];
+    mgc_level<NL, UNIFORM, true, true>(pool, sh, a, 0, nrelax, tid);
     const int w = G.g.nx + 2, h = G.g.ny + 2;
     for (int t = tid; t < w * h * NL; t += MGC_NT) {
       const int i = t % w - 1, j = (t / w) % h - 1, l = t / (w * h);
-      G.da[split_idx(G.g, l, j, i)] = L.da[split_idx(L.g, l, j, i)];
+      G.da[split_idx(G.g, l, j, i)] = lda[split_idx(L.g, l, j, i)];
     }
-  }
+  } else if (lds_from <= 1) mgc_level<NL, UNIFORM, false, true>(pool, sh, a, 0, nrelax, tid);
+  else mgc_level<NL, UNIFORM, false, false>(pool, sh, a, 0, nrelax, tid);
 }
 template <int NL>
 static void mg_coarse_dispatch(hipStream_t st, const CoarseArgs *d_args, int nrelax, int uniformS) {

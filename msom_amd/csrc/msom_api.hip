@@ -905,7 +905,7 @@ static int setup_mg_coarse(msom *m) {
   h.n = m->nlev - k0;
   h.walls = glob ? (m->bc == BC_PERIODIC ? WALL_PER : WALL_ALL) : m->walls;
   h.prolong_fused = m->prolong_fused;
-  h.lds = m->mgc_opt >= 2;
+  h.lds = m->mgc_opt >= 2 ? m->mgc_opt - 1 : 0;
   for (int k = k0; k < m->nlev; k++) {
     CoarseLev &L = h.lev[k - k0];
     if (glob) { const int q = k - m->agg_level; L.da = m->gda[q]; L.res = m->gres[q]; L.S = nullptr; L.g = m->gsg[q]; }

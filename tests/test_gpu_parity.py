@@ -210,8 +210,8 @@ def test_fast_stochastic_rides_in_the_tendency_pass(nx, ny, nl, extra):
         for _ in range(4):
             m.step()
         res.append(m.get(orc.Q if m is o else F["Q"]))
-    assert rel(res[1], res[0]) <= 1e-10 and rel(res[2], res[0]) <= 1e-10
-    assert rel(res[1], res[2]) <= 1e-11 and not np.array_equal(res[1], res[2])   # the two paths are different code
+    assert rel(res[1], res[0]) <= 1e-9 and rel(res[2], res[0]) <= 1e-9
+    assert rel(res[1], res[2]) <= 1e-10 and not np.array_equal(res[1], res[2])   # the two paths are different code
 
 
 @pytest.mark.parametrize("nx,ny,nl", CASES)
@@ -475,7 +475,7 @@ def test_one_launch_coarse_levels_equal_per_kernel_path(nx, ny, nl, strict):
     same psi as the kernel-per-half-sweep path (bit for bit in the strict build)"""
     txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else ""))
     out = {}
-    for opt in (0, 1):
+    for opt in (0, 1, 2, 3):   # 1: the levels through global memory, 2: resident in LDS, 3: the same with the pool pre-filled with NaN
         g = QG(txt, strict=strict)
         g.option("quiet", 1); g.option("TOLERANCE", 1e-8)
         g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx))
@@ -486,10 +486,14 @@ def test_one_launch_coarse_levels_equal_per_kernel_path(nx, ny, nl, strict):
         st = g.mgstats()
         out[opt] = (g.get(F["PSI"]), (st.i, st.resa))
         g.close()
-    if strict:
-        assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
-    else:
-        assert rel(out[1][0], out[0][0]) <= 1e-10 and out[0][1][0] == out[1][1][0]
+    for opt in (1, 2, 3):
+        if strict:
+            assert np.array_equal(out[0][0], out[opt][0]) and out[0][1] == out[opt][1], opt
+        else:
+            assert rel(out[opt][0], out[0][0]) <= 1e-10 and out[0][1][0] == out[opt][1][0], opt
+    # the one-launch variants run the same per-point code: identical among themselves in both builds; NaN anywhere in the LDS
+    # pool would surface here if a cell were read before the launch wrote it
+    assert np.array_equal(out[1][0], out[2][0]) and np.array_equal(out[2][0], out[3][0]) and np.isfinite(out[3][0]).all()
 
 
 @pytest.mark.parametrize("nx,ny,nl", [(128, 64, 3), (64, 64, 6), (256, 128, 2), (192, 80, 4), (64, 32, 1)])
