@@ -1095,17 +1095,22 @@ __device__ __forceinline__ void mgc_level(double *pool, const MgcShared &sh, con
   else
     for (int t = tid; t < L.g.nx * L.g.ny; t += MGC_NT) prolong_pt(cda, C.g, da, L.g, NL, a.walls, t % L.g.nx, t / L.g.nx);
   __syncthreads();
+  // a phase of a small level is one wavefront's serial instruction stream (~4.5 cycles per instruction with nothing to overlap):
+  // the arguments and the (column, row) of the thread's first point are formed once per level, not once per phase
+  RelaxArgs p;
+  p.da = da; p.res = res; p.S = L.S; p.g = L.g; p.color = 0; p.walls = a.walls; p.rc = L.rc; p.region = 0;
+  const int hk = p.g.hk, cnt = hk * p.g.ny, kx0 = tid % hk, j0 = tid / hk;
   for (int it = 0; it < nrelax; it++)
     for (int c = 0; c < 2; c++) {
       if (fused && it == 0 && c == 0) {
-        RelaxPArgs p;
-        p.da = da; p.res = res; p.S = L.S; p.coarse = cda; p.g = L.g; p.cg = C.g; p.walls = a.walls; p.rc = L.rc;
-        const int nj = (L.g.ny + 1) / 2;
-        for (int t = tid; t < L.g.hk * nj; t += MGC_NT) red_prolong2_pt<NL, UNIFORM>(p, t % L.g.hk, t / L.g.hk);
+        RelaxPArgs q;
+        q.da = da; q.res = res; q.S = L.S; q.coarse = cda; q.g = p.g; q.cg = C.g; q.walls = a.walls; q.rc = p.rc;
+        const int nj = (p.g.ny + 1) / 2;
+        for (int t = tid; t < hk * nj; t += MGC_NT) red_prolong2_pt<NL, UNIFORM>(q, t % hk, t / hk);
       } else {
-        RelaxArgs p;
-        p.da = da; p.res = res; p.S = L.S; p.g = L.g; p.color = c; p.walls = a.walls; p.rc = L.rc; p.region = 0;
-        for (int t = tid; t < L.g.hk * L.g.ny; t += MGC_NT) relax_color_pt<NL, UNIFORM>(p, t % L.g.hk, t / L.g.hk);
+        p.color = c;
+        if (tid < cnt) relax_color_pt<NL, UNIFORM>(p, kx0, j0);
+        for (int t = tid + MGC_NT; t < cnt; t += MGC_NT) relax_color_pt<NL, UNIFORM>(p, t % hk, t / hk);
       }
       __syncthreads();
     }
