@@ -21,12 +21,7 @@
 // updates a wall cell also rewrites its ghost(s); no separate boundary kernel is launched.
 #include "kernels.h"
 #include "mg_inl.h"
-
-#ifdef MSOM_STRICT
-#define DIVC(x, c, rc) ((x) / (c))
-#else
-#define DIVC(x, c, rc) ((x) * (rc))
-#endif
+#include "rhs_inl.h"  // DIVC, whole-wave DPP shifts
 
 
 #define BX 64
@@ -443,6 +438,104 @@ __global__ void __launch_bounds__(BX *BY, 4) k_correct_residual(Res2Args p) {
   }
 }
 
+// Max-only pass of the finest level as a marching kernel (round 2): max |res(a)| and max |u(a)| of an a that is already corrected
+// (mode 8).  One wavefront per strip of 62 columns (+1 halo lane each side), lane = column, marching up a chunk of rows with a
+// 3-row register window of every layer: x neighbours by whole-wave DPP shifts, the diagonal neighbours of the face velocities
+// from the shifts of the previous row, rows prefetched two steps ahead.  No LDS tile, no barrier per layer, halo 2 lanes in 64
+// and 2 rows per chunk: the pass reads psi and q once.  Uniform S only; the expressions are those of k_correct_residual, so
+// both maxima are the same numbers.
+#define RM_OW 62
+int g_resmax_rows = 0;  // option resmax_rows: rows per chunk of k_resmax_march (0: 32), -1: the LDS-tiled kernel instead
+template <int NL>
+__global__ void __launch_bounds__(256) k_resmax_march(Res2Args p, int H) {
+  __shared__ double smm[4];
+  __shared__ double smu[MSOM_MAXNL][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int strip = blockIdx.x * 4 + wv;
+  const int nx = p.g.nx, ny = p.g.ny, pitch = p.g.pitch;
+  const int nstrips = (nx + RM_OW - 1) / RM_OW;
+  const double D = p.rc.D, rD = 1. / D;
+  double m = 0., uu[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) uu[l] = 0.;
+  const int y0 = blockIdx.y * H, y1 = min(y0 + H, ny);
+  if (strip < nstrips && y0 < ny) {
+    const int x0 = strip * RM_OW, gi = min(x0 - 1 + lane, nx);
+    const bool own = lane >= 1 && lane <= RM_OW && x0 - 1 + lane < nx;
+    const size_t ls = p.g.ls;
+    const double *pa = p.a + nat_idx(p.g, 0, 0, gi), *pb = p.b + nat_idx(p.g, 0, 0, min(gi, nx - 1) < 0 ? 0 : min(gi, nx - 1));
+    double Wm[NL], Wc[NL], Wp[NL], Wn[NL], Em[NL], Mm[NL], qc[NL], qn[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      Wm[l] = pa[l * ls + (ptrdiff_t)(y0 - 1) * pitch];
+      Wc[l] = pa[l * ls + (ptrdiff_t)y0 * pitch];
+      Wp[l] = pa[l * ls + (ptrdiff_t)min(y0 + 1, ny) * pitch];
+      qc[l] = pb[l * ls + (ptrdiff_t)y0 * pitch];
+    }
+#pragma unroll
+    for (int l = 0; l < NL; l++) { Em[l] = lane_above(Wm[l]); Mm[l] = lane_below(Wm[l]); }
+    for (int j = y0; j < y1; j++) {
+      const ptrdiff_t rn = (ptrdiff_t)min(j + 2, ny) * pitch, rq = (ptrdiff_t)min(j + 1, ny - 1) * pitch;
+#pragma unroll
+      for (int l = 0; l < NL; l++) { Wn[l] = pa[l * ls + rn]; qn[l] = pb[l * ls + rq]; }
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        const double c = Wc[l], E = lane_above(c), W = lane_below(c), N = Wp[l], S = Wm[l], NW = lane_below(N), SE = Em[l], SW = Mm[l];
+        const double be = qc[l];
+        double re = be;
+        if (NL > 1) {
+          const double i0 = p.rc.idh0[l], i1 = p.rc.idh1[l];
+          const double z0 = l > 0 ? p.rc.S[l - 1] : 0., z1 = l < NL - 1 ? p.rc.S[l] : 0.;
+          if (l == 0) re = be + z1 * (c - Wc[l + 1 < NL ? l + 1 : l]) * i1;
+          else if (l < NL - 1) re = be + z0 * (c - Wc[l - 1]) * i0 - z1 * (Wc[l + 1 < NL ? l + 1 : l] - c) * i1;
+          else re = be + z0 * (c - Wc[l - 1]) * i0;
+        }
+        re += DIVC(DIVC(c - W, D, rD) - DIVC(E - c, D, rD), D, rD);
+        re += DIVC(DIVC(c - S, D, rD) - DIVC(N - c, D, rD), D, rD);
+        const double u = fabs(DIVC(0.25 * (N - S + NW - SW), D, rD)), v = fabs(DIVC(0.25 * (E - W + SE - SW), D, rD));
+        if (own) { m = fmax(m, fabs(re)); uu[l] = fmax(uu[l], fmax(u, v)); }
+        Em[l] = E; Mm[l] = W;
+      }
+#pragma unroll
+      for (int l = 0; l < NL; l++) { Wm[l] = Wc[l]; Wc[l] = Wp[l]; Wp[l] = Wn[l]; qc[l] = qn[l]; }
+    }
+  }
+  m = wave_max(m);
+  if (lane == 0) smm[wv] = m;
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    const double w = wave_max(uu[l]);
+    if (lane == 0) smu[l][wv] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double mm = fmax(fmax(smm[0], smm[1]), fmax(smm[2], smm[3]));
+    atomicMax((unsigned long long *)p.maxres, (unsigned long long)__double_as_longlong(mm));
+  }
+  if (threadIdx.x < NL)
+    p.umax_partial[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NL + threadIdx.x] =
+        fmax(fmax(smu[threadIdx.x][0], smu[threadIdx.x][1]), fmax(smu[threadIdx.x][2], smu[threadIdx.x][3]));
+}
+template <int NL>
+static dim3 resmax_march_launch(hipStream_t st, const Res2Args &p, int H) {
+  const int nstrips = (p.g.nx + RM_OW - 1) / RM_OW;
+  dim3 gr((nstrips + 3) / 4, (p.g.ny + H - 1) / H);
+  hipLaunchKernelGGL(k_resmax_march<NL>, gr, dim3(256), 0, st, p, H);
+  return gr;
+}
+static dim3 launch_resmax_march(hipStream_t st, const Res2Args &p, int H) {
+  switch (p.nl) {
+    case 1: return resmax_march_launch<1>(st, p, H);
+    case 2: return resmax_march_launch<2>(st, p, H);
+    case 3: return resmax_march_launch<3>(st, p, H);
+    case 4: return resmax_march_launch<4>(st, p, H);
+    case 5: return resmax_march_launch<5>(st, p, H);
+    case 6: return resmax_march_launch<6>(st, p, H);
+    case 7: return resmax_march_launch<7>(st, p, H);
+    default: return resmax_march_launch<8>(st, p, H);
+  }
+}
+
 // out[l] = max_b partial[b][l]
 __global__ void k_max_final_mg(const double *partial, double *out, int nb, int nl) {
   // MAXF_BLOCKS blocks, each over a contiguous chunk of partial rows; thread = row, the nl values of a
@@ -502,7 +595,9 @@ void launch_residual2(hipStream_t st, int mode, const double *a, const double *d
     case 6: hipLaunchKernelGGL((k_residual2<false, true, true>), gr, block2d(), 0, st, p); break;
     case 0: hipLaunchKernelGGL((k_residual2<false, false, false>), gr, block2d(), 0, st, p); break;
     case 8:  // max |res(a)| and max |u(a)| of an a that is already corrected
-      if (g.nx % 2 == 0 && g.nx >= CR_TW && g.ny >= CR_TR && !(p.dbg & 128)) {
+      if (uniformS && g.nx >= 64 && g.ny >= 16 && g_resmax_rows >= 0) {
+        gr = launch_resmax_march(st, p, g_resmax_rows ? g_resmax_rows : 32);
+      } else if (g.nx % 2 == 0 && g.nx >= CR_TW && g.ny >= CR_TR && !(p.dbg & 128)) {
         gr = dim3((g.nx + CR_TW - 1) / CR_TW, (g.ny + CR_TR - 1) / CR_TR);
         if (uniformS) hipLaunchKernelGGL((k_correct_residual<true, false>), gr, block2d(), 0, st, p);
         else hipLaunchKernelGGL((k_correct_residual<false, false>), gr, block2d(), 0, st, p);
