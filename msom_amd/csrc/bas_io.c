@@ -19,6 +19,11 @@ int msom_bas_write(const char *path, const double *a, int nl, int n, double L0) 
   }
   const size_t n1 = (size_t)n + 1;
   float *frame = (float *)malloc(n1 * n1 * sizeof(float));
+  if (!frame) {
+    fclose(fp);
+    msom_set_error("out of memory writing %s (frame %d)", path, n);
+    return -2;
+  }
   const float fn = (float)n, delta = (float)L0 / fn; /* float arithmetic as in the reference */
   for (int l = 0; l < nl; l++) {
     const double *al = a + (size_t)l * n * n;
