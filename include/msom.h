@@ -89,14 +89,16 @@ int msom_destroy(msom_t *m);
  * "TOLERANCE" "NITERMAX" "NITERMIN" (mspg/elliptic.h:111-112, qg.h:159), "DT", "quiet",
  * "stochastic" (-D_STOCHASTIC), "seed", "noise_mode" (0: the reference's serial rand() stream generated on
  * the host, 1: counter-based Philox on the device), "flag_topo", "uniform_S" (0 forces the general
- * S-field kernels), "profile" (HIP-event timing of the finest-level smoother and residual launches).
+ * S-field kernels), "profile" (HIP-event timing of the finest-level launches: 1 every kernel, 2 only the chained smoother passes;
+ * an event pair costs ~10 us of stream time).
  * Implementation switches, all result-preserving in the strict build (defaults in brackets):
  * "fused" [1] one-pass tendency kernel, "adv_fused" [1] advance folded into it, "stoch_fused" [1] (product build only) the
  * stochastic variant rides in that kernel too: -q/tau and the noise are folded into q_in by a one-read pre-pass, "rhs_variant" [6: one layer per
  * wavefront with register windows; 1: LDS tiles],
  * "rhs_resid" [0] first residual of the next inversion as its by-product, "mg_fused" [1] fused
- * residual/restriction and correction/residual passes, "prolong_fused" [1], "mg_coarse" [1] coarse levels
- * in one launch, "march" [1] chained half-sweep smoother on HBM-bound single-GPU levels (2: on every level that is
+ * residual/restriction and correction/residual passes, "prolong_fused" [1], "mg_coarse" [2] coarse levels
+ * in one launch (1: their arrays in global memory, 2: resident in LDS, 3: as 2 with the LDS pool pre-filled with NaN -- test aid),
+ * "resmax_rows" [0 = 32] rows per chunk of the marching max-only residual pass (-1: the LDS-tiled kernel), "march" [1] chained half-sweep smoother on HBM-bound single-GPU levels (2: on every level that is
  * wide enough), "march_k" [4] half-sweeps per pass, "march_rows" [0 = auto] chunk height, "march_min" [23] log2 of the cell-layers a level needs, "march_prolong" [1] prolongation folded
  * into the first pass, "march_dma" [2] memory side of the pass (0: register-window loads, 1: LDS-DMA prefetch with one strip per
  * workgroup, 2: four strips per workgroup marching in step; PROCESS-WIDE tuning knob like march_rows / march_xcd / march_flip /
@@ -269,7 +271,10 @@ typedef struct msomn msomn_t;
 msomn_t *msomn_create(const char *params_path);
 msomn_t *msomn_create_str(const char *params_text);
 void msomn_destroy(msomn_t *m);                                 /* trash_vars qg.h:537-544 */
-/* keys: TOLERANCE NITERMAX NITERMIN (nodal-poisson.h:19-23) DT quiet stochastic seed tiled_relax */
+/* keys: TOLERANCE NITERMAX NITERMIN (nodal-poisson.h:19-23) DT quiet stochastic seed; implementation switches (result-preserving in
+ * the strict build): node_split [65] levels of >= that many vertices a side keep correction / residual / mask / S2 copies in the
+ * x-parity split layout (0: off), s2_rows [1] row tables for an S2 that does not depend on x, mg_coarse [32] levels of at most that
+ * many cells a side in one launch, tiled_relax [0], node_march [0] (measured slower, kept for the tests) */
 int msomn_set_option(msomn_t *m, const char *key, double value);
 /* keys: N nl L0 DT tend dtout nlevels iRd2_low bc_fac idh0_<l> idh1_<l>; NaN if unknown */
 double msomn_get_param(msomn_t *m, const char *key);
