@@ -468,7 +468,7 @@ def test_lds_correct_residual_equals_plain(nx, ny, nl, extra, strict):
         assert out[0][2] == pytest.approx(out[384][2], rel=1e-9) and out[0][3][0] == out[384][3][0]
 
 
-@pytest.mark.parametrize("nx,ny,nl", [(256, 128, 6), (64, 64, 3), (32, 32, 1), (512, 64, 2)])
+@pytest.mark.parametrize("nx,ny,nl", [(256, 128, 6), (64, 64, 3), (32, 32, 1), (512, 64, 2), (128, 128, 8), (128, 64, 7), (64, 64, 5), (256, 256, 4)])
 @pytest.mark.parametrize("strict", [True, False])
 def test_one_launch_coarse_levels_equal_per_kernel_path(nx, ny, nl, strict):
     """option mg_coarse: the levels of at most 32 cells a side (option mg_coarse_dim) solved by ONE workgroup (k_mg_coarse) give the
