@@ -273,7 +273,7 @@ msomn_t *msomn_create_str(const char *params_text);
 void msomn_destroy(msomn_t *m);                                 /* trash_vars qg.h:537-544 */
 /* keys: TOLERANCE NITERMAX NITERMIN (nodal-poisson.h:19-23) DT quiet stochastic seed; implementation switches (result-preserving in
  * the strict build): node_split [65] levels of >= that many vertices a side keep correction / residual / mask / S2 copies in the
- * x-parity split layout (0: off), s2_rows [1] row tables for an S2 that does not depend on x, mg_coarse [32] levels of at most that
+ * x-parity split layout (0: off), s2_rows [1] row tables for an S2 that does not depend on x, node_pfused [1] prolongation folded into the first colour pass of the split levels, mg_coarse [32] levels of at most that
  * many cells a side in one launch, tiled_relax [0], node_march [0] (measured slower, kept for the tests) */
 int msomn_set_option(msomn_t *m, const char *key, double value);
 /* keys: N nl L0 DT tend dtout nlevels iRd2_low bc_fac idh0_<l> idh1_<l>; NaN if unknown */

@@ -180,6 +180,8 @@ void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, doubl
 void launch_n_prolong(hipStream_t st, const double *c, const NatGeom &cg, double *f, const NatGeom &fg, int nl, int csp = 0, int fsp = 0);
 void launch_n_correct(hipStream_t st, double *a, const double *da, const NatGeom &g, int nl, double bcv, const NatGeom *gda = nullptr);
 void launch_n_row_table(hipStream_t st, const double *f, const NatGeom &g, int nl, double *out);
+void launch_n_relax_prolong(hipStream_t st, double *a, const double *b, const double *mk, const double *S2, const NatGeom &g, int nl, double D,
+                            double iRd2, const LayerCoef &lc, const double *S2row, const double *coarse, const NatGeom &cg, int csp);
 void launch_n_relayout(hipStream_t st, const double *src, const NatGeom &sg, int ssp, double *dst, const NatGeom &dg, int dsp, int nl);
 void launch_n_umax(hipStream_t st, const double *psi, double *out, const NatGeom &g, int nl, double D);
 void launch_n_add_noise(hipStream_t st, double *q, const double *n, const NatGeom &g, const NatGeom &cg, double dts);

@@ -393,6 +393,81 @@ __global__ void __launch_bounds__(BX *BY) k_n_relax_s(NRelaxArgs p) {
 #pragma unroll
   for (int l = 0; l < NL; l++) p.a[c + l * ls] = x[l];
 }
+// Prolongation folded into the first colour pass of a split level (round 2): refine_vert (my_vertex.h:82-105) + boundary_level,
+// then colour 0 of the smoother.  In red-black order the first pass reads only the prolongated values of the OTHER colour, and a
+// vertex of the other colour has one odd and one even coordinate: its value is the mean of two coarse vertices (the four-vertex
+// and the injected cases are colour-0 vertices, whose prolongated values nothing reads).  One thread per colour-0 vertex (i + j
+// even, boundary included): it forms its four neighbours from 4 - 5 coarse values, relaxes (interior) or writes 0 (boundary), and
+// stores its east neighbour (and the west one at i = 1), so that every vertex of the level is written exactly once -- what the
+// prolongation launch (w written, then half of it read back) and the first pass did before.  Same expressions, same values.
+template <int NL>
+__global__ void __launch_bounds__(BX *BY) k_n_relax_prolong_s(NRelaxArgs p, const double *__restrict__ co, NatGeom cg, int csp) {
+  const int j = blockIdx.y * BY + threadIdx.y;
+  const int i = 2 * (blockIdx.x * BX + threadIdx.x) + (j & 1);
+  const int n = p.g.nx - 1;
+  if (i > n || j > n) return;
+  const size_t ls = p.g.ls, cls = cg.ls;
+  const bool odd = j & 1;  // (odd, odd) vertex: centre of coarse cell (I, J); (even, even): coarse vertex (I, J)
+  const int I = i >> 1, J = j >> 1;
+  // coarse vertices used: centre C = (I, J); (even, even): E (I+1, J), W (I-1, J), N (I, J+1), S (I, J-1);
+  // (odd, odd): the other three corners of the cell
+  const size_t kC = gidx(cg, csp, 0, J, I);
+  const size_t kE = gidx(cg, csp, 0, J, min(I + 1, cg.nx - 1)), kN = gidx(cg, csp, 0, min(J + 1, cg.ny - 1), I);
+  const size_t kW = gidx(cg, csp, 0, J, max(I - 1, 0)), kS = gidx(cg, csp, 0, max(J - 1, 0), I);
+  const size_t kNE = gidx(cg, csp, 0, min(J + 1, cg.ny - 1), min(I + 1, cg.nx - 1));
+  // boundary vertices of the level are 0 (boundary_level)
+  const bool bE = i + 1 >= n || j == 0 || j == n, bW = i - 1 <= 0 || j == 0 || j == n;
+  const bool bN = j + 1 >= n || i == 0 || i == n, bS = j - 1 <= 0 || i == 0 || i == n;
+  const bool interior = i > 0 && j > 0 && i < n && j < n;
+  double aE[NL], aW[NL], ew[NL], ns[NL], x[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    const double cC = co[kC + l * cls];
+    double e, w, nn, ss;
+    if (!odd) {
+      e = (cC + co[kE + l * cls]) / 2.; w = (co[kW + l * cls] + cC) / 2.;
+      nn = (cC + co[kN + l * cls]) / 2.; ss = (co[kS + l * cls] + cC) / 2.;
+    } else {
+      const double cE = co[kE + l * cls], cN = co[kN + l * cls], cNE = co[kNE + l * cls];
+      e = (cE + cNE) / 2.; w = (cC + cN) / 2.; nn = (cN + cNE) / 2.; ss = (cC + cE) / 2.;
+    }
+    aE[l] = bE ? 0. : e; aW[l] = bW ? 0. : w;
+    ew[l] = aE[l] + aW[l];
+    ns[l] = (bN ? 0. : nn) + (bS ? 0. : ss);
+  }
+  const size_t c = gidx(p.g, 1, 0, j, i);
+  if (interior) n_col_solve<NL>(p, c, ew, ns, x, j);
+#pragma unroll
+  for (int l = 0; l < NL; l++) p.a[c + l * ls] = interior ? x[l] : 0.;
+  if (i + 1 <= n) {
+    const size_t e = gidx(p.g, 1, 0, j, i + 1);
+#pragma unroll
+    for (int l = 0; l < NL; l++) p.a[e + l * ls] = aE[l];
+  }
+  if (i == 1) {
+    const size_t w = gidx(p.g, 1, 0, j, 0);
+#pragma unroll
+    for (int l = 0; l < NL; l++) p.a[w + l * ls] = aW[l];
+  }
+}
+void launch_n_relax_prolong(hipStream_t st, double *a, const double *b, const double *mk, const double *S2, const NatGeom &g, int nl, double D,
+                            double iRd2, const LayerCoef &lc, const double *S2row, const double *coarse, const NatGeom &cg, int csp) {
+  NRelaxArgs p;
+  p.a = a; p.b = b; p.mk = mk; p.S2 = S2; p.g = g; p.color = 0; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc; p.S2row = S2row;
+  const int n = g.nx - 1;
+  dim3 gr = grid2d(n / 2 + 1, n + 1);
+  switch (nl) {
+    case 1: hipLaunchKernelGGL(k_n_relax_prolong_s<1>, gr, block2d(), 0, st, p, coarse, cg, csp); break;
+    case 2: hipLaunchKernelGGL(k_n_relax_prolong_s<2>, gr, block2d(), 0, st, p, coarse, cg, csp); break;
+    case 3: hipLaunchKernelGGL(k_n_relax_prolong_s<3>, gr, block2d(), 0, st, p, coarse, cg, csp); break;
+    case 4: hipLaunchKernelGGL(k_n_relax_prolong_s<4>, gr, block2d(), 0, st, p, coarse, cg, csp); break;
+    case 5: hipLaunchKernelGGL(k_n_relax_prolong_s<5>, gr, block2d(), 0, st, p, coarse, cg, csp); break;
+    case 6: hipLaunchKernelGGL(k_n_relax_prolong_s<6>, gr, block2d(), 0, st, p, coarse, cg, csp); break;
+    case 7: hipLaunchKernelGGL(k_n_relax_prolong_s<7>, gr, block2d(), 0, st, p, coarse, cg, csp); break;
+    case 8: hipLaunchKernelGGL(k_n_relax_prolong_s<8>, gr, block2d(), 0, st, p, coarse, cg, csp); break;
+    default: break;
+  }
+}
 // ---- K consecutive colour half-sweeps of the vertex smoother in ONE pass (round 2), the marching scheme of kernels_march.hip in
 // the natural layout.  A colour pass of k_n_relax touches every cache line of `a` twice (it reads the other colour and writes
 // its own: half of each line both ways) and half of every line of b / mask / S2: ~1.9 w of line traffic per pass, 10 passes per

@@ -64,6 +64,7 @@ struct msomn {
                         // software-prefetched one step ahead).  Measured at 2049^2 x 3: 27.1 vs 26.6 ms per step, 513^2 x 3: 4.2 vs 3.1 --
                         // half the bytes, but in the natural layout half of the lanes idle in every half-sweep and the vertex column
                         // solve (vertex-dependent coefficients, one reciprocal per layer) is arithmetic-bound: off
+  int node_pfused = 1;   // option: prolongation folded into the first colour pass of the split levels
   int s2_xuniform = 0;   // set_const: S2 does not depend on x
   int s2_rows = 1;       // option: use row tables of S2 in the smoother and the residual when S2 does not depend on x
   int node_split = 65;   // option: levels of >= node_split vertices per side keep da / res / mask / S2 copies in the x-parity split layout (0: off)
@@ -262,6 +263,7 @@ extern "C" int msomn_set_option(msomn_t *m, const char *key, double v) {
   else if (!strcmp(key, "DT")) m->p.DT = v;
   else if (!strcmp(key, "quiet")) m->quiet = (int)v;
   else if (!strcmp(key, "tiled_relax")) m->tiled_relax = (int)v;
+  else if (!strcmp(key, "node_pfused")) m->node_pfused = (int)v;
   else if (!strcmp(key, "s2_rows")) { m->s2_rows = (int)v; if (m->const_set) return choose_layouts(m); }
   else if (!strcmp(key, "node_split")) { m->node_split = (int)v; if (m->const_set) return choose_layouts(m); }
   else if (!strcmp(key, "node_march")) m->node_march = (int)v;
@@ -377,10 +379,17 @@ static void relax_level(msomn *m, int k, double *da, const double *res) {
 }
 // nsweeps red-black sweeps of level k on L.da.  Wide levels: LDS-tiled passes of 2 (or 1) sweeps, out of place
 // (L.da <-> L.da2 swap, L.da always the current one); narrow levels: one launch per colour.
-static void relax_sweeps(msomn *m, int k, int nsweeps) {
+// prolong = 1: the correction of level k + 1 has not been prolongated yet; the first colour pass does it on the fly (split levels)
+static void relax_sweeps(msomn *m, int k, int nsweeps, int prolong = 0) {
   NLevel &L = m->lev[k];
   if (L.sp) {  // split layout: a colour pass already moves only the bytes it uses
-    for (int s = 0; s < nsweeps; s++) relax_level(m, k, L.da, L.res);
+    for (int s = 0; s < nsweeps; s++) {
+      if (prolong && s == 0) {
+        const NLevel &C = m->lev[k + 1];
+        launch_n_relax_prolong(m->st, L.da, L.res, L.mask_s, L.S2_s, L.ga, m->nl, L.D, m->iRd2_low, m->lc, L.S2row, C.da, C.ga, C.sp);
+        launch_n_relax(m->st, L.da, L.res, L.mask_s, L.S2_s, L.ga, m->nl, 1, L.D, m->iRd2_low, m->lc, 1, L.S2row);
+      } else relax_level(m, k, L.da, L.res);
+    }
     return;
   }
   if (m->node_march && L.n + 1 >= m->node_march && L.n + 1 >= 64) {
@@ -489,11 +498,17 @@ static int vpoisson(msomn *m, double *a, const double *b) {
         ca.lev[k - kc] = NCoarseLev{L.da, L.res, L.mask, L.S2, L.g, L.D * L.D};
       }
       launch_n_mg_coarse(m->st, ca, mg.nrelax, nl);
-      if (kc > 0) launch_n_prolong(m->st, m->lev[kc].da, m->lev[kc].ga, m->lev[kc - 1].da, m->lev[kc - 1].ga, nl, m->lev[kc].sp, m->lev[kc - 1].sp);
     } else HIPCHK(hipMemsetAsync(m->lev[nlev - 1].da, 0, m->lev[nlev - 1].g.ls * nl * sizeof(double), m->st));
+    // prolongation into level kf: a launch, or (split levels) left to the first colour pass of that level
+    auto prolong_into = [&](int kf) -> int {
+      if (m->lev[kf].sp && m->node_pfused && mg.nrelax >= 1) return 1;
+      launch_n_prolong(m->st, m->lev[kf + 1].da, m->lev[kf + 1].ga, m->lev[kf].da, m->lev[kf].ga, nl, m->lev[kf + 1].sp, m->lev[kf].sp);
+      return 0;
+    };
+    int pending = (kc < nlev && kc > 0) ? prolong_into(kc - 1) : 0;
     for (int k = (kc < nlev ? kc : nlev) - 1; k >= 0; k--) {
-      relax_sweeps(m, k, mg.nrelax);
-      if (k > 0) launch_n_prolong(m->st, m->lev[k].da, m->lev[k].ga, m->lev[k - 1].da, m->lev[k - 1].ga, nl, m->lev[k].sp, m->lev[k - 1].sp);
+      relax_sweeps(m, k, mg.nrelax, pending);
+      pending = k > 0 ? prolong_into(k - 1) : 0;
     }
     launch_n_correct(m->st, a, m->lev[0].da, m->g, nl, m->psi_bc, m->lev[0].sp ? &m->lev[0].ga : nullptr);
   }

@@ -361,7 +361,8 @@ def test_split_layout_levels(nl, N, split, s2x, strict):
         same(g.get(name), o.get(idx), strict, 1e-6)
     # natural layout from the same start: the same numbers in both builds
     o2, g2 = make_pair(N, nl, strict, mask=True, bc_fac=0.5, extra="gp_low = 0.02\n", s2x=s2x)
-    g2.set_option("node_split", 0)
+    g2.set_option("node_split", 0 if nl != 3 else split)      # nl = 3: split layout again, but with the prolongation as its own launch
+    g2.set_option("node_pfused", 0)
     g2.set_option("s2_rows", 0)
     g2.set_tnext(float("inf"))
     for _ in range(3):
