@@ -1177,6 +1177,9 @@ __device__ __forceinline__ void mgc_restrict(double *pool, const MgcShared &sh, 
 // first guess (prolongation, fused into the first red half-sweep where possible) and the nrelax sweeps of level k
 template <int NL, bool UNIFORM, bool LL, bool CL>
 __device__ __forceinline__ void mgc_level(double *pool, const MgcShared &sh, const CoarseArgs &a, int k, int nrelax, int tid) {
+  // the fused first phase (prolongation inside the first red half-sweep) needs ~210 VGPRs at nl = 6: inside this 512-thread
+  // workgroup (256 per lane) it spilled, and a prolongation phase of its own costs the same 2 us; compiled out from nl = 4 on
+  constexpr bool MGC_FUSE = NL <= 3;
   const CoarseLev &L = sh.lev[k];
   double *da = LL ? pool + sh.da[k] : L.da;
   const double *res = LL ? pool + sh.res[k] : L.res;
@@ -1186,7 +1189,7 @@ __device__ __forceinline__ void mgc_level(double *pool, const MgcShared &sh, con
   bool fused = false;
   if (coarsest) {  // first guess 0 (ghosts included)
     for (size_t t = tid; t < L.g.ls * NL; t += MGC_NT) da[(LL ? MSOM_SP - 1 : 0) + t] = 0.;
-  } else if (a.prolong_fused && nrelax >= 1 && L.g.nx >= 4 && L.g.ny >= 4) fused = true;
+  } else if (MGC_FUSE && a.prolong_fused && nrelax >= 1 && L.g.nx >= 4 && L.g.ny >= 4) fused = true;
   else
     for (int t = tid; t < L.g.nx * L.g.ny; t += MGC_NT) prolong_pt(cda, C.g, da, L.g, NL, a.walls, t % L.g.nx, t / L.g.nx);
   __syncthreads();
@@ -1197,7 +1200,7 @@ __device__ __forceinline__ void mgc_level(double *pool, const MgcShared &sh, con
   const int hk = p.g.hk, cnt = hk * p.g.ny, kx0 = tid % hk, j0 = tid / hk;
   for (int it = 0; it < nrelax; it++)
     for (int c = 0; c < 2; c++) {
-      if (fused && it == 0 && c == 0) {
+      if (MGC_FUSE && fused && it == 0 && c == 0) {
         RelaxPArgs q;
         q.da = da; q.res = res; q.S = L.S; q.coarse = cda; q.g = p.g; q.cg = C.g; q.walls = a.walls; q.rc = p.rc;
         const int nj = (p.g.ny + 1) / 2;
