@@ -1178,8 +1178,8 @@ __device__ __forceinline__ void mgc_restrict(double *pool, const MgcShared &sh, 
 template <int NL, bool UNIFORM, bool LL, bool CL>
 __device__ __forceinline__ void mgc_level(double *pool, const MgcShared &sh, const CoarseArgs &a, int k, int nrelax, int tid) {
   // the fused first phase (prolongation inside the first red half-sweep) needs ~210 VGPRs at nl = 6: inside this 512-thread
-  // workgroup (256 per lane) it spilled, and a prolongation phase of its own costs the same 2 us; compiled out from nl = 4 on
-  constexpr bool MGC_FUSE = NL <= 3;
+  // workgroup (256 per lane) it spilled, and a prolongation phase of its own costs the same 2 us; compiled out from nl = 5 on
+  constexpr bool MGC_FUSE = NL <= 4;
   const CoarseLev &L = sh.lev[k];
   double *da = LL ? pool + sh.da[k] : L.da;
   const double *res = LL ? pool + sh.res[k] : L.res;

@@ -132,7 +132,7 @@ struct msom {
   // coarse levels (<= MGC_MAXDIM cells a side) solved by ONE launch (k_mg_coarse)
   CoarseArgs *d_cargs = nullptr;
   int mgc_dim = MGC_MAXDIM;  // widest level of that group
-  int mgc_pfused = 1;   // option: prolongation fused into the first red phase inside k_mg_coarse (nl <= 3)
+  int mgc_pfused = 1;   // option: prolongation fused into the first red phase inside k_mg_coarse (nl <= 4)
   int umax_clean = 0;  // the max|u| accumulators were zeroed with the solve's scalars and not used since
   int mgc_first = -1, mgc_opt = 2;  // first (finest) level of the group, -1: none; option "mg_coarse" (1: through global memory, 2: levels resident in LDS)
   int res_ready = -1;  // field id whose first multigrid residual (levels 0, 1; SC_RESF; partial sums) the last tendency pass already produced
@@ -907,7 +907,7 @@ static int setup_mg_coarse(msom *m) {
   memset(&h, 0, sizeof h);
   h.n = m->nlev - k0;
   h.walls = glob ? (m->bc == BC_PERIODIC ? WALL_PER : WALL_ALL) : m->walls;
-  h.prolong_fused = m->prolong_fused && m->mgc_pfused;  // the kernel itself compiles the fused phase out from nl = 4 on (registers)
+  h.prolong_fused = m->prolong_fused && m->mgc_pfused;  // the kernel itself compiles the fused phase out from nl = 5 on (registers)
   h.lds = m->mgc_opt >= 2 ? m->mgc_opt - 1 : 0;
   for (int k = k0; k < m->nlev; k++) {
     CoarseLev &L = h.lev[k - k0];
