@@ -93,7 +93,7 @@ int msom_destroy(msom_t *m);
  * an event pair costs ~10 us of stream time).
  * Implementation switches, all result-preserving in the strict build (defaults in brackets):
  * "fused" [1] one-pass tendency kernel, "adv_fused" [1] advance folded into it, "stoch_fused" [1] (product build only) the
- * stochastic variant rides in that kernel too: -q/tau and the noise are folded into q_in by a one-read pre-pass, "rhs_variant" [6: one layer per
+ * stochastic variant rides in that kernel too: -q/tau and the noise are read in its finalisation next to q_in, "rhs_variant" [6: one layer per
  * wavefront with register windows; 1: LDS tiles],
  * "rhs_resid" [0] first residual of the next inversion as its by-product, "mg_fused" [1] fused
  * residual/restriction and correction/residual passes, "prolong_fused" [1], "mg_coarse" [2] coarse levels

@@ -32,6 +32,8 @@
 
 struct LpwArgs {
   const double *psi, *S, *qforc, *wind, *q_in;
+  const double *q_stage, *noise;  // STOCH: q_out = q_in + crelax * q_stage + dts * noise + dt * dq (msqg/qg_stochastic.h:48-63, 139-147)
+  double crelax, dts;
   double *dq, *q_out;  // q_out != 0: q_out = q_in + dt * dq (msqg/qg.h:602), dq not stored
   double dt;
   NatGeom g;
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
 #else
   double tlA[R];
 #endif
-  double pnext[R], qnext[R], qreg[R], fqreg[R];
+  double pnext[R], qnext[R], qreg[R], fqreg[R], qsreg[STOCH ? R : 1], nzreg[STOCH ? R : 1];
 #pragma unroll
   for (int r = 0; r < R; r++) {
 #ifdef MSOM_STRICT
@@ -230,6 +232,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
     }
 #endif
     if (QF) dq += fq;
+    if (STOCH) return (qreg[r] + qsreg[r] * a.crelax + nzreg[r] * a.dts) + dq * a.dt;
     return ADV ? qreg[r] + dq * a.dt : dq;
   };
 
@@ -289,6 +292,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
         const size_t c = nat_idx(a.g, l, min(j0 + r, ny - 1), gic);
         if (ADV) qreg[r] = a.q_in[c];
         if (QF) fqreg[r] = a.qforc[c];
+        if (STOCH) { qsreg[r] = a.q_stage[c]; nzreg[r] = a.noise[c]; }
       }
 #pragma unroll
       for (int r = 0; r < R; r++) {
@@ -310,8 +314,10 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
 
 void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq, const NatGeom &g,
                     int nl, int walls, int uniformS, const double *Su, int have_qforc, double D, double beta, double iRe, double iRe4, double cs,
-                    double cb, double slip_c, const LayerCoef &lc, const double *q_in, double *q_out, double dt, int chunk_rows, int stoch) {
+                    double cb, double slip_c, const LayerCoef &lc, const double *q_in, double *q_out, double dt, int chunk_rows, int stoch,
+                    const double *q_stage, const double *noise, double crelax, double dts) {
   LpwArgs a;
+  a.q_stage = q_stage; a.noise = noise; a.crelax = crelax; a.dts = dts;
   a.psi = psi; a.S = S; a.qforc = qforc; a.wind = wind; a.q_in = q_in; a.dq = dq; a.q_out = q_out; a.dt = dt;
   a.g = g; a.nl = nl; a.walls = walls; a.uniformS = uniformS; a.have_qforc = have_qforc;
   a.D = D; a.beta = beta; a.iRe = iRe; a.iRe4 = iRe4; a.cs = cs; a.cb = cb; a.slip_c = slip_c; a.lc = lc;

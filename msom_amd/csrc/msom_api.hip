@@ -1443,8 +1443,8 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
   const double D = p.L0 / m->gnx;
   const int nl = m->nl;
   // stochastic runs (msqg/qg_stochastic.h) ride in the same kernel when the advance does: the relaxation -q/tau and the
-  // noise are linear in fields that exist before the pass, so a one-read pre-pass folds them into q_in.  The validation
-  // build keeps the reference's operation order (separate kernels) instead.
+  // noise are linear in fields that exist before the pass, so the finalisation of the pass reads them next to q_in.  The
+  // validation build keeps the reference's operation order (separate kernels) instead.
 #ifdef MSOM_STRICT
   const bool stoch_fused = false;
 #else
@@ -1472,13 +1472,12 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
       int r = stoch_prepare(m, adv_dt, &dts);
       if (r) return r;
       m->res_ready = -1;
-      // DQ is free (the fused advance never stores the tendency): DQ = q_in - (dt / tau) q_stage + dts * noise
-      launch_advance(m->st, m->f[dqfield], m->f[adv_in], m->f[qfield], m->f[MSOM_NOISE], m->g, nl, -adv_dt * p.itr_stoch, dts);
+      // the relaxation -q_stage / tau and the noise are read in the finalisation of the pass: q_out = q_in - (dt / tau) q_stage + dts n + dt dq
       prof_begin(m, m->prof_rhs);
       launch_rhs_lpw(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, nullptr, m->g, nl, m->walls & WALL_ALL, m->uniformS,
                      m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe, iRe4, Eks / (p.Rom * 2 * m->dhf[0]),
-                     Ekb / (p.Rom * 2 * m->dhf[nl - 1]), p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, m->f[dqfield],
-                     m->f[adv_out], adv_dt, g_rhs_dbg >> 8, 1);
+                     Ekb / (p.Rom * 2 * m->dhf[nl - 1]), p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, m->f[adv_in],
+                     m->f[adv_out], adv_dt, g_rhs_dbg >> 8, 1, m->f[qfield], m->f[MSOM_NOISE], -adv_dt * p.itr_stoch, dts);
       prof_end(m, m->prof_rhs);
       if (advanced) *advanced = 1;
       return MSOM_OK;
