@@ -363,11 +363,17 @@ def main():
         tx, ty = cfg["N"] // px, cfg["N"] // py
     else:
         tx = ty = cfg["N"]
-    leg = Leg(tx, ty, nl, px, py, rank, dist, cfg["N"], stochastic=cfg["stochastic"], local_rank=local_rank)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        leg.g.option(k, float(v))
-    elapsed = leg.run(args.steps, args.warmup)
+    try:
+        leg = Leg(tx, ty, nl, px, py, rank, dist, cfg["N"], stochastic=cfg["stochastic"], local_rank=local_rank)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            leg.g.option(k, float(v))
+        elapsed = leg.run(args.steps, args.warmup)
+    except Exception as e:  # noqa: BLE001  -- say what failed in the one line the driver reads, then fail
+        if rank == 0:
+            print(json.dumps({"metric": "grid-point-updates/s", "value": 0.0, "unit": "grid-point-updates/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "higher_is_better": True, "error": repr(e)}), flush=True)
+        raise
     main_sum = leg.summary(args.steps, elapsed)
     roof = roofline(leg, world, args.steps) if rank == 0 else None
     uniform = leg.g.param("uniform_S") == 1.0
