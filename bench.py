@@ -241,6 +241,11 @@ class Leg:
                 out[key] = {"kernel": name, "avg_launch_ms": ms, "launches_timed": n, "compulsory_bytes_per_launch": nbytes, "bytes_are": what,
                             "achieved_GBs": nbytes / (ms * 1e-3) / 1e9, "frac_hbm": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if "rhs" in out:
+            # SURVEY 8(d) prices the tendency as three separate passes -- Jacobians (3 + sigma) w, dissipation (3 + sigma) w, advance 3 w;
+            # the fused pass does their work on 3 w, so this figure is an EFFECTIVE rate (it may exceed the HBM peak), never `frac`
+            sv = (9.0 + 2.0 * (nl - 1) / nl) * w
+            out["rhs"]["effective_bw_in_survey_units"] = {"GBs": sv / (out["rhs"]["avg_launch_ms"] * 1e-3) / 1e9, "bytes_if_run_as_separate_passes": sv,
+                                                          "note": "K1+K3 (3+sigma) w + K5 (3+sigma) w + K7 3 w, SURVEY 8(d)"}
             out["rhs"]["fp64_flop_per_point_layer"] = 215
             out["rhs"]["achieved_fp64_TFLOPs"] = 215.0 * self.tx * self.ty * nl / (out["rhs"]["avg_launch_ms"] * 1e-3) / 1e12
         return out, w, plain_bytes, uniform
