@@ -1567,6 +1567,10 @@ static int stoch_prepare(msom *m, double dt, double *dts) {
   float fdts = sqrt(dt);
   if (m->corrector_step) {
     if (m->noise_mode == 0) {  // reference-exact serial rand() stream
+      if (m->nranks > 1) {  // one stream per process would repeat the same numbers on every tile
+        msom_set_error("stochastic forcing on tiles: the serial rand() stream (noise_mode = 0) exists on a single tile only, use noise_mode = 1");
+        return MSOM_ERR_STATE;
+      }
       int r = generate_noise_host(m);
       if (r) return r;
     } else  // counter-based device generator

@@ -530,3 +530,20 @@ def test_energy_budgets_on_tiles(px, py, tile, nl, extra, strict):
             got = np.concatenate([np.concatenate([out[iy * px + ix]["extra"][stage][k] for ix in range(px)], axis=2) for iy in range(py)], axis=1)
             assert np.array_equal(got, ref[stage][k]), (stage, k, np.abs(got - ref[stage][k]).max())
     assert np.abs(ref[0]["DE_J1"]).max() > 0 and np.abs(ref[1]["DE_FT"]).max() > 0
+
+
+def test_serial_noise_stream_is_refused_on_tiles():
+    """noise_mode = 0 replays the reference's serial rand() stream: one stream per process would give every tile the same
+    numbers, so a tiled model refuses it instead of forcing wrongly."""
+    params = orc.double_gyre_params(64, 2, extra="MGLEVELS = 5\ntr_stoch = 50\namp_stoch = 1e-5\n")
+    psi = orc.synthetic_psi(2, 64, 64)
+
+    def step(g, r):
+        try:
+            g.step()
+        except Exception as e:  # noqa: BLE001
+            return repr(e)
+        return "stepped"
+
+    out = run_tiled(params, 2, 1, psi, nsteps=0, strict=False, opts={"stochastic": 1, "noise_mode": 0}, fn=step)
+    assert all("noise_mode = 1" in o["extra"] for o in out), [o["extra"] for o in out]
