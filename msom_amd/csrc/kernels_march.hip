@@ -20,6 +20,7 @@
 // Used on one GPU (no halo exchange between half-sweeps), walls (not the periodic domain), uniform S, nl >= 2.
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 #include "mg_inl.h"
 #include "rhs_inl.h"
@@ -51,6 +52,7 @@ struct MarchArgs {
   int walls, H, remap, flip;
   int partial;  // another half-sweep follows this pass: the colour updated by half-sweep K - 1 is overwritten before anybody reads it, only the last colour is stored
   int dbg;  // timing experiments only (results wrong): 1 = no stores, 2 = no loads after the first step
+  int lean; // interior chunks take the lean body (march_lean below)
   RelaxCoef rc;
 };
 
@@ -280,6 +282,342 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// march_lean (round 3): the body of k_relax_march_dma for INTERIOR chunks -- every row and every lane the chunk touches
+// lies inside the level (no wall, no tile edge), which is all but the outermost ring of chunks.
+//
+// SQ counters of the round-2 body (profiles/r02_pmc_sq_march.json): ~570 vector + ~445 scalar wave-instructions per
+// marching step at nl = 6, K = 4 with the prolongation -- the scalar half (row clamps, wall tests, 64-bit address
+// products, an m0 save / restore per LDS-DMA) and ~950 branches made the pass issue-bound (0.30 ms with no memory
+// traffic at all).  Here:
+//  * all rows of a step derive from ONE byte offset that advances by a constant per step (the colour half alternates, so
+//    two constants); streams are (uniform 64-bit base in SGPRs) + (32-bit per-lane offset in a VGPR): no clamps, no
+//    multiplies, no per-access address arithmetic in vector registers;
+//  * the x parity of the updated cells is the same for all K half-sweeps of a step and alternates from step to step:
+//    the loop is unrolled by two with the parity as a compile-time constant (whole-wave shift direction, colour half);
+//  * the 3-row windows rotate by renaming inside the pair of steps: two register moves per value and PAIR instead of
+//    two per step;
+//  * the LDS-DMA requests of a step are one sequence with a single m0 save / restore;
+//  * loads, stores and LDS-DMA retire in issue order on the vector-memory counter, the requests of step t + 1 are issued
+//    BEFORE the stores of step t, so the wait at the top of a step is vmcnt(number of stores): the write
+//    acknowledgements are no longer waited for.
+// Arithmetic: the expressions of the general body, same order => bit-identical (tests/test_gpu_march.py).
+template <int NL, int K, int HL, int WPB, bool PL, bool CORR>
+struct MarchLeanRows {
+  static constexpr int NLE = (NL + 1) & ~1;                 // two layer-rows per DMA instruction; odd NL repeats its last layer
+  static constexpr int CB = 2 * NLE;                        // PL: coarse ring (4 slots of NLE rows)
+  static constexpr int PBL = 3 * NLE;                       // CORR: psi block (NL x 128 doubles)
+  static constexpr int XBL = PBL + 2 * NL;                  // CORR: values of half-sweep K waiting one step for their psi row
+  static constexpr int ROWS = PL ? CB + 4 * NLE : (CORR ? XBL + NL : 3 * NLE);
+};
+
+#define MARCH_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+template <int NL, int K, int HL, int WPB, bool PL, bool CORR>
+__device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64], const int lane, const int kx0, const int y0, const int y1,
+                                           const bool down) {
+  using LR = MarchLeanRows<NL, K, HL, WPB, PL, CORR>;
+  constexpr int D1 = K >= 3 ? 3 : 1, D2 = K >= 4 ? 3 : 1;
+  constexpr int NLE = LR::NLE, ND = NLE / 2, CB = LR::CB, PBL = LR::PBL, XBL = LR::XBL;
+  const int kx = kx0 + lane;
+  const bool own_lane = lane >= HL && lane < 64 - HL;   // interior strip: every lane of the wave lies inside the level
+  const int d = down ? -1 : 1;
+  const long long rp8 = (long long)p.g.rp * 8, hp8 = (long long)p.g.hp * 8, ls8 = (long long)p.g.ls * 8;
+  const long long drp8 = down ? -rp8 : rp8;
+  const double sqD = p.rc.sqD;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) double *)(&ring[0][0]));
+  const int sub = lane >> 5;
+  // per-lane byte offsets inside a layer-row pair of a split field (requests) and of the lane's own cell (stores)
+  unsigned voffL[ND];
+#pragma unroll
+  for (int q = 0; q < ND; q++) {
+    const int lsel = sub ? (2 * q + 1 < NL ? 2 * q + 1 : NL - 1) : 2 * q;
+    voffL[q] = (unsigned)(((size_t)lsel * p.g.ls + MSOM_SP + kx0 + 2 * (lane & 31)) * 8);
+  }
+  const unsigned voffS = (unsigned)((MSOM_SP + kx) * 8);
+  // PL: the lane's 16-byte piece of a coarse row pair (see k_relax_march_dma) and where its own coarse cell lands in the ring
+  unsigned voffC[PL ? ND : 1];
+  if constexpr (PL) {
+#pragma unroll
+    for (int q = 0; q < ND; q++) {
+      const int la = 2 * q + sub < NL ? 2 * q + sub : NL - 1;
+      voffC[q] = (unsigned)(((size_t)la * p.cg.ls + ((lane >> 4) & 1) * p.cg.hp + MSOM_SP + (kx0 >> 1) + 2 * (lane & 15)) * 8);
+    }
+  }
+  const int cld = (lane & 1) * 32 + (lane >> 1);
+  const long long crp8 = (long long)p.cg.rp * 8;
+  // CORR: the lane's cell pair of a natural row
+  const unsigned voffN = (unsigned)((MSOM_XP + 2 * kx) * 8);
+  const long long np8 = (long long)p.ng.pitch * 8, nls8 = (long long)p.ng.ls * 8;
+  const long long dnp8 = down ? -np8 : np8;
+
+  const int tA = y0 - K + 1, tB = y1 + K - 2;
+  int ra = down ? y0 + y1 - 1 - tA : tA;                               // row of half-sweep 1 in the current step
+  long long rowoff = ((long long)(ra + 1) * p.g.rp + ((ra + p.c1) & 1) * p.g.hp) * 8;   // its colour half, in bytes
+  const char *const res8 = reinterpret_cast<const char *>(p.res);
+  const char *const resb8 = res8 - drp8;                               // row of half-sweep 2
+  const char *const in8 = PL ? nullptr : reinterpret_cast<const char *>(p.in) + drp8;   // the new input row
+  char *const outK8 = CORR ? nullptr : reinterpret_cast<char *>(p.out) - (long long)(K - 1) * drp8;   // row of half-sweep K
+  // CORR: psi of the row half-sweep K finished one step ago, t - K in marching coordinates
+  long long natoff = CORR ? ((long long)(ra - d * K + MSOM_YP) * p.ng.pitch) * 8 : 0;
+  const char *const psi8 = reinterpret_cast<const char *>(p.psi);
+  char *const pso8 = reinterpret_cast<char *>(p.psi_out);
+  // PL: coarse rows of the ring
+  const char *const co8 = reinterpret_cast<const char *>(p.coarse);
+
+  unsigned m0keep;
+#define MARCH_DMA(voff, base, ldsrow) \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds0 + (unsigned)(ldsrow) * 512u) : "memory")
+  // rows of the step whose half-sweep 1 sits at byte offset ro; with them (CORR) psi of the row at natural offset no
+  auto request = [&](long long ro, long long no, bool want_psi) {
+    asm volatile("s_mov_b32 %0, m0" : "=s"(m0keep));
+    const char *b1 = res8 + ro, *b2 = resb8 + ro;
+#pragma unroll
+    for (int q = 0; q < ND; q++) MARCH_DMA(voffL[q], b1, 2 * q);
+#pragma unroll
+    for (int q = 0; q < ND; q++) MARCH_DMA(voffL[q], b2, NLE + 2 * q);
+    if constexpr (!PL) {
+      const char *b3 = in8 + ro;
+#pragma unroll
+      for (int q = 0; q < ND; q++) MARCH_DMA(voffL[q], b3, 2 * NLE + 2 * q);
+    }
+    if constexpr (CORR) {
+      if (want_psi && own_lane) {
+        const char *bp = psi8 + no;
+#pragma unroll
+        for (int l = 0; l < NL; l++) MARCH_DMA(voffN, bp + l * nls8, PBL + 2 * l);
+      }
+    }
+    asm volatile("s_mov_b32 m0, %0" ::"s"(m0keep));
+  };
+  // PL: coarse row J into its ring slot
+  auto request_coarse = [&](int J) {
+    const char *cb = co8 + (long long)(J + 1) * crp8;
+    const unsigned slotrow = (unsigned)(CB + ((J + 8) & 3) * NLE) * 512u;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(m0keep));
+#pragma unroll
+    for (int q = 0; q < ND; q++)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voffC[q]), "s"(cb), "s"(lds0 + slotrow + (unsigned)(2 * q) * 512u) : "memory");
+    asm volatile("s_mov_b32 m0, %0" ::"s"(m0keep));
+  };
+
+  double W[K][3][NL];
+#pragma unroll
+  for (int s = 0; s < K; s++)
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int l = 0; l < NL; l++) W[s][q][l] = 0.;
+  double R1[D1][NL], R2[D2][NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+#pragma unroll
+    for (int q = 0; q < D1; q++) R1[q][l] = 0.;
+#pragma unroll
+    for (int q = 0; q < D2; q++) R2[q][l] = 0.;
+  }
+  // the first request; PL: the two coarse rows the first step interpolates from
+  int rn = ra + d;   // the new input row of the current step
+  if constexpr (PL) {
+    const int J = rn >> 1, cy = (rn & 1) ? 1 : -1;
+    request_coarse(J);
+    request_coarse(J + cy);
+  }
+  request(rowoff, natoff, false);
+  // rows y0 - K and y0 - K + 1 (marching coordinates) of the input fill the first window (plain loads, once per chunk)
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int r = ra + d * (q - 1);
+    const int half = (r + 1 - p.c1) & 1;
+    if constexpr (PL) {
+      const int J = r >> 1, cy = (r & 1) ? 1 : -1;
+      const size_t coff = (size_t)(kx & 1) * p.cg.hp + MSOM_SP + (kx >> 1);
+      const double *c0p = p.coarse + (size_t)(J + 1) * p.cg.rp + coff, *c1p = p.coarse + (size_t)(J + cy + 1) * p.cg.rp + coff;
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        const double a0 = c0p[l * p.cg.ls], a1 = c1p[l * p.cg.ls];
+        const double b0 = half ? lane_above(a0) : lane_below(a0), b1 = half ? lane_above(a1) : lane_below(a1);
+        W[0][q][l] = BILINEAR(a0, b0, a1, b1);
+      }
+    } else {
+      const double *src = p.in + (size_t)(r + 1) * p.g.rp + (size_t)half * p.g.hp + MSOM_SP + kx;
+#pragma unroll
+      for (int l = 0; l < NL; l++) W[0][q][l] = src[l * p.g.ls];
+    }
+  }
+  // stores a full step issues after its requests (what the counted wait at the top of the next step leaves in flight)
+  const int nstore = CORR ? NL : (p.partial ? NL : 2 * NL);
+  bool full_prev = false;
+  const int tK = y0 + K - 1;     // first step whose half-sweep K lands on a row of the chunk (the last one is tB)
+  const long long strideA = drp8 + hp8, strideB = drp8 - hp8;   // to the next step's row: from an even half / from an odd half
+
+  auto step = [&](auto pxc, auto phic, const int t) {
+    constexpr int PX = decltype(pxc)::value;      // x parity (= colour half) of the cells updated in this step
+    constexpr int PHI = decltype(phic)::value;    // position in the pair of steps: window slots (old, mid, new)
+    constexpr int O = PHI ? 1 : 0, M = PHI ? 2 : 1, NW = PHI ? 0 : 2;
+    constexpr int RA0 = PHI ? 2 : 0, RA2 = PHI ? 1 : 2;   // residual windows: slots of age 0 (new) and age 2
+    if (WPB > 1) __builtin_amdgcn_s_barrier();
+    if (full_prev) {
+      if constexpr (CORR) MARCH_VMCNT(NL);
+      else if (p.partial) MARCH_VMCNT(NL);
+      else MARCH_VMCNT(2 * NL);
+    } else MARCH_VMCNT(0);
+    double A0[PL ? NL : 1], A1[PL ? NL : 1];
+    if constexpr (PL) {
+      const int J = rn >> 1, cy = (rn & 1) ? 1 : -1;
+      const double *s0 = &ring[CB + ((J + 8) & 3) * NLE][cld], *s1 = &ring[CB + ((J + cy + 8) & 3) * NLE][cld];
+#pragma unroll
+      for (int l = 0; l < NL; l++) { A0[l] = s0[64 * l]; A1[l] = s1[64 * l]; }
+    }
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      R1[D1 == 3 ? RA0 : 0][l] = ring[l][lane];
+      R2[D2 == 3 ? RA0 : 0][l] = ring[NLE + l][lane];
+      if constexpr (!PL) W[0][NW][l] = ring[2 * NLE + l][lane];
+    }
+    // CORR: the row half-sweep K finished in the previous step: its psi and its values wait in the ring
+    const bool corr_now = CORR && t - K >= y0;
+    double2 pa[CORR ? NL : 1];
+    double xv[CORR ? NL : 1];
+    if constexpr (CORR) {
+      if (corr_now) {
+        const double *pb = &ring[0][0] + PBL * 64 + 2 * lane;
+#pragma unroll
+        for (int l = 0; l < NL; l++) { pa[l] = *reinterpret_cast<const double2 *>(pb + 128 * l); xv[l] = ring[XBL + l][lane]; }
+      }
+    }
+    // the ring is free again once these reads have returned: the next step's rows have this whole step to arrive
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    asm volatile("" ::: "memory");
+    const long long ronext = rowoff + (PX ? strideB : strideA);
+    if (t < tB) {
+      if (!(p.dbg & 2)) {
+        if constexpr (PL) {
+          // rows J, J + cy of the next step's input row: one of them is new on every second step
+          if ((PX == 1) != down) request_coarse(((rn + d) >> 1) + d);
+        }
+        request(ronext, natoff + dnp8, t + 1 - K >= y0);
+      }
+    } else if constexpr (CORR) {
+      if (own_lane) {
+        asm volatile("s_mov_b32 %0, m0" : "=s"(m0keep));
+        const char *bp = psi8 + natoff + dnp8;
+#pragma unroll
+        for (int l = 0; l < NL; l++) MARCH_DMA(voffN, bp + l * nls8, PBL + 2 * l);
+        asm volatile("s_mov_b32 m0, %0" ::"s"(m0keep));
+      }
+    }
+    if constexpr (CORR) {
+      if (corr_now && own_lane && !(p.dbg & 1)) {
+        // psi_out = psi + da: this step's parity is the one of half-sweep K's cells one step ago flipped
+        char *po = pso8 + natoff;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+          const double yv = W[K - 1][O][l];
+          const double de = PX ? xv[l] : yv, dd = PX ? yv : xv[l];   // previous step: px = 1 - PX
+          v2d o;
+          o.x = pa[l].x + de; o.y = pa[l].y + dd;
+          asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voffN), "v"(o), "s"(po + l * nls8) : "memory");
+        }
+      }
+    }
+    if constexpr (PL) {
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        const double a0 = A0[l], a1 = A1[l];
+        const double b0 = PX ? lane_above(a0) : lane_below(a0), b1 = PX ? lane_above(a1) : lane_below(a1);
+        W[0][NW][l] = BILINEAR(a0, b0, a1, b1);
+      }
+    }
+    double x[NL];
+#pragma unroll
+    for (int s = 1; s <= K; s++) {
+      double rhs[NL];
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        const double rs = (s & 1) ? R1[(s == 3 && D1 == 3) ? RA2 : (D1 == 3 ? RA0 : 0)][l] : R2[(s == 4 && D2 == 3) ? RA2 : (D2 == 3 ? RA0 : 0)][l];
+        const double a = W[s - 1][M][l];
+        double v = -sqD * rs;
+        if (PX) v += lane_above(a) + a;
+        else v += a + lane_below(a);
+        v += W[s - 1][NW][l] + W[s - 1][O][l];
+        rhs[l] = v;
+      }
+#pragma unroll
+      for (int l = 1; l < NL; l++) rhs[l] -= p.rc.w[l] * rhs[l - 1];
+      x[NL - 1] = rhs[NL - 1] * p.rc.it1[NL - 1];
+#pragma unroll
+      for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - p.rc.t2[l] * x[l + 1]) * p.rc.it1[l];
+      if (s < K) {
+#pragma unroll
+        for (int l = 0; l < NL; l++) W[s][NW][l] = x[l];
+      }
+    }
+    bool full = false;
+    if constexpr (CORR) {
+#pragma unroll
+      for (int l = 0; l < NL; l++) ring[XBL + l][lane] = x[l];
+      full = corr_now && !(p.dbg & 1);
+    } else {
+      // the last update of each colour is what the level keeps; partial: only the colour of half-sweep K (see the general body)
+      const bool stK = t >= tK, stK1 = t >= tK - 1 && t < tB && !p.partial;
+      if (own_lane && !(p.dbg & 1)) {
+        char *bo = outK8 + rowoff;
+        if (stK) {
+#pragma unroll
+          for (int l = 0; l < NL; l++) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voffS), "v"(x[l]), "s"(bo + l * ls8) : "memory");
+        }
+        if (stK1) {
+          bo += drp8;
+#pragma unroll
+          for (int l = 0; l < NL; l++) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voffS), "v"(W[K - 1][NW][l]), "s"(bo + l * ls8) : "memory");
+        }
+      }
+      full = stK && (p.partial || stK1) && !(p.dbg & 1);
+    }
+    full_prev = full;
+    if constexpr (PHI == 1) {   // back to the slot names of the first step of a pair
+#pragma unroll
+      for (int s = 0; s < K; s++)
+#pragma unroll
+        for (int l = 0; l < NL; l++) { W[s][1][l] = W[s][0][l]; W[s][0][l] = W[s][2][l]; }
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        if constexpr (D1 == 3) { R1[1][l] = R1[2][l]; R1[2][l] = R1[0][l]; }
+        if constexpr (D2 == 3) { R2[1][l] = R2[2][l]; R2[2][l] = R2[0][l]; }
+      }
+    }
+    rowoff = ronext;
+    natoff += dnp8;
+    ra += d; rn += d;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  if ((ra + p.c1) & 1) {
+    for (int t = tA; t < tB; t += 2) { step(I1{}, I0{}, t); step(I0{}, I1{}, t + 1); }
+  } else {
+    for (int t = tA; t < tB; t += 2) { step(I0{}, I0{}, t); step(I1{}, I1{}, t + 1); }
+  }
+  if constexpr (CORR) {   // the last row of the chunk
+    MARCH_VMCNT(0);
+    if (own_lane && !(p.dbg & 1)) {
+      const double *pb = &ring[0][0] + PBL * 64 + 2 * lane;
+      char *po = pso8 + natoff;
+      // the pair of steps ended: slot 0 holds the row of half-sweep K - 1 that half-sweep K visited last; its parity is the last step's
+      const int pxl = (ra - d + p.c1) & 1;
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        const double2 a = *reinterpret_cast<const double2 *>(pb + 128 * l);
+        const double xl = ring[XBL + l][lane], yv = W[K - 1][0][l];
+        const double de = pxl ? yv : xl, dd = pxl ? xl : yv;
+        *reinterpret_cast<double2 *>(po + l * nls8 + voffN) = make_double2(a.x + de, a.y + dd);
+      }
+    }
+  }
+#undef MARCH_DMA
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // k_relax_march_dma: the same pass with the memory side rebuilt (round 2).
 //
 // Measured on the register-window kernel above (tools/ab_march_dbg.py, 4096^2 x 6, K = 4): arithmetic alone 0.17 ms, with
@@ -316,7 +654,9 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
   constexpr int CB = 2 * NLE;                              // first coarse ring row
   constexpr int PB = 2 * ((3 * NL + 1) / 2);                // CORR: first row of the psi block (NL x 128 doubles)
   constexpr int XB = PB + 2 * NL;                           // CORR: values of half-sweep K waiting one step for their psi row
-  constexpr int LROWS = PL ? CB + 4 * NLE : (CORR ? XB + NL : 2 * ((3 * NL + 1) / 2));
+  constexpr int LROWS0 = PL ? CB + 4 * NLE : (CORR ? XB + NL : 2 * ((3 * NL + 1) / 2));
+  constexpr int LROWSL = MarchLeanRows<NL, K, HL, WPB, PL, CORR>::ROWS;
+  constexpr int LROWS = LROWS0 > LROWSL ? LROWS0 : LROWSL;
   __shared__ __align__(16) double ring_all[WPB][LROWS][64];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -328,6 +668,12 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
   const int y0 = by * p.H, y1 = min(p.g.ny, y0 + p.H);
   const int hk = p.g.hk, ny = p.g.ny, hp = p.g.hp;
   const bool down = p.flip && (by & 1);
+  // interior chunks (no wall, no tile edge within reach of any row or lane; an even number of rows): the lean body.  All
+  // wavefronts of a workgroup share by, hence the number of steps and of barriers
+  if (p.lean && y0 - K >= 0 && y1 + K <= ny && !((y1 - y0) & 1) && kx0 >= 0 && kx0 + 63 <= hk - 1) {
+    march_lean<NL, K, HL, WPB, PL, CORR>(p, ring, lane, kx0, y0, y1, down);
+    return;
+  }
   auto ph = [&](int t) -> int { return down ? y0 + y1 - 1 - t : t; };
   const ptrdiff_t rp = p.g.rp;
   const size_t ls = p.g.ls;
@@ -688,11 +1034,13 @@ static void march_launch(hipStream_t st, Kern kern, MarchArgs a, int ow, int chu
     }
     if (H < 16) H = 16;
   }
+  if (a.lean) H = (H + 1) & ~1;   // the lean body marches in pairs of steps
   a.H = H;
   hipLaunchKernelGGL(kern, dim3(strips, (a.g.ny + H - 1) / H), dim3(nthreads), 0, st, a);
 }
 
 int g_march_dbg = 0;    // timing experiments (option march_dbg)
+int g_march_lean = 1;   // interior chunks of the LDS-DMA pass take the lean body (option march_lean)
 int g_march_dma = 2;    // LDS-DMA version of the pass (option march_dma: 0 register-window kernel, 1 one strip, 2 four strips per workgroup)
 
 template <int NL>
@@ -761,6 +1109,9 @@ int launch_relax_march(hipStream_t st, const double *in, double *out, const doub
   extern int g_march_remap;
   extern int g_march_flip;
   extern int g_march_dbg;
+  extern int g_march_lean;
+  // lean body: 32-bit per-lane byte offsets span all layers of a field; the prolongation variant is written for c1 = 0
+  a.lean = g_march_lean && (size_t)(nl + 1) * sg.ls * 8 < ((size_t)1 << 32) && (!mc || (size_t)(nl + 1) * mc->g.ls * 8 < ((size_t)1 << 32)) && (!coarse || c1 == 0);
   a.in = in; a.out = out; a.res = res; a.g = sg; a.c1 = c1; a.walls = walls; a.rc = rc; a.remap = g_march_remap; a.flip = g_march_flip; a.dbg = g_march_dbg;
   if (nl >= 7 && K > 3) return -1;  // 4 windows of 7 or 8 layers do not fit 256 VGPRs
   switch (nl) {

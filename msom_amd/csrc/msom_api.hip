@@ -663,6 +663,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "march_flip")) { extern int g_march_flip; g_march_flip = (int)v; }
   else if (!strcmp(key, "march_dma")) { extern int g_march_dma; g_march_dma = (int)v; }
   else if (!strcmp(key, "march_dbg")) { extern int g_march_dbg; g_march_dbg = (int)v; }
+  else if (!strcmp(key, "march_lean")) { extern int g_march_lean; g_march_lean = (int)v; }
   else if (!strcmp(key, "march_k")) m->march_k = (int)v < 2 ? 2 : ((int)v > 4 ? 4 : (int)v);
   else if (!strcmp(key, "block_small")) m->block_small = (int)v;
   else if (!strcmp(key, "block_sweeps")) { m->block_sweeps = (int)v; if (m->const_set) return build_coefs(m); }
