@@ -308,17 +308,26 @@ struct MarchLeanRows {
   static constexpr int PBL = 3 * NLE;                       // CORR: psi block (NL x 128 doubles)
   static constexpr int XBL = PBL + 2 * NL;                  // CORR: values of half-sweep K waiting one step for their psi row
   static constexpr int ROWS = PL ? CB + 4 * NLE : (CORR ? XBL + NL : 3 * NLE);
+  // DEEP (requests two steps ahead; not with CORR, whose psi block and parked values leave no room): two buffers of
+  // residual (+ input) rows; PL: then a coarse ring of two slots (slot = J & 1: the row a request overwrites was read
+  // for the last time in the step that issues it)
+  static constexpr int RB = PL ? 2 * NLE : 3 * NLE;
+  static constexpr int CBD = 2 * RB;
+  static constexpr int ROWSD = PL ? CBD + 2 * NLE : 2 * RB;
 };
 
 #define MARCH_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-template <int NL, int K, int HL, int WPB, bool PL, bool CORR>
+template <int NL, int K, int HL, int WPB, bool PL, bool CORR, bool DEEP>
 __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64], const int lane, const int kx0, const int y0, const int y1,
                                            const bool down) {
   using LR = MarchLeanRows<NL, K, HL, WPB, PL, CORR>;
   constexpr int D1 = K >= 3 ? 3 : 1, D2 = K >= 4 ? 3 : 1;
-  constexpr int NLE = LR::NLE, ND = NLE / 2, CB = LR::CB, PBL = LR::PBL, XBL = LR::XBL;
+  static_assert(!(DEEP && CORR), "no LDS for a second buffer beside the psi block");
+  constexpr int NLE = LR::NLE, ND = NLE / 2, CB = DEEP ? LR::CBD : LR::CB, PBL = LR::PBL, XBL = LR::XBL, RB = LR::RB;
+  constexpr int CSLOTS = DEEP ? 2 : 4;
+  constexpr int NREQ = (PL ? 2 : 3) * ND;   // LDS-DMA instructions of one request of residual (+ input) rows
   const int kx = kx0 + lane;
   const bool own_lane = lane >= HL && lane < 64 - HL;   // interior strip: every lane of the wave lies inside the level
   const int d = down ? -1 : 1;
@@ -369,17 +378,18 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
 #define MARCH_DMA(voff, base, ldsrow) \
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds0 + (unsigned)(ldsrow) * 512u) : "memory")
   // rows of the step whose half-sweep 1 sits at byte offset ro; with them (CORR) psi of the row at natural offset no
-  auto request = [&](long long ro, long long no, bool want_psi) {
+  auto request = [&](long long ro, long long no, bool want_psi, int buf = 0) {
     asm volatile("s_mov_b32 %0, m0" : "=s"(m0keep));
     const char *b1 = res8 + ro, *b2 = resb8 + ro;
+    const int r0 = buf * RB;
 #pragma unroll
-    for (int q = 0; q < ND; q++) MARCH_DMA(voffL[q], b1, 2 * q);
+    for (int q = 0; q < ND; q++) MARCH_DMA(voffL[q], b1, r0 + 2 * q);
 #pragma unroll
-    for (int q = 0; q < ND; q++) MARCH_DMA(voffL[q], b2, NLE + 2 * q);
+    for (int q = 0; q < ND; q++) MARCH_DMA(voffL[q], b2, r0 + NLE + 2 * q);
     if constexpr (!PL) {
       const char *b3 = in8 + ro;
 #pragma unroll
-      for (int q = 0; q < ND; q++) MARCH_DMA(voffL[q], b3, 2 * NLE + 2 * q);
+      for (int q = 0; q < ND; q++) MARCH_DMA(voffL[q], b3, r0 + 2 * NLE + 2 * q);
     }
     if constexpr (CORR) {
       if (want_psi && own_lane) {
@@ -393,7 +403,7 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
   // PL: coarse row J into its ring slot
   auto request_coarse = [&](int J) {
     const char *cb = co8 + (long long)(J + 1) * crp8;
-    const unsigned slotrow = (unsigned)(CB + ((J + 8) & 3) * NLE) * 512u;
+    const unsigned slotrow = (unsigned)(CB + ((J + 8) & (CSLOTS - 1)) * NLE) * 512u;
     asm volatile("s_mov_b32 %0, m0" : "=s"(m0keep));
 #pragma unroll
     for (int q = 0; q < ND; q++)
@@ -423,7 +433,15 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
     request_coarse(J);
     request_coarse(J + cy);
   }
-  request(rowoff, natoff, false);
+  const long long strideA = drp8 + hp8, strideB = drp8 - hp8;   // to the next step's row: from an even half / from an odd half
+  request(rowoff, natoff, false, 0);
+  // DEEP: vector-memory operations retire in issue order, so "the request of this buffer has landed" = "at most
+  // (issued - mark) younger operations are outstanding"; counted at run time, waited for with the nearest constant below
+  unsigned issued = NREQ, markR[2] = {NREQ, 0}, markC = 0;
+  if constexpr (DEEP) {
+    request(rowoff + (((ra + p.c1) & 1) ? strideB : strideA), 0, false, 1);
+    issued += NREQ; markR[1] = issued;
+  }
   // rows y0 - K and y0 - K + 1 (marching coordinates) of the input fill the first window (plain loads, once per chunk)
 #pragma unroll
   for (int q = 0; q < 2; q++) {
@@ -449,7 +467,6 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
   const int nstore = CORR ? NL : (p.partial ? NL : 2 * NL);
   bool full_prev = false;
   const int tK = y0 + K - 1;     // first step whose half-sweep K lands on a row of the chunk (the last one is tB)
-  const long long strideA = drp8 + hp8, strideB = drp8 - hp8;   // to the next step's row: from an even half / from an odd half
 
   auto step = [&](auto pxc, auto phic, const int t) {
     constexpr int PX = decltype(pxc)::value;      // x parity (= colour half) of the cells updated in this step
@@ -457,7 +474,16 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
     constexpr int O = PHI ? 1 : 0, M = PHI ? 2 : 1, NW = PHI ? 0 : 2;
     constexpr int RA0 = PHI ? 2 : 0, RA2 = PHI ? 1 : 2;   // residual windows: slots of age 0 (new) and age 2
     if (WPB > 1) __builtin_amdgcn_s_barrier();
-    if (full_prev) {
+    if constexpr (DEEP) {
+      const unsigned need = PL ? max(markR[PHI], markC) : markR[PHI];
+      const unsigned n = issued - need;
+      if (n >= NREQ + 4 * NL) MARCH_VMCNT(NREQ + 4 * NL);
+      else if (n >= NREQ + 3 * NL) MARCH_VMCNT(NREQ + 3 * NL);
+      else if (n >= NREQ + 2 * NL) MARCH_VMCNT(NREQ + 2 * NL);
+      else if (n >= NREQ + NL) MARCH_VMCNT(NREQ + NL);
+      else if (n >= NREQ) MARCH_VMCNT(NREQ);
+      else MARCH_VMCNT(0);
+    } else if (full_prev) {
       if constexpr (CORR) MARCH_VMCNT(NL);
       else if (p.partial) MARCH_VMCNT(NL);
       else MARCH_VMCNT(2 * NL);
@@ -465,15 +491,16 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
     double A0[PL ? NL : 1], A1[PL ? NL : 1];
     if constexpr (PL) {
       const int J = rn >> 1, cy = (rn & 1) ? 1 : -1;
-      const double *s0 = &ring[CB + ((J + 8) & 3) * NLE][cld], *s1 = &ring[CB + ((J + cy + 8) & 3) * NLE][cld];
+      const double *s0 = &ring[CB + ((J + 8) & (CSLOTS - 1)) * NLE][cld], *s1 = &ring[CB + ((J + cy + 8) & (CSLOTS - 1)) * NLE][cld];
 #pragma unroll
       for (int l = 0; l < NL; l++) { A0[l] = s0[64 * l]; A1[l] = s1[64 * l]; }
     }
+    constexpr int R0 = DEEP ? PHI * RB : 0;   // DEEP: the buffer of this step
 #pragma unroll
     for (int l = 0; l < NL; l++) {
-      R1[D1 == 3 ? RA0 : 0][l] = ring[l][lane];
-      R2[D2 == 3 ? RA0 : 0][l] = ring[NLE + l][lane];
-      if constexpr (!PL) W[0][NW][l] = ring[2 * NLE + l][lane];
+      R1[D1 == 3 ? RA0 : 0][l] = ring[R0 + l][lane];
+      R2[D2 == 3 ? RA0 : 0][l] = ring[R0 + NLE + l][lane];
+      if constexpr (!PL) W[0][NW][l] = ring[R0 + 2 * NLE + l][lane];
     }
     // CORR: the row half-sweep K finished in the previous step: its psi and its values wait in the ring
     const bool corr_now = CORR && t - K >= y0;
@@ -490,10 +517,17 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
     asm volatile("" ::: "memory");
     const long long ronext = rowoff + (PX ? strideB : strideA);
-    if (t < tB) {
+    if constexpr (DEEP) {
       if (!(p.dbg & 2)) {
         if constexpr (PL) {
           // rows J, J + cy of the next step's input row: one of them is new on every second step
+          if (t < tB && (PX == 1) != down) { request_coarse(((rn + d) >> 1) + d); issued += ND; markC = issued; }
+        }
+        if (t + 2 <= tB) { request(rowoff + 2 * drp8, 0, false, PHI); issued += NREQ; markR[PHI] = issued; }
+      }
+    } else if (t < tB) {
+      if (!(p.dbg & 2)) {
+        if constexpr (PL) {
           if ((PX == 1) != down) request_coarse(((rn + d) >> 1) + d);
         }
         request(ronext, natoff + dnp8, t + 1 - K >= y0);
@@ -530,6 +564,10 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
       }
     }
     double x[NL];
+    if (p.dbg & 4) {   // timing experiment: the memory traffic of the pass without its arithmetic
+#pragma unroll
+      for (int l = 0; l < NL; l++) { x[l] = R1[D1 == 3 ? RA0 : 0][l] + R2[D2 == 3 ? RA0 : 0][l] + W[0][NW][l]; W[K - 1][NW][l] = x[l]; }
+    } else
 #pragma unroll
     for (int s = 1; s <= K; s++) {
       double rhs[NL];
@@ -566,11 +604,13 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
         if (stK) {
 #pragma unroll
           for (int l = 0; l < NL; l++) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voffS), "v"(x[l]), "s"(bo + l * ls8) : "memory");
+          issued += NL;
         }
         if (stK1) {
           bo += drp8;
 #pragma unroll
           for (int l = 0; l < NL; l++) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voffS), "v"(W[K - 1][NW][l]), "s"(bo + l * ls8) : "memory");
+          issued += NL;
         }
       }
       full = stK && (p.partial || stK1) && !(p.dbg & 1);
@@ -655,7 +695,8 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
   constexpr int PB = 2 * ((3 * NL + 1) / 2);                // CORR: first row of the psi block (NL x 128 doubles)
   constexpr int XB = PB + 2 * NL;                           // CORR: values of half-sweep K waiting one step for their psi row
   constexpr int LROWS0 = PL ? CB + 4 * NLE : (CORR ? XB + NL : 2 * ((3 * NL + 1) / 2));
-  constexpr int LROWSL = MarchLeanRows<NL, K, HL, WPB, PL, CORR>::ROWS;
+  using LRows = MarchLeanRows<NL, K, HL, WPB, PL, CORR>;
+  constexpr int LROWSL = (!CORR && LRows::ROWSD > LRows::ROWS) ? LRows::ROWSD : LRows::ROWS;
   constexpr int LROWS = LROWS0 > LROWSL ? LROWS0 : LROWSL;
   __shared__ __align__(16) double ring_all[WPB][LROWS][64];
   const int lane = threadIdx.x & 63;
@@ -671,7 +712,10 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
   // interior chunks (no wall, no tile edge within reach of any row or lane; an even number of rows): the lean body.  All
   // wavefronts of a workgroup share by, hence the number of steps and of barriers
   if (p.lean && y0 - K >= 0 && y1 + K <= ny && !((y1 - y0) & 1) && kx0 >= 0 && kx0 + 63 <= hk - 1) {
-    march_lean<NL, K, HL, WPB, PL, CORR>(p, ring, lane, kx0, y0, y1, down);
+    if constexpr (!CORR) {
+      if (p.lean >= 2) { march_lean<NL, K, HL, WPB, PL, CORR, true>(p, ring, lane, kx0, y0, y1, down); return; }
+    }
+    march_lean<NL, K, HL, WPB, PL, CORR, false>(p, ring, lane, kx0, y0, y1, down);
     return;
   }
   auto ph = [&](int t) -> int { return down ? y0 + y1 - 1 - t : t; };
@@ -1040,7 +1084,7 @@ static void march_launch(hipStream_t st, Kern kern, MarchArgs a, int ow, int chu
 }
 
 int g_march_dbg = 0;    // timing experiments (option march_dbg)
-int g_march_lean = 1;   // interior chunks of the LDS-DMA pass take the lean body (option march_lean)
+int g_march_lean = 2;   // interior chunks of the LDS-DMA pass take the lean body (option march_lean; 2: requests two steps ahead where LDS allows)
 int g_march_dma = 2;    // LDS-DMA version of the pass (option march_dma: 0 register-window kernel, 1 one strip, 2 four strips per workgroup)
 
 template <int NL>
@@ -1111,7 +1155,7 @@ int launch_relax_march(hipStream_t st, const double *in, double *out, const doub
   extern int g_march_dbg;
   extern int g_march_lean;
   // lean body: 32-bit per-lane byte offsets span all layers of a field; the prolongation variant is written for c1 = 0
-  a.lean = g_march_lean && (size_t)(nl + 1) * sg.ls * 8 < ((size_t)1 << 32) && (!mc || (size_t)(nl + 1) * mc->g.ls * 8 < ((size_t)1 << 32)) && (!coarse || c1 == 0);
+  a.lean = !g_march_lean ? 0 : g_march_lean * (int)((size_t)(nl + 1) * sg.ls * 8 < ((size_t)1 << 32) && (!mc || (size_t)(nl + 1) * mc->g.ls * 8 < ((size_t)1 << 32)) && (!coarse || c1 == 0));
   a.in = in; a.out = out; a.res = res; a.g = sg; a.c1 = c1; a.walls = walls; a.rc = rc; a.remap = g_march_remap; a.flip = g_march_flip; a.dbg = g_march_dbg;
   if (nl >= 7 && K > 3) return -1;  // 4 windows of 7 or 8 layers do not fit 256 VGPRs
   switch (nl) {

@@ -36,6 +36,7 @@
 // RES0, RES1 and UMAX[nl] are contiguous: one max all-reduce / one copy brings them to the host
 enum { SC_BSUM = 2, SC_KE = 3, SC_SCRATCH = 4, SC_RES0 = 6, SC_RES1 = 7, SC_UMAX = 8 /* MAXNL */, SC_RESF = 16 /* max|res| from the fused tendency pass */, SC_LSUM = 32 /* MAXNL */, SC_COUNT = 64 };
 
+static int g_dbg_interleave = 0;  // timing experiment of msom_bench_kernel (march passes)
 static int g_march_rows = 0;  // tuning knob: chunk height of k_relax_march (0 = automatic)
 #define MARCH_HALO 4    // rows (= cells in x) of neighbour data a pass of up to 4 chained half-sweeps reads
 struct ProfSlot {
@@ -663,6 +664,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "march_flip")) { extern int g_march_flip; g_march_flip = (int)v; }
   else if (!strcmp(key, "march_dma")) { extern int g_march_dma; g_march_dma = (int)v; }
   else if (!strcmp(key, "march_dbg")) { extern int g_march_dbg; g_march_dbg = (int)v; }
+  else if (!strcmp(key, "dbg_interleave")) g_dbg_interleave = (int)v;
   else if (!strcmp(key, "march_lean")) { extern int g_march_lean; g_march_lean = (int)v; }
   else if (!strcmp(key, "march_k")) m->march_k = (int)v < 2 ? 2 : ((int)v > 4 ? 4 : (int)v);
   else if (!strcmp(key, "block_small")) m->block_small = (int)v;
@@ -2612,7 +2614,13 @@ extern "C" int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double
                        m->nl, m->have_pg, m->have_zpg, m->stochastic, D, m->p.beta, m->p.itr_stoch, m->lc);
     } else if (!strncmp(kernel, "march", 5) && kernel[5] >= '2' && kernel[5] <= '4') {
       const bool rev = kernel[6] == 'r';  // "march3r": da_alt -> da (the direction of the second pass of a level)
-      launch_relax_march(m->st, rev ? m->da_alt[0] : m->da[0], rev ? m->da[0] : m->da_alt[0], m->res[0], m->sg[0], m->nl, m->rc[0], 1, kernel[5] - '0', m->walls,
+      const bool pl = kernel[6] == 'p';   // "march4p": the pass with the prolongation (coarse = level 1)
+      // timing experiment (option dbg_interleave; results meaningless): the same buffers addressed as [row][layer][x]
+      // instead of [layer][row][x] -- all layers of a row within one 2-MB fragment
+      SplitGeom g0 = m->sg[0], g1 = m->sg[m->nlev > 1 ? 1 : 0];
+      if (g_dbg_interleave) { g0.ls = g0.rp; g0.rp *= m->nl; g1.ls = g1.rp; g1.rp *= m->nl; }
+      if (pl) launch_relax_march(m->st, nullptr, m->da_alt[0], m->res[0], g0, m->nl, m->rc[0], 0, kernel[5] - '0', m->walls, g_march_rows, nullptr, m->da[1], &g1, nullptr, 1);
+      else launch_relax_march(m->st, rev ? m->da_alt[0] : m->da[0], rev ? m->da[0] : m->da_alt[0], m->res[0], g0, m->nl, m->rc[0], 1, kernel[5] - '0', m->walls,
                          g_march_rows);
     } else if (!strcmp(kernel, "block2")) {
       launch_relax_block2(m->st, m->da[0], nullptr, m->sg[0], m->res[0], m->da_alt[0], m->sg[0], m->nl, m->rc[0], m->walls, 1);
