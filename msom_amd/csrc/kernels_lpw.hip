@@ -38,6 +38,7 @@ struct LpwArgs {
   double dt;
   NatGeom g;
   int nl, walls, uniformS, have_qforc, H, NS;  // NS strips per workgroup
+  int dbg;  // timing experiments only (results wrong): 1 = no stores, 2 = every load hits the chunk's first row (no HBM reads)
   double D, beta, iRe, iRe4, cs, cb, slip_c;
   LayerCoef lc;
   double Su[MSOM_MAXNL];
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
     pnext[r] = qnext[r] = qreg[r] = fqreg[r] = 0.;
   }
 
-  auto ld = [&](const double *base, int j) -> double { return base[(ptrdiff_t)min(j, ny + 2) * pitch]; };
+  auto ld = [&](const double *base, int j) -> double { return base[(ptrdiff_t)((a.dbg & 2) ? y0 : min(j, ny + 2)) * pitch]; };
   auto lap5 = [&](double c, double w, double e, double n, double s) -> double { return DIVC(e + w + n + s - 4 * c, D2, rD2); };
   // x walls: the ghost lane takes -dst(mirror lane) or the partial-slip value c (src(mirror) - src(ghost))
   auto xfix = [&](double raw, double so, double sw, double se) -> double {
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < R; r++)
-        if (out_ok && jb + r < y1) outp[nat_idx(a.g, l, jb + r, gic)] = val[r];
+        if (out_ok && jb + r < y1 && !(a.dbg & 1)) outp[nat_idx(a.g, l, jb + r, gic)] = val[r];
     }
     if (k < nblk) {
       const int j0 = y0 + k * R;
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
       // the inputs of the NEXT finalisation first: they are the oldest loads in flight when it starts
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        const size_t c = nat_idx(a.g, l, min(j0 + r, ny - 1), gic);
+        const size_t c = nat_idx(a.g, l, (a.dbg & 2) ? y0 : min(j0 + r, ny - 1), gic);
         if (ADV) qreg[r] = a.q_in[c];
         if (QF) fqreg[r] = a.qforc[c];
         if (STOCH) { qsreg[r] = a.q_stage[c]; nzreg[r] = a.noise[c]; }
@@ -312,6 +313,8 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
   }
 }
 
+int g_lpw_dbg = 0;  // option lpw_dbg
+
 void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq, const NatGeom &g,
                     int nl, int walls, int uniformS, const double *Su, int have_qforc, double D, double beta, double iRe, double iRe4, double cs,
                     double cb, double slip_c, const LayerCoef &lc, const double *q_in, double *q_out, double dt, int chunk_rows, int stoch,
@@ -319,6 +322,8 @@ void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const do
   LpwArgs a;
   a.q_stage = q_stage; a.noise = noise; a.crelax = crelax; a.dts = dts;
   a.psi = psi; a.S = S; a.qforc = qforc; a.wind = wind; a.q_in = q_in; a.dq = dq; a.q_out = q_out; a.dt = dt;
+  extern int g_lpw_dbg;
+  a.dbg = g_lpw_dbg;
   a.g = g; a.nl = nl; a.walls = walls; a.uniformS = uniformS; a.have_qforc = have_qforc;
   a.D = D; a.beta = beta; a.iRe = iRe; a.iRe4 = iRe4; a.cs = cs; a.cb = cb; a.slip_c = slip_c; a.lc = lc;
   for (int l = 0; l < MSOM_MAXNL; l++) a.Su[l] = Su ? Su[l] : 0.;

@@ -564,10 +564,6 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
       }
     }
     double x[NL];
-    if (p.dbg & 4) {   // timing experiment: the memory traffic of the pass without its arithmetic
-#pragma unroll
-      for (int l = 0; l < NL; l++) { x[l] = R1[D1 == 3 ? RA0 : 0][l] + R2[D2 == 3 ? RA0 : 0][l] + W[0][NW][l]; W[K - 1][NW][l] = x[l]; }
-    } else
 #pragma unroll
     for (int s = 1; s <= K; s++) {
       double rhs[NL];
@@ -1047,6 +1043,11 @@ template <typename Kern>
 static void march_launch(hipStream_t st, Kern kern, MarchArgs a, int ow, int chunk_rows, int nthreads = 64) {
   const int strips = (a.g.hk + ow - 1) / ow;
   int H = chunk_rows;
+  // Round 3, lean body: short chunks win although they re-compute more (2 K - 2 of H + 2 K - 2 steps): the halo rows are
+  // L2 hits (vertically adjacent chunks reach their common edge together, march_flip), and many short workgroups even out
+  // the memory traffic and the tail of the launch.  4096^2 x 6 (tools/ab_prof.py): 12-14 rows PL 0.388 / CORR 0.584 ms,
+  // 16: 0.390 / 0.590, 20: 0.399 / 0.592, 26 (the round-2 rule below): 0.414 / 0.596, 32: 0.43 / 0.61, 48: 0.49 / 0.66
+  if (H == 0 && a.lean) H = 14;
   if (H <= 0) {
     // occupancy per (device, instantiation), asked once; tiled tests drive this from several host threads
     static std::mutex mu;

@@ -677,6 +677,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "mgc_pfused")) { m->mgc_pfused = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "mg_coarse_dim")) { m->mgc_dim = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "block_variant")) { extern int g_block_variant; g_block_variant = (int)v; }
+  else if (!strcmp(key, "lpw_dbg")) { extern int g_lpw_dbg; g_lpw_dbg = (int)v; }
   else if (!strcmp(key, "rhs_dbg")) { extern int g_rhs_dbg; g_rhs_dbg = (int)v; }
   else if (!strcmp(key, "resmax_rows")) { extern int g_resmax_rows; g_resmax_rows = (int)v; }
   else if (!strcmp(key, "rhs_variant")) m->rhs_variant = (int)v;
