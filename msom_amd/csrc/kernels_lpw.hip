@@ -17,6 +17,12 @@
 //  * psi rows, psi_{l+1} rows and q_in are prefetched one interval ahead into registers.
 #include "rhs_inl.h"
 
+// Product build: no automatic contraction in this file -- every fused multiply-add below is written out.  The kernel exists
+// in two instantiations (with / without the ghost-line code) and a cell is computed by either, depending on the tiling; left
+// to the compiler, contraction follows the basic-block structure, which differs between the two (one cell in 2 x 10^6
+// differed by an ulp after three steps of a 2 x 2 tiling, tests/test_gpu_tiled.py).  The validation build never contracts.
+#pragma clang fp contract(off)
+
 #define LPW_W 58  // output columns of a strip (64 lanes - 2 x 3 halo)
 #define LPW_R 4   // rows per barrier interval
 // A workgroup is floor(LPW_MAXW / nl) strips x nl layers.  12 wavefronts = 3 per SIMD is what the register budget of the
@@ -38,6 +44,7 @@ struct LpwArgs {
   double dt;
   NatGeom g;
   int nl, walls, uniformS, have_qforc, H, NS;  // NS strips per workgroup
+  int noedge_off;  // every wavefront takes the EDGE instantiation (cross-check)
   int dbg;  // timing experiments only (results wrong): 1 = no stores, 2 = every load hits the chunk's first row (no HBM reads)
   double D, beta, iRe, iRe4, cs, cb, slip_c;
   LayerCoef lc;
@@ -47,9 +54,13 @@ struct LpwArgs {
 // UNI: uniform S (constants), QF: 3-D forcing present, ADV: advance fused.  Compile-time so that the unrolled row body
 // is straight-line code: s_waitcnt counters stay exact and a wave never waits for a prefetch it does not need yet
 // STOCH (msqg/qg_stochastic.h:36-63): the top layer drops J(psi, zeta), no layer has the interface Jacobian
-template <int R, bool UNI, bool QF, bool ADV, bool STOCH = false>
-__global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
-  __shared__ double ring[2][LPW_MAXW][R][LPW_NV][64];
+// EDGE (round 3): a wavefront whose strip touches no x wall and whose chunk touches no y wall takes the instantiation
+// without the ghost-line code (wave-uniform choice at kernel entry; same arithmetic for every cell it owns).  The wall
+// tests were two branches per Laplacian and four per row in EVERY row of EVERY wavefront: 0.60 -> 0.55 ms per launch at
+// 4096^2 x 6 with the tests compiled out everywhere (tools/ab_prof.py lpw_dbg), of a kernel that is issue-bound (0.545 ms
+// with no memory traffic at all)
+template <int R, bool UNI, bool QF, bool ADV, bool STOCH, bool EDGE>
+__device__ __forceinline__ void lpw_body(const LpwArgs &a, double (&ring)[2][LPW_MAXW][R][LPW_NV][64]) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // ring slot; wv +- 1 = neighbouring layers of the strip
   const int nl = a.nl, nx = a.g.nx, ny = a.g.ny;
@@ -67,7 +78,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
   const int lW = ((a.walls & WALL_W) && x0 == 0) ? 2 : -1;
   const int eL = nx - x0 + 3;
   const int lE = ((a.walls & WALL_E) && eL <= 63) ? eL : -1;
-  const bool bcx = lW >= 0 || lE >= 0;
+  const bool bcx = EDGE && (lW >= 0 || lE >= 0);
   const bool south = (a.walls & WALL_S) != 0, north = (a.walls & WALL_N) != 0;
   const bool slip = a.slip_c > 0.;
   const bool out_ok = lane >= 3 && lane <= 60 && gi < nx && strip < nstrips;
@@ -114,7 +125,11 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
   }
 
   auto ld = [&](const double *base, int j) -> double { return base[(ptrdiff_t)((a.dbg & 2) ? y0 : min(j, ny + 2)) * pitch]; };
+#ifdef MSOM_STRICT
   auto lap5 = [&](double c, double w, double e, double n, double s) -> double { return DIVC(e + w + n + s - 4 * c, D2, rD2); };
+#else
+  auto lap5 = [&](double c, double w, double e, double n, double s) -> double { return fma(-4., c, e + w + n + s) * rD2; };
+#endif
   // x walls: the ghost lane takes -dst(mirror lane) or the partial-slip value c (src(mirror) - src(ghost))
   auto xfix = [&](double raw, double so, double sw, double se) -> double {
     if (bcx) {
@@ -176,7 +191,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
     const double be = DIVC(a.beta * (p[1][0] - p[1][2]), D2x, rD2x);
     const double jd = (lower && !STOCH) ? mjac9(p, p1, D12, rD12) : 0.;
     const double zc = Z[1], tc = T[1];
-    const double lapT = DIVC(TR[0] + TL[0] + T[2] + T[0] - 4 * tc, D2, rD2);
+    const double lapT = lap5(tc, TL[0], TR[0], T[2], T[0]);
 #ifdef MSOM_STRICT
     abA[r] = adv + be; jdA[r] = jd; lapTA[r] = lapT; zcA[r] = zc; tcA[r] = tc;
     ring[b][wv][r][0][lane] = zc;
@@ -184,11 +199,11 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
     ring[b][wv][r][2][lane] = jd;
 #else
     // everything of layer l that does not need the neighbouring layers; the stretching terms share X = iRe zeta + iRe4 tmp
-    double tl = adv + be + a.iRe4 * lapT + tc * a.iRe;
-    if (l == 0) tl -= a.cs * zc + wind_row(j);
-    if (l == nl - 1) tl -= a.cb * zc;
+    double tl = fma(tc, a.iRe, fma(a.iRe4, lapT, adv + be));
+    if (l == 0) tl -= fma(a.cs, zc, wind_row(j));
+    if (l == nl - 1) tl = fma(-a.cb, zc, tl);
     tlA[r] = tl;
-    ring[b][wv][r][0][lane] = a.iRe * zc + a.iRe4 * tc;
+    ring[b][wv][r][0][lane] = fma(a.iRe, zc, a.iRe4 * tc);
     ring[b][wv][r][1][lane] = jd;
 #endif
   };
@@ -228,13 +243,18 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
     double dq = tlA[r];
     const double xc = ring[b][wv][r][0][lane];
     if (nl > 1) {
-      if (upper) dq += s0 * idh0 * ((ring[b][wv - 1][r][0][lane] - xc) - ring[b][wv - 1][r][1][lane]);
-      if (lower) dq += s1 * idh1 * ((ring[b][wv + 1][r][0][lane] - xc) + ring[b][wv][r][1][lane]);
+      if (upper) dq = fma(s0 * idh0, (ring[b][wv - 1][r][0][lane] - xc) - ring[b][wv - 1][r][1][lane], dq);
+      if (lower) dq = fma(s1 * idh1, (ring[b][wv + 1][r][0][lane] - xc) + ring[b][wv][r][1][lane], dq);
     }
 #endif
     if (QF) dq += fq;
+#ifdef MSOM_STRICT
     if (STOCH) return (qreg[r] + qsreg[r] * a.crelax + nzreg[r] * a.dts) + dq * a.dt;
     return ADV ? qreg[r] + dq * a.dt : dq;
+#else
+    if (STOCH) return fma(dq, a.dt, fma(nzreg[r], a.dts, fma(qsreg[r], a.crelax, qreg[r])));
+    return ADV ? fma(dq, a.dt, qreg[r]) : dq;
+#endif
   };
 
   // rows of the first interval start travelling before the warm-up
@@ -251,7 +271,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
     for (int k = 0; k < 6; k++) wp[k] = ld(pP, y0 - 3 + k);
     wq[0] = ld(pQ, y0 - 1); wq[1] = ld(pQ, y0);
 #pragma unroll
-    for (int k = 0; k < 6; k++) row(y0 - 6 + k, wp[k], k >= 4 ? wq[k - 4] : 0., false, true, 0, 0);
+    for (int k = 0; k < 6; k++) row(y0 - 6 + k, wp[k], k >= 4 ? wq[k - 4] : 0., false, EDGE, 0, 0);
   }
 
   // Rows past the end of a ragged chunk are computed on clamped addresses and never stored: the unrolled body has no
@@ -286,7 +306,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
     }
     if (k < nblk) {
       const int j0 = y0 + k * R;
-      const bool yedge = j0 + R + 2 > ny;  // rows j0 .. j0 + R - 1 build zeta / tmp rows up to j0 + R + 1
+      const bool yedge = EDGE && j0 + R + 2 > ny;  // rows j0 .. j0 + R - 1 build zeta / tmp rows up to j0 + R + 1
       // the inputs of the NEXT finalisation first: they are the oldest loads in flight when it starts
 #pragma unroll
       for (int r = 0; r < R; r++) {
@@ -313,7 +333,22 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
   }
 }
 
-int g_lpw_dbg = 0;  // option lpw_dbg
+template <int R, bool UNI, bool QF, bool ADV, bool STOCH = false>
+__global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
+  __shared__ double ring[2][LPW_MAXW][R][LPW_NV][64];
+  // the same geometry as lpw_body (all wavefronts of a workgroup share the chunk, hence the number of barriers)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nx = a.g.nx, ny = a.g.ny;
+  const int strip = blockIdx.x * a.NS + wv / a.nl, nstrips = (nx + LPW_W - 1) / LPW_W;
+  const int x0 = min(strip, nstrips - 1) * LPW_W, y0 = blockIdx.y * a.H, y1 = min(ny, y0 + a.H);
+  const bool xwall = ((a.walls & WALL_W) && x0 == 0) || ((a.walls & WALL_E) && nx - x0 + 3 <= 63);
+  const int nblk = (y1 - y0 + R - 1) / R;
+  const bool ywall = y0 == 0 || y0 + nblk * R + 2 > ny;
+  if (xwall || ywall || a.noedge_off) lpw_body<R, UNI, QF, ADV, STOCH, true>(a, ring);
+  else lpw_body<R, UNI, QF, ADV, STOCH, false>(a, ring);
+}
+
+int g_lpw_dbg = 0;  // option lpw_dbg: bits 1, 2 timing experiments; 4: every wavefront takes the instantiation with the ghost-line code
 
 void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq, const NatGeom &g,
                     int nl, int walls, int uniformS, const double *Su, int have_qforc, double D, double beta, double iRe, double iRe4, double cs,
@@ -323,7 +358,8 @@ void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const do
   a.q_stage = q_stage; a.noise = noise; a.crelax = crelax; a.dts = dts;
   a.psi = psi; a.S = S; a.qforc = qforc; a.wind = wind; a.q_in = q_in; a.dq = dq; a.q_out = q_out; a.dt = dt;
   extern int g_lpw_dbg;
-  a.dbg = g_lpw_dbg;
+  a.dbg = g_lpw_dbg & 3;
+  a.noedge_off = (g_lpw_dbg & 4) != 0;
   a.g = g; a.nl = nl; a.walls = walls; a.uniformS = uniformS; a.have_qforc = have_qforc;
   a.D = D; a.beta = beta; a.iRe = iRe; a.iRe4 = iRe4; a.cs = cs; a.cb = cb; a.slip_c = slip_c; a.lc = lc;
   for (int l = 0; l < MSOM_MAXNL; l++) a.Su[l] = Su ? Su[l] : 0.;

@@ -376,7 +376,7 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
 
   unsigned m0keep;
 #define MARCH_DMA(voff, base, ldsrow) \
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds0 + (unsigned)(ldsrow) * 512u) : "memory")
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds0 + (unsigned)(ldsrow) * 512u) : "memory")
   // rows of the step whose half-sweep 1 sits at byte offset ro; with them (CORR) psi of the row at natural offset no
   auto request = [&](long long ro, long long no, bool want_psi, int buf = 0) {
     asm volatile("s_mov_b32 %0, m0" : "=s"(m0keep));
@@ -407,7 +407,7 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
     asm volatile("s_mov_b32 %0, m0" : "=s"(m0keep));
 #pragma unroll
     for (int q = 0; q < ND; q++)
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voffC[q]), "s"(cb), "s"(lds0 + slotrow + (unsigned)(2 * q) * 512u) : "memory");
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voffC[q]), "s"(cb), "s"(lds0 + slotrow + (unsigned)(2 * q) * 512u) : "memory");
     asm volatile("s_mov_b32 m0, %0" ::"s"(m0keep));
   };
 
@@ -483,7 +483,7 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
       else if (n >= NREQ + NL) MARCH_VMCNT(NREQ + NL);
       else if (n >= NREQ) MARCH_VMCNT(NREQ);
       else MARCH_VMCNT(0);
-    } else if (full_prev) {
+    } else if (full_prev && !(p.dbg & 8)) {
       if constexpr (CORR) MARCH_VMCNT(NL);
       else if (p.partial) MARCH_VMCNT(NL);
       else MARCH_VMCNT(2 * NL);
@@ -551,7 +551,7 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
           const double de = PX ? xv[l] : yv, dd = PX ? yv : xv[l];   // previous step: px = 1 - PX
           v2d o;
           o.x = pa[l].x + de; o.y = pa[l].y + dd;
-          asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voffN), "v"(o), "s"(po + l * nls8) : "memory");
+          asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voffN), "v"(o), "s"(po + l * nls8) : "memory");
         }
       }
     }
@@ -599,13 +599,13 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
         char *bo = outK8 + rowoff;
         if (stK) {
 #pragma unroll
-          for (int l = 0; l < NL; l++) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voffS), "v"(x[l]), "s"(bo + l * ls8) : "memory");
+          for (int l = 0; l < NL; l++) asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" ::"v"(voffS), "v"(x[l]), "s"(bo + l * ls8) : "memory");
           issued += NL;
         }
         if (stK1) {
           bo += drp8;
 #pragma unroll
-          for (int l = 0; l < NL; l++) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voffS), "v"(W[K - 1][NW][l]), "s"(bo + l * ls8) : "memory");
+          for (int l = 0; l < NL; l++) asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" ::"v"(voffS), "v"(W[K - 1][NW][l]), "s"(bo + l * ls8) : "memory");
           issued += NL;
         }
       }

@@ -15,10 +15,25 @@
 __device__ __forceinline__ double mjac9(const double (&p)[3][3], const double (&q)[3][3], double D12, double rD12) {
 #define P(a, b) p[(b) + 1][(a) + 1]
 #define Q(a, b) q[(b) + 1][(a) + 1]
+#ifdef MSOM_STRICT
   const double s = (Q(1, 0) - Q(-1, 0)) * (P(0, 1) - P(0, -1)) + (Q(0, -1) - Q(0, 1)) * (P(1, 0) - P(-1, 0)) +
                    Q(1, 0) * (P(1, 1) - P(1, -1)) - Q(-1, 0) * (P(-1, 1) - P(-1, -1)) - Q(0, 1) * (P(1, 1) - P(-1, 1)) +
                    Q(0, -1) * (P(1, -1) - P(-1, -1)) + P(0, 1) * (Q(1, 1) - Q(-1, 1)) - P(0, -1) * (Q(1, -1) - Q(-1, -1)) -
                    P(1, 0) * (Q(1, 1) - Q(1, -1)) + P(-1, 0) * (Q(-1, 1) - Q(-1, -1));
+#else
+  // product build: the same sum as ONE explicit chain of fused multiply-adds (the terms in the order above), so that every
+  // instantiation that inlines it rounds alike whatever the compiler's contraction heuristics see around it
+  double s = (Q(1, 0) - Q(-1, 0)) * (P(0, 1) - P(0, -1));
+  s = fma(Q(0, -1) - Q(0, 1), P(1, 0) - P(-1, 0), s);
+  s = fma(Q(1, 0), P(1, 1) - P(1, -1), s);
+  s = fma(-Q(-1, 0), P(-1, 1) - P(-1, -1), s);
+  s = fma(-Q(0, 1), P(1, 1) - P(-1, 1), s);
+  s = fma(Q(0, -1), P(1, -1) - P(-1, -1), s);
+  s = fma(P(0, 1), Q(1, 1) - Q(-1, 1), s);
+  s = fma(-P(0, -1), Q(1, -1) - Q(-1, -1), s);
+  s = fma(-P(1, 0), Q(1, 1) - Q(1, -1), s);
+  s = fma(P(-1, 0), Q(-1, 1) - Q(-1, -1), s);
+#endif
 #undef P
 #undef Q
   return DIVC(s, D12, rD12);
