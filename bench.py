@@ -35,6 +35,18 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 
+TRAFFIC_PROFILE = "r03_pmc_traffic_march.json"   # FETCH_SIZE / WRITE_SIZE passes of tools/prof_pmc.sh, summarised by tools/pmc_summary.py
+
+
+def kernel_source_sha1():
+    """fingerprint of the chained-smoother source the PMC traffic figure belongs to"""
+    import hashlib
+    try:
+        return hashlib.sha1(open(os.path.join(ROOT, "msom_amd", "csrc", "kernels_march.hip"), "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
 CONFIGS = {
     "C2": dict(N=512, nl=3, stochastic=False),
     "C3": dict(N=2048, nl=3, stochastic=False),
@@ -43,9 +55,11 @@ CONFIGS = {
 }
 
 
-def cpu_baseline(nl, n_cpu=1024, steps=2):
-    """CPU oracle (plain C + OpenMP, red-black smoother) on a bounded sample: `steps` RK2 steps of the same parameter
-    set on an n_cpu^2 x nl grid; grid-point-updates/s is size-normalised.  The only place bench.py touches oracle/."""
+def cpu_baseline(nl, n_cpu=4096, steps=2):
+    """CPU oracle (plain C + OpenMP, red-black smoother, all host cores of this process) on a bounded sample of the SAME
+    workload: 1 warm-up + `steps` timed RK2 steps at the metric configuration's own size (4096^2 x 6 by default: ~3 s per
+    step on the GPU box's 16-thread share, ~1-2 min for the leg with the 14 GB of first touch).  The only place bench.py
+    touches oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     from msom_amd import workloads as wl
@@ -77,8 +91,8 @@ def cpu_baseline(nl, n_cpu=1024, steps=2):
         "unit": "grid-point-updates/s",
         "cores": orc.lib().orc_num_threads(),
         "kind": "port",
-        "sample": f"{steps} RK2 steps at {n_cpu}x{n_cpu}x{nl} fp64 (same params, red-black smoother, 1 warm-up step), "
-                  f"{dt / steps * 1e3:.0f} ms/step; a 4096^2 x 6 step of the oracle takes ~16x longer (BASELINE.md section 5)",
+        "sample": f"{steps} RK2 steps at {n_cpu}x{n_cpu}x{nl} fp64 (same params.in, same initial psi, TOLERANCE 1e-3, red-black smoother, "
+                  f"1 warm-up step), {dt / steps * 1e3:.0f} ms/step on {orc.lib().orc_num_threads()} OpenMP threads",
         "steps_per_s": steps / dt,
     }
 
@@ -219,11 +233,12 @@ class Leg:
         uniform = g.param("uniform_S") == 1.0
         sigma = 0.0 if uniform else (nl - 1) / nl
         plain_bytes = (3.0 + sigma) * w / 2.0
+        lean = "; interior chunks in the lean body march_lean" if g.param("march_lean") >= 1.0 else ""
         spec = [
-            ("march4", "k_relax_march_dma<nl,4> (4 chained red-black half-sweeps per pass, rows by LDS-DMA)", 2.5 * w, "other colour in w/2 + residual w + both colours out w"),
-            ("march_pl", "k_relax_march_dma<nl,4,PL> (bilinear prolongation + 4 chained half-sweeps: first pass of a level visit)", 1.75 * w,
+            ("march4", "k_relax_march_dma<nl,4> (4 chained red-black half-sweeps per pass, rows by LDS-DMA" + lean + ")", 2.5 * w, "other colour in w/2 + residual w + both colours out w"),
+            ("march_pl", "k_relax_march_dma<nl,4,PL> (bilinear prolongation + 4 chained half-sweeps: first pass of a level visit" + lean + ")", 1.75 * w,
              "coarse correction w/4 + residual w + last colour out w/2 (the other colour is recomputed by the next pass before anything reads it)"),
-            ("march_corr", "k_relax_march_dma<nl,4,CORR> (4 chained half-sweeps + correction psi += da: last pass of the cycle)", 3.5 * w,
+            ("march_corr", "k_relax_march_dma<nl,4,CORR> (4 chained half-sweeps + correction psi += da: last pass of the cycle" + lean + ")", 3.5 * w,
              "other colour in w/2 + residual w + psi in w + psi out w"),
             ("march3", "k_relax_march<nl,3> (3 chained half-sweeps per pass)", 2.5 * w, "as march4"),
             ("march2", "k_relax_march<nl,2>", 2.5 * w, "as march4"),
@@ -231,7 +246,8 @@ class Leg:
             ("red_prolong", "k_relax_red_prolong3 (first red half-sweep + bilinear prolongation)", 1.25 * w, "residual w/2 + coarse w/4 + red out w/2"),
             ("resid_restrict", "k_residual2<write+restrict> (pre-cycle residual + first restriction)", 3.25 * w, "psi, q in, residual out, level-1 residual out w/4"),
             ("resid_correct", "k_correct_residual (psi += da, residual max, max|u|)", 4.0 * w, "psi, da, q in, psi out"),
-            ("resid_max", "k_correct_residual<max only> (max|res|, max|u| of the corrected psi)", 2.0 * w, "psi, q in"),
+            ("resid_max", "k_resmax_march<nl> (marching max|res|, max|u| of the corrected psi)" if g.param("resmax_marching") == 1.0 else
+             "k_correct_residual<max only> (LDS-tiled max|res|, max|u| of the corrected psi)", 2.0 * w, "psi, q in"),
             ("rhs", "k_rhs_lpw (Arakawa Jacobians + beta + dissipation + drag + forcing + advance)", 3.0 * w, "psi, q_in in, q_out out"),
         ]
         out = {}
@@ -298,11 +314,17 @@ def roofline(leg, world, leg_steps=1):
     achieved = nbytes / (ms * 1e-3) / 1e9
     # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, collected with rocprofv3 --pmc in separate
     # runs and stored under profiles/); only quoted for the exact configuration it was measured on
-    traffic = None
+    traffic, traffic_source = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_march.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
         if (leg.tx, leg.ty, nl, world) == (4096, 4096, 6, 1) and uniform and dom.startswith("march"):
             traffic = pmc.get(f"traffic_bytes_per_launch_{dom}")
+            # NOT measured by this run: PMC counters need their own rocprofv3 passes (no --pmc beside tracing on this pool)
+            traffic_source = {"file": "profiles/" + TRAFFIC_PROFILE, "measured_at_commit": pmc.get("commit"), "kernel_source_sha1_then": pmc.get("kernel_source_sha1"),
+                              "kernel_source_sha1_now": kernel_source_sha1(), "how": pmc.get("what")}
+            if traffic_source["kernel_source_sha1_then"] != traffic_source["kernel_source_sha1_now"]:
+                traffic = None   # the kernel changed since the counters were read: do not quote a stale figure
+                traffic_source["stale"] = True
     except Exception:
         pass
     # SURVEY 8(d)'s accounting unit for the smoother is a red+black SWEEP = (3 + sigma) w [R a, R b, W a]; a pass of K
@@ -311,7 +333,7 @@ def roofline(leg, world, leg_steps=1):
     return {
         "bound": "hbm",
         "kernel": d["kernel"] if dom != "sweep" else f"k_relax_color_x2<{nl}> (one colour half-sweep per launch)",
-        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms, "launches_timed": d["launches_timed"],
         "half_sweeps_per_launch": K,
         "traffic_over_algorithmic": (traffic / nbytes) if traffic else None,
@@ -338,7 +360,7 @@ def main():
     ap.add_argument("--nl", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (other configs at N = 1, split grid at N > 1)")
-    ap.add_argument("--cpu-n", type=int, default=1024)
+    ap.add_argument("--cpu-n", type=int, default=0, help="grid of the cpu_baseline leg (0: the configuration's own N)")
     ap.add_argument("--opt", action="append", default=[], help="key=value library option (tuning A/B), repeatable")
     args = ap.parse_args()
 
@@ -449,7 +471,7 @@ def main():
         if extra:
             out["other_legs"] = extra
         if not args.no_cpu and world == 1:   # CPU baseline: rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(nl, n_cpu=args.cpu_n)
+            out["cpu_baseline"] = cpu_baseline(nl, n_cpu=args.cpu_n or cfg["N"])
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             out["cpu_baseline"]["variants"] = cpu_variants(nl)
         print(json.dumps(out), flush=True)

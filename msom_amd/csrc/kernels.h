@@ -94,6 +94,7 @@ void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const do
 struct CoarseLev { double *da, *res; const double *S; SplitGeom g; RelaxCoef rc; };
 struct CoarseArgs { CoarseLev lev[MGC_MAXLEV]; int n, walls, prolong_fused, lds; };
 void launch_mg_coarse(hipStream_t st, const CoarseArgs *d_args, int nrelax, int nl, int uniformS);
+size_t mg_coarse_static_lds();  // bytes of static LDS k_mg_coarse declares (its launch needs a device that grants them)
 void launch_nat_to_split(hipStream_t st, const double *nat, const NatGeom &g, double *sp, const SplitGeom &sg, int nl);
 void launch_split_to_nat(hipStream_t st, const double *sp, const SplitGeom &sg, double *nat, const NatGeom &g, int nl);
 void launch_split_pack(hipStream_t st, const double *src, double *sp, const SplitGeom &sg, int nl, int bc, int walls);

@@ -25,6 +25,42 @@
 #include "mg_inl.h"
 #include "rhs_inl.h"
 
+// Product build: no automatic contraction in this file; the fused multiply-adds of the column solve are written out in the two
+// helpers below, which every body of the pass calls (register-window kernel, LDS-DMA kernel, its lean interior body).  A
+// cell is relaxed by one body or another depending on where the chunk and tile edges fall, and left to the compiler the
+// contraction follows the code around the expression: lean and general bodies differed in the last bit
+// (tests/test_gpu_fullsize.py), which breaks "tiled = single tile, bit for bit".  The validation build never contracts.
+#pragma clang fp contract(off)
+
+// right-hand side of one cell's column system, one layer: -Delta^2 res + (W + E) + (N + S)   (msqg/poisson_layer.h:101-110)
+__device__ __forceinline__ double march_rhs(double sqD, double rs, double we, double ns) {
+#ifdef MSOM_STRICT
+  double v = -sqD * rs;
+  v += we;
+  v += ns;
+  return v;
+#else
+  return fma(-sqD, rs, we) + ns;
+#endif
+}
+// uniform-S Thomas solve with the factors of RelaxCoef (msqg/poisson_layer.h:137-146; same recurrence as relax_color_pt)
+template <int NL>
+__device__ __forceinline__ void march_thomas(double (&rhs)[NL], double (&x)[NL], const RelaxCoef &rc) {
+#ifdef MSOM_STRICT
+#pragma unroll
+  for (int l = 1; l < NL; l++) rhs[l] -= rc.w[l] * rhs[l - 1];
+  x[NL - 1] = rhs[NL - 1] * rc.it1[NL - 1];
+#pragma unroll
+  for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - rc.t2[l] * x[l + 1]) * rc.it1[l];
+#else
+#pragma unroll
+  for (int l = 1; l < NL; l++) rhs[l] = fma(-rc.w[l], rhs[l - 1], rhs[l]);
+  x[NL - 1] = rhs[NL - 1] * rc.it1[NL - 1];
+#pragma unroll
+  for (int l = NL - 2; l >= 0; l--) x[l] = fma(-rc.t2[l], x[l + 1], rhs[l]) * rc.it1[l];
+#endif
+}
+
 struct MarchArgs {
   const double *in, *res;
   double *out;
@@ -210,26 +246,16 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
 #pragma unroll
           for (int l = 0; l < NL; l++) {
             const double a = W[s - 1][1][l];
-            double v = -sqD * rs[l];
-            v += lane_above(a) + a;
-            v += W[s - 1][2][l] + W[s - 1][0][l];
-            rhs[l] = v;
+            rhs[l] = march_rhs(sqD, rs[l], lane_above(a) + a, W[s - 1][2][l] + W[s - 1][0][l]);
           }
         } else {   // even-half cells: E is the lane's own odd-half value, W the previous lane's
 #pragma unroll
           for (int l = 0; l < NL; l++) {
             const double a = W[s - 1][1][l];
-            double v = -sqD * rs[l];
-            v += a + lane_below(a);
-            v += W[s - 1][2][l] + W[s - 1][0][l];
-            rhs[l] = v;
+            rhs[l] = march_rhs(sqD, rs[l], a + lane_below(a), W[s - 1][2][l] + W[s - 1][0][l]);
           }
         }
-#pragma unroll
-        for (int l = 1; l < NL; l++) rhs[l] -= p.rc.w[l] * rhs[l - 1];
-        x[NL - 1] = rhs[NL - 1] * p.rc.it1[NL - 1];
-#pragma unroll
-        for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - p.rc.t2[l] * x[l + 1]) * p.rc.it1[l];
+        march_thomas<NL>(rhs, x, p.rc);
         // ghost columns of this colour in this row: x = -1 is an odd-half position, x = nx an even-half one
         if (wallW && px == 1) {
 #pragma unroll
@@ -571,17 +597,9 @@ __device__ __forceinline__ void march_lean(const MarchArgs &p, double (*ring)[64
       for (int l = 0; l < NL; l++) {
         const double rs = (s & 1) ? R1[(s == 3 && D1 == 3) ? RA2 : (D1 == 3 ? RA0 : 0)][l] : R2[(s == 4 && D2 == 3) ? RA2 : (D2 == 3 ? RA0 : 0)][l];
         const double a = W[s - 1][M][l];
-        double v = -sqD * rs;
-        if (PX) v += lane_above(a) + a;
-        else v += a + lane_below(a);
-        v += W[s - 1][NW][l] + W[s - 1][O][l];
-        rhs[l] = v;
+        rhs[l] = march_rhs(sqD, rs, PX ? lane_above(a) + a : a + lane_below(a), W[s - 1][NW][l] + W[s - 1][O][l]);
       }
-#pragma unroll
-      for (int l = 1; l < NL; l++) rhs[l] -= p.rc.w[l] * rhs[l - 1];
-      x[NL - 1] = rhs[NL - 1] * p.rc.it1[NL - 1];
-#pragma unroll
-      for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - p.rc.t2[l] * x[l + 1]) * p.rc.it1[l];
+      march_thomas<NL>(rhs, x, p.rc);
       if (s < K) {
 #pragma unroll
         for (int l = 0; l < NL; l++) W[s][NW][l] = x[l];
@@ -958,30 +976,20 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
         double rhs[NL], rs[NL];
 #pragma unroll
         for (int l = 0; l < NL; l++) rs[l] = (s & 1) ? R1[(s - 1) < D1 ? (s - 1) : 0][l] : R2[(s - 2) >= 0 && (s - 2) < D2 ? (s - 2) : 0][l];
-        if (px) {
+        if (px) {  // odd-half cells: W is the lane's own even-half value, E the next lane's
 #pragma unroll
           for (int l = 0; l < NL; l++) {
             const double a = W[s - 1][1][l];
-            double v = -sqD * rs[l];
-            v += lane_above(a) + a;
-            v += W[s - 1][2][l] + W[s - 1][0][l];
-            rhs[l] = v;
+            rhs[l] = march_rhs(sqD, rs[l], lane_above(a) + a, W[s - 1][2][l] + W[s - 1][0][l]);
           }
-        } else {
+        } else {   // even-half cells: E is the lane's own odd-half value, W the previous lane's
 #pragma unroll
           for (int l = 0; l < NL; l++) {
             const double a = W[s - 1][1][l];
-            double v = -sqD * rs[l];
-            v += a + lane_below(a);
-            v += W[s - 1][2][l] + W[s - 1][0][l];
-            rhs[l] = v;
+            rhs[l] = march_rhs(sqD, rs[l], a + lane_below(a), W[s - 1][2][l] + W[s - 1][0][l]);
           }
         }
-#pragma unroll
-        for (int l = 1; l < NL; l++) rhs[l] -= p.rc.w[l] * rhs[l - 1];
-        x[NL - 1] = rhs[NL - 1] * p.rc.it1[NL - 1];
-#pragma unroll
-        for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - p.rc.t2[l] * x[l + 1]) * p.rc.it1[l];
+        march_thomas<NL>(rhs, x, p.rc);
         if (wallW && px == 1) {
 #pragma unroll
           for (int l = 0; l < NL; l++) {

@@ -1291,6 +1291,8 @@ static void mg_coarse_dispatch(hipStream_t st, const CoarseArgs *d_args, int nre
   if (uniformS) hipLaunchKernelGGL((k_mg_coarse<NL, true>), dim3(1), dim3(MGC_NT), 0, st, d_args, nrelax);
   else hipLaunchKernelGGL((k_mg_coarse<NL, false>), dim3(1), dim3(MGC_NT), 0, st, d_args, nrelax);
 }
+size_t mg_coarse_static_lds() { return sizeof(double) * MGC_POOL + sizeof(MgcShared); }
+
 void launch_mg_coarse(hipStream_t st, const CoarseArgs *d_args, int nrelax, int nl, int uniformS) {
   switch (nl) {
     case 1: mg_coarse_dispatch<1>(st, d_args, nrelax, uniformS); break;

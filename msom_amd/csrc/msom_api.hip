@@ -385,14 +385,14 @@ static int exch_split_deep(msom *m, double *f, const SplitGeom &sg, double *fs, 
   if (m->nb[DIR_W] >= 0) pack(DIR_W, 0, -1, H, sg.ny + 2);
   if (m->nb[DIR_E] >= 0) pack(DIR_E, sg.nx - H, -1, H, sg.ny + 2);
   int r = comm_exchange(m->comm, x, n);
-  if (r) return r;
+  if (r) { comm_end(m); return r; }   // the compute stream is re-ordered after the communication stream on every exit
   if (m->nb[DIR_W] >= 0) launch_split_unpack_strip(cs, f, sg, nl, -H, -1, H, sg.ny + 2, comm_recvbuf(m->comm, DIR_W));
   if (m->nb[DIR_E] >= 0) launch_split_unpack_strip(cs, f, sg, nl, sg.nx, -1, H, sg.ny + 2, comm_recvbuf(m->comm, DIR_E));
   n = 0;
   const int x0 = -H, xw = sg.nx + 2 * H;
   if (m->nb[DIR_S] >= 0) pack(DIR_S, x0, 0, xw, H);
   if (m->nb[DIR_N] >= 0) pack(DIR_N, x0, sg.ny - H, xw, H);
-  if ((r = comm_exchange(m->comm, x, n))) return r;
+  if ((r = comm_exchange(m->comm, x, n))) { comm_end(m); return r; }
   if (m->nb[DIR_S] >= 0) launch_split_unpack_strip(cs, fs, hg, nl, x0, 0, xw, H, comm_recvbuf(m->comm, DIR_S));
   if (m->nb[DIR_N] >= 0) launch_split_unpack_strip(cs, fn, hg, nl, x0, 0, xw, H, comm_recvbuf(m->comm, DIR_N));
   comm_end(m);
@@ -727,6 +727,9 @@ extern "C" double msom_get_param(msom_t *m, const char *key) {
   if (!strcmp(key, "nlevels")) return m->nlev;
   if (!strcmp(key, "uniform_S")) return m->uniformS;
   if (!strcmp(key, "agg_level")) return m->agg_level;
+  // which kernels the dispatch picks for this handle (bench.py names what ran from these, not from a table)
+  if (!strcmp(key, "resmax_marching")) { extern int g_resmax_rows; return m->uniformS && m->g.nx >= 64 && m->g.ny >= 16 && g_resmax_rows >= 0; }
+  if (!strcmp(key, "march_lean")) { extern int g_march_lean; return g_march_lean; }
   auto idx = [](const char *s, int n) { const int k = atoi(s); return k >= 0 && k < n ? k : -1; };
   if (!strncmp(key, "idh0_", 5)) { const int k = idx(key + 5, MSOM_MAXNL); return k < 0 ? NAN : m->lc.idh0[k]; }
   if (!strncmp(key, "idh1_", 5)) { const int k = idx(key + 5, MSOM_MAXNL); return k < 0 ? NAN : m->lc.idh1[k]; }
@@ -907,6 +910,13 @@ static int setup_mg_coarse(msom *m) {
     k0 = k;
   }
   if (k0 < 0 || m->nlev - k0 > MGC_MAXLEV) return MSOM_OK;
+  {
+    // k_mg_coarse declares a static LDS pool sized for the 160 KB of gfx950 (MGC_POOL doubles + its bookkeeping): on a
+    // device that cannot give a workgroup that much the kernel cannot launch at all, so the levels keep one launch each
+    int dev = 0, lds_max = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || (size_t)lds_max < mg_coarse_static_lds()) return MSOM_OK;
+  }
   CoarseArgs h;
   memset(&h, 0, sizeof h);
   h.n = m->nlev - k0;
@@ -1240,7 +1250,10 @@ static void mg_cycle_levels(msom *m, int nrelax, int first_restrict) {
     launch_assemble_global(m->st, m->agg_recv, m->gres[0], m->gsg[0], nl, tg.nx, tg.ny, m->px);
     const int gtop = kg >= 0 ? kg : m->nlev - 1;  // coarsest level restricted by its own launch
     for (int k = kc + 1; k <= gtop; k++) launch_restrict(m->st, m->gres[k - 1 - kc], m->gsg[k - 1 - kc], m->gres[k - kc], m->gsg[k - kc], nl);
-    if (kg >= 0) launch_mg_coarse(m->st, m->d_cargs, nrelax, nl, m->uniformS);
+    if (kg >= 0) {
+      launch_mg_coarse(m->st, m->d_cargs, nrelax, nl, m->uniformS);
+      if (hipGetLastError() != hipSuccess && !m->sticky) m->sticky = MSOM_ERR_HIP;
+    }
     for (int k = (kg >= 0 ? kg : m->nlev) - 1; k >= kc; k--) {
       Lev L = glob_lev(m, k);
       if (k == m->nlev - 1) level_solve(m, L, nullptr, nrelax, 0);
@@ -1248,7 +1261,10 @@ static void mg_cycle_levels(msom *m, int nrelax, int first_restrict) {
     }
     // this rank's tile of the level-kc correction, with its ghost ring
     launch_extract_tile(m->st, m->gda[0], m->gsg[0], m->da[kc], tg, nl, m->ix * tg.nx, m->iy * tg.ny);
-  } else if (kg >= 0) launch_mg_coarse(m->st, m->d_cargs, nrelax, nl, m->uniformS);
+  } else if (kg >= 0) {
+    launch_mg_coarse(m->st, m->d_cargs, nrelax, nl, m->uniformS);
+    if (hipGetLastError() != hipSuccess && !m->sticky) m->sticky = MSOM_ERR_HIP;
+  }
   for (int k = (glob ? kc : (kg >= 0 ? kg : m->nlev)) - 1; k >= 0; k--) {
     Lev L = tile_lev(m, k);
     if (k == m->nlev - 1) level_solve(m, L, nullptr, nrelax, k > 0);
@@ -1567,14 +1583,15 @@ static int generate_noise_host(msom *m) {
 // the stochastic part of advance_qg (msqg/qg_stochastic.h:128-138): every other call draws new noise and uses
 // sqrt(dt)/sqrt(2), computed in float as the reference does
 static int stoch_prepare(msom *m, double dt, double *dts) {
+  // refused before any state changes: one rand() stream per process would repeat the same numbers on every tile
+  if (m->noise_mode == 0 && m->nranks > 1) {
+    msom_set_error("stochastic forcing on tiles: the serial rand() stream (noise_mode = 0) exists on a single tile only, use noise_mode = 1");
+    return MSOM_ERR_STATE;
+  }
   m->corrector_step = (m->corrector_step + 1) % 2;
   float fdts = sqrt(dt);
   if (m->corrector_step) {
     if (m->noise_mode == 0) {  // reference-exact serial rand() stream
-      if (m->nranks > 1) {  // one stream per process would repeat the same numbers on every tile
-        msom_set_error("stochastic forcing on tiles: the serial rand() stream (noise_mode = 0) exists on a single tile only, use noise_mode = 1");
-        return MSOM_ERR_STATE;
-      }
       int r = generate_noise_host(m);
       if (r) return r;
     } else  // counter-based device generator
@@ -1985,7 +2002,9 @@ static int wavelet_apply(msom *m, double *f) {
   } else {
     // levels kt .. depth 0 on the gathered top grid, on the host (a few cells), every rank the same arithmetic as the kernels:
     // s_k+1 = mean of the 4 children, w = (s - bilinear(s coarse)) sig, r = bilinear(r coarse) + w, root r = s sig
-    if (m->sticky) return m->sticky;
+    // a recorded error of THIS rank must not keep it out of the collective below (the other ranks would wait in it):
+    // gather first (whatever the block holds), report afterwards
+    const int sticky_before = m->sticky;
     const int kt = m->wv_kt, bx = m->nx >> kt, by = m->ny >> kt, nt = m->wv_nlev - kt;
     const NatGeom &gk = m->wv_g[kt];
     const double *src = kt == 0 ? f : m->wv_s[kt];
@@ -1995,6 +2014,7 @@ static int wavelet_apply(msom *m, double *f) {
                               hipMemcpyDeviceToHost, m->st));
     HIPCHK(hipStreamSynchronize(m->st));
     if ((r = wv_gather(m, mine, all))) return r;
+    if (sticky_before) return sticky_before;
     wv_assemble(m, all, nl, bx, by, top);
     std::vector<WvTop> S(nt), R(nt);
     int gx = m->wv_gx, gy = m->wv_gy;

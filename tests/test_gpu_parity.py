@@ -742,3 +742,28 @@ def test_randomised_configurations_strict_vs_oracle(seed):
     assert g.t == o.t, desc
     assert np.array_equal(g.get(F["PSI"]), o.get(orc.PSI)), desc
     assert np.array_equal(g.get(F["Q"]), o.get(orc.Q)), desc
+
+
+@pytest.mark.parametrize("nx,nl", [(128, 1), (512, 3)])
+def test_graph_replay_of_the_cycle_equals_eager_launches(nx, nl):
+    """option graph: the launches of one multigrid cycle captured into a hipGraph per (nrelax, first restriction) and replayed
+    (launch-bound grids only: no marching level).  Strict build: psi, q and mgstats equal the eager cycle step by step; the
+    captured kernels hold pointers and coefficients by value, so an option or TOLERANCE change in between must drop the
+    captured graphs (set_option -> clear_graphs) -- exercised by toggling TOLERANCE between the steps"""
+    outs = []
+    for graph in (0, 1):
+        txt = orc.double_gyre_params(nx, nl)
+        g = QG(txt, strict=True)
+        g.option("quiet", 1); g.option("graph", graph)
+        g.set(F["PSI"], orc.synthetic_psi(nl, nx, nx)); g.set_const(); g.set_tnext(float("inf"))
+        rec = []
+        for k in range(4):
+            g.option("TOLERANCE", [1e-3, 1e-9, 1e-6, 1e-9][k])   # several cycles per solve, nrelax adapts: more than one captured graph
+            g.step()
+            st = g.mgstats()
+            rec.append((g.get(F["PSI"]), g.get(F["Q"]), (st.i, st.resb, st.resa, st.nrelax)))
+        outs.append(rec)
+        g.close()
+    for a, b in zip(*outs):
+        assert a[2] == b[2]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
