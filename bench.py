@@ -141,7 +141,7 @@ def psi_fn(l, y, x):
 class Leg:
     """one model instance on this rank's tile of a (tx px) x (ty py) domain + its timed loop"""
 
-    def __init__(self, tx, ty, nl, px, py, rank, dist, cfg_n, stochastic=False, local_rank=0):
+    def __init__(self, tx, ty, nl, px, py, rank, dist, cfg_n, stochastic=False, local_rank=0, extra_params="", fr_field=False):
         from msom_amd import FIELDS as F
         from msom_amd import QG, load_library, tiling
         from msom_amd import workloads as wl
@@ -152,6 +152,7 @@ class Leg:
         extra = (f"Ny = {self.gny}\n" if self.gny != self.gnx else "")
         if stochastic:
             extra += "tr_stoch = 50\namp_stoch = 1e-5\n"
+        extra += extra_params
         params = wl.double_gyre_params(self.gnx, nl, extra=extra, L0=80.0 * self.gnx / cfg_n)
         self.params = params
         lib = load_library()
@@ -170,6 +171,14 @@ class Leg:
         g.set(F["PSI"], tiling.synthetic_tile(psi_fn, rank, px, py, nl, tx, ty))
         if stochastic:
             g.set(F["SIGMA"], np.ones((nl, ty, tx)))
+        if fr_field:
+            # a spatially varying Froude field, what frpg_<nl>l_N<N>.bas supplies (msqg/qg.h:940-984): S = (Fr / Ro)^2 per cell
+            ix, iy = rank % px, rank // px
+            x = (ix * tx + np.arange(tx) + 0.5) / self.gnx
+            y = (iy * ty + np.arange(ty) + 0.5) / self.gny
+            shape = 1.0 + 0.3 * np.outer(np.sin(2 * np.pi * y), np.cos(2 * np.pi * x))
+            if nl > 1:
+                g.set(F["FR"], np.stack([g.param(f"Fr_{l}") * shape for l in range(g.shape(F["FR"])[0])]))
         g.set_const()
         g.set_tnext(float("inf"))
         self.g = g
@@ -426,14 +435,44 @@ def main():
                     lg.g.close()
                 except Exception as e:  # noqa: BLE001
                     extra[name] = {"error": repr(e)}
+            # the metric configuration off the uniform-S / walls fast path: the doubly periodic box
+            # (sbc = -1, msqg/qg.h:842-846; tau0 = 0: a periodic box cannot absorb the mean of the wind curl) and a
+            # spatially varying Froude field (general column solver: every cell factorises its own tridiagonal system)
+            for name, kw, what in (("C4_periodic", dict(extra_params="sbc = -1\ntau0 = 0\n"), "4096x4096x6, sbc = -1 (doubly periodic), tau0 = 0"),
+                                   ("C4_general_S", dict(fr_field=True), "4096x4096x6, Fr(x, y) = Frm (1 + 0.3 sin 2 pi y cos 2 pi x): general column solver")):
+                try:
+                    c = CONFIGS["C4"]
+                    lg = Leg(c["N"], c["N"], c["nl"], 1, 1, 0, None, c["N"], local_rank=local_rank, **kw)
+                    el = lg.run(10, 3)
+                    s_ = lg.summary(10, el)
+                    ks, _, _, _ = lg.kernels()
+                    s_["kernels"] = {k: {"avg_launch_ms": v["avg_launch_ms"], "frac_hbm": v["frac_hbm"]} for k, v in ks.items()}
+                    s_["smoother_that_ran"] = next((k for k in ("march_corr", "march4", "march3", "march2", "sweep") if k in ks), None)
+                    s_["uniform_S_fast_path"] = bool(lg.g.param("uniform_S") == 1.0)
+                    s_["variant"] = what
+                    extra[name] = s_
+                    lg.g.close()
+                except Exception as e:  # noqa: BLE001
+                    extra[name] = {"error": repr(e)}
             try:
                 extra["C5_vertex_sqg"] = vertex_sqg_leg()
             except Exception as e:  # noqa: BLE001
                 extra["C5_vertex_sqg"] = {"error": repr(e)}
         elif world > 1 and not args.split and not args.tile:
             # BASELINE C4 as written: the configuration's own grid split over the ranks (2 x 4 tiles of 2048 x 1024 at N = 8)
-            try:   # an error here is the same on every rank (creation, a sticky communication error): recorded, not fatal
-                lg = Leg(cfg["N"] // px, cfg["N"] // py, nl, px, py, rank, dist, cfg["N"], stochastic=cfg["stochastic"], local_rank=local_rank)
+            try:
+                lg, err = None, None
+                try:
+                    lg = Leg(cfg["N"] // px, cfg["N"] // py, nl, px, py, rank, dist, cfg["N"], stochastic=cfg["stochastic"], local_rank=local_rank)
+                except Exception as e:  # noqa: BLE001
+                    err = e
+                # a rank that failed to create its tile must not leave the others inside the first collective of the leg:
+                # every rank learns whether all tiles exist before any of them steps
+                import torch
+                bad = torch.tensor([1.0 if err is not None else 0.0], device="cuda")
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                if float(bad.item()) > 0:
+                    raise err if err is not None else RuntimeError("another rank could not create its tile of the split layout")
                 el = lg.run(args.steps, args.warmup)
                 extra["split_global_grid"] = lg.summary(args.steps, el)
                 if rank == 0:

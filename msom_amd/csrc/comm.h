@@ -41,5 +41,6 @@ void launch_split_unpack_strip(hipStream_t st, double *f, const SplitGeom &g, in
 void launch_split_pack_faces(hipStream_t st, const double *f, const SplitGeom &g, int nl, double *const bufs[4]);
 void launch_split_unpack_faces(hipStream_t st, double *f, const SplitGeom &g, int nl, double *const bufs[4]);
 void launch_split_wall_corners(hipStream_t st, double *f, const SplitGeom &g, int nl, int walls);
+void launch_split_wrap(hipStream_t st, double *f, const SplitGeom &g, double *fs, double *fn, const SplitGeom &hg, int nl, int H, int phase);
 
 #endif

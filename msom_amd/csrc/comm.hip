@@ -396,6 +396,40 @@ void launch_split_pack_strip(hipStream_t st, const double *f, const SplitGeom &g
 void launch_split_unpack_strip(hipStream_t st, double *f, const SplitGeom &g, int nl, int i0, int j0, int w, int h, const double *buf) {
   hipLaunchKernelGGL(k_split_unpack_strip, g1(w * h * nl), dim3(256), 0, st, f, g, nl, i0, j0, w, h, buf);
 }
+// Doubly periodic domain on ONE tile (sbc = -1, msqg/qg.h:842-846): the deep halo of the chained smoother is the field's own
+// other side.  phase 0: H cells beyond the W / E edges into the row pads (all rows -1 .. ny); phase 1: H rows beyond the
+// S / N edges into the halo arrays fs / fn (geometry hg: H rows), pad columns included, so the corner regions follow;
+// phase 2: the depth-1 ghost rows / columns of the field itself with their corners (what boundary_level() leaves).
+__global__ void k_split_wrap(double *f, SplitGeom g, double *fs, double *fn, SplitGeom hg, int nl, int H, int phase) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+  if (phase == 0) {
+    const int rows = g.ny + 2;
+    if (t >= rows * H) return;
+    const int j = t / H - 1, c = t % H;
+    f[split_idx(g, l, j, -H + c)] = f[split_idx(g, l, j, g.nx - H + c)];
+    f[split_idx(g, l, j, g.nx + c)] = f[split_idx(g, l, j, c)];
+  } else if (phase == 1) {
+    const int xw = g.nx + 2 * H;
+    if (t >= xw * H) return;
+    const int r = t / xw, i = t % xw - H;
+    fs[split_idx(hg, l, r, i)] = f[split_idx(g, l, g.ny - H + r, i)];
+    fn[split_idx(hg, l, r, i)] = f[split_idx(g, l, r, i)];
+  } else {
+    const int nx = g.nx, ny = g.ny;
+    if (t < ny) {            // ghost columns of the interior rows
+      f[split_idx(g, l, t, -1)] = f[split_idx(g, l, t, nx - 1)];
+      f[split_idx(g, l, t, nx)] = f[split_idx(g, l, t, 0)];
+    } else if (t < ny + nx + 2) {   // ghost rows, corners included (the source columns -1 / nx wrap as well)
+      const int i = t - ny - 1, si = i < 0 ? nx - 1 : (i >= nx ? 0 : i);
+      f[split_idx(g, l, -1, i)] = f[split_idx(g, l, ny - 1, si)];
+      f[split_idx(g, l, ny, i)] = f[split_idx(g, l, 0, si)];
+    }
+  }
+}
+void launch_split_wrap(hipStream_t st, double *f, const SplitGeom &g, double *fs, double *fn, const SplitGeom &hg, int nl, int H, int phase) {
+  const int n = phase == 0 ? (g.ny + 2) * H : (phase == 1 ? (g.nx + 2 * H) * H : g.ny + g.nx + 2);
+  hipLaunchKernelGGL(k_split_wrap, dim3((n + 255) / 256, nl), dim3(256), 0, st, f, g, fs, fn, hg, nl, H, phase);
+}
 void launch_split_wall_corners(hipStream_t st, double *f, const SplitGeom &g, int nl, int walls) {
   hipLaunchKernelGGL(k_split_wall_corners, dim3(1), dim3(64), 0, st, f, g, nl, walls);
 }

@@ -1168,6 +1168,7 @@ int launch_relax_march(hipStream_t st, const double *in, double *out, const doub
   a.in = in; a.out = out; a.res = res; a.g = sg; a.c1 = c1; a.walls = walls; a.rc = rc; a.remap = g_march_remap; a.flip = g_march_flip; a.dbg = g_march_dbg;
   if (nl >= 7 && K > 3) return -1;  // 4 windows of 7 or 8 layers do not fit 256 VGPRs
   switch (nl) {
+    case 1: return march_dispatch<1>(st, a, K, chunk_rows);
     case 2: return march_dispatch<2>(st, a, K, chunk_rows);
     case 3: return march_dispatch<3>(st, a, K, chunk_rows);
     case 4: return march_dispatch<4>(st, a, K, chunk_rows);

@@ -703,6 +703,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   return MSOM_OK;
 }
 
+static int march_levels(msom *m);
 extern "C" double msom_get_param(msom_t *m, const char *key) {
   if (!m || !key) return NAN;
   const Params &p = m->p;
@@ -730,6 +731,7 @@ extern "C" double msom_get_param(msom_t *m, const char *key) {
   // which kernels the dispatch picks for this handle (bench.py names what ran from these, not from a table)
   if (!strcmp(key, "resmax_marching")) { extern int g_resmax_rows; return m->uniformS && m->g.nx >= 64 && m->g.ny >= 16 && g_resmax_rows >= 0; }
   if (!strcmp(key, "march_lean")) { extern int g_march_lean; return g_march_lean; }
+  if (!strcmp(key, "march_levels")) return march_levels(m);   // tile levels whose half-sweeps are chained (kernels_march.hip)
   auto idx = [](const char *s, int n) { const int k = atoi(s); return k >= 0 && k < n ? k : -1; };
   if (!strncmp(key, "idh0_", 5)) { const int k = idx(key + 5, MSOM_MAXNL); return k < 0 ? NAN : m->lc.idh0[k]; }
   if (!strncmp(key, "idh1_", 5)) { const int k = idx(key + 5, MSOM_MAXNL); return k < 0 ? NAN : m->lc.idh1[k]; }
@@ -837,7 +839,7 @@ static void make_relax_coef(msom *m, int k) {
   rc.D = m->p.L0 / (double)(m->gnx >> k);
   rc.sqD = rc.D * rc.D;
   for (int l = 0; l < nl; l++) { rc.idh0[l] = m->lc.idh0[l]; rc.idh1[l] = m->lc.idh1[l]; }
-  if (nl < 2) return;
+  if (nl < 2) { rc.it1[0] = 0.25; return; }   // one layer: plain Poisson relaxation, x = rhs / 4 (exact either way)
   double t0[MSOM_MAXNL], t1[MSOM_MAXNL], t2[MSOM_MAXNL];
   for (int l = 0; l < nl - 1; l++) {
     const double r = m->s_zero ? 0. : m->p.Frm[l] / m->p.Rom;
@@ -1075,10 +1077,20 @@ static bool block_ok(msom *m, const Lev &L) {
 // only ~2000 concurrent chunks hide (measured at nl = 6: 4096^2 1.54 -> 1.05 ms per 7 half-sweeps, 2048^2 385 -> 310 us,
 // but 1024^2 105 -> 238 us).  march = 2 forces it on every level that is wide enough (tests)
 static bool march_ok(msom *m, const Lev &L) {
-  if (!m->march || m->block_sweeps || !m->uniformS || m->nl < 2 || (m->walls & WALL_PER) || (!L.tiled && L.walls != WALL_ALL) || L.sg->nx < 512 ||
-      L.sg->ny < 64)
-    return false;
+  // round 3: one layer (no vertical coupling: the column system is x = rhs / 4) and the doubly periodic single tile (deep
+  // halo = the field's own other side, launch_split_wrap) take the pass too
+  const bool walls_ok = L.tiled || L.walls == WALL_ALL || L.walls == WALL_PER;
+  if (!m->march || m->block_sweeps || !(m->uniformS || m->nl == 1) || !walls_ok || L.sg->nx < 512 || L.sg->ny < 64) return false;
+  if (!L.tiled && L.walls == WALL_PER && L.k < 0) return false;   // gathered coarse levels keep their per-colour launches
   return m->march >= 2 || (size_t)L.sg->nx * L.sg->ny * m->nl >= ((size_t)1 << m->march_min);
+}
+static int march_levels(msom *m) {
+  int n = 0;
+  for (int k = 0; k < m->nlev && (m->agg_level < 0 || k < m->agg_level); k++) {
+    Lev L = tile_lev(m, k);
+    n += march_ok(m, L);
+  }
+  return n;
 }
 // is the prolongation coarse -> L folded into the first smoothing pass of L?
 static bool fuse_prolong(msom *m, const Lev &L, int nrelax) {
@@ -1099,9 +1111,19 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
     // Tiles: a pass reads MARCH_HALO cells / rows of its neighbours (exchanged once per pass instead of once per
     // half-sweep; the cone of dependence is re-computed, bit-identically, on both sides of the edge)
     int n = 2 * nrelax, c = 0;
+    // doubly periodic single tile: the pass sees a tile without walls whose four neighbours are the tile itself; the deep
+    // halo (pads W / E, halo arrays S / N) is filled by local copies (launch_split_wrap) where tiles exchange
+    const bool wrap = !L.tiled && (L.walls & WALL_PER);
+    const bool deep = L.tiled || wrap;
+    const int kwalls = wrap ? 0 : L.walls;
+    auto deep_halo = [&](double *f, const SplitGeom &sg, double *fs, double *fn, const SplitGeom &hgeo) {
+      if (L.tiled) STICKY(m, exch_split_deep(m, f, sg, fs, fn, hgeo, nl));
+      else { launch_split_wrap(m->st, f, sg, fs, fn, hgeo, nl, MARCH_HALO, 0); launch_split_wrap(m->st, f, sg, fs, fn, hgeo, nl, MARCH_HALO, 1); }
+    };
+    auto has_nb = [&](int dir) { return wrap || m->nb[dir] >= 0; };
     MarchHalo mh{nullptr, nullptr, nullptr, nullptr, 0, MARCH_HALO};
     SplitGeom hg = make_split(L.sg->nx, MARCH_HALO);
-    if (L.tiled) {
+    if (deep) {
       const int k = L.k;
       if (m->mh_da_s.size() < (size_t)m->nlev) {
         m->mh_da_s.assign(m->nlev, nullptr); m->mh_da_n.assign(m->nlev, nullptr); m->mh_res_s.assign(m->nlev, nullptr); m->mh_res_n.assign(m->nlev, nullptr);
@@ -1113,20 +1135,20 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
         }
       }
       mh.ls = hg.ls;
-      mh.in_s = m->nb[DIR_S] >= 0 ? m->mh_da_s[k] : nullptr; mh.in_n = m->nb[DIR_N] >= 0 ? m->mh_da_n[k] : nullptr;
-      mh.res_s = m->nb[DIR_S] >= 0 ? m->mh_res_s[k] : nullptr; mh.res_n = m->nb[DIR_N] >= 0 ? m->mh_res_n[k] : nullptr;
-      STICKY(m, exch_split_deep(m, L.res, *L.sg, m->mh_res_s[k], m->mh_res_n[k], hg, nl));  // constant during the sweeps
+      mh.in_s = has_nb(DIR_S) ? m->mh_da_s[k] : nullptr; mh.in_n = has_nb(DIR_N) ? m->mh_da_n[k] : nullptr;
+      mh.res_s = has_nb(DIR_S) ? m->mh_res_s[k] : nullptr; mh.res_n = has_nb(DIR_N) ? m->mh_res_n[k] : nullptr;
+      deep_halo(const_cast<double *>(L.res), *L.sg, m->mh_res_s[k], m->mh_res_n[k], hg);  // constant during the sweeps
     }
     const int kmax = nl >= 7 && m->march_k > 3 ? 3 : m->march_k;
     // tiles: the pass then needs MARCH_HALO cells / rows of the COARSE correction beyond the tile edges too (LDS-DMA kernel, nl <= 6)
-    const bool pl_tiled = L.tiled && coarse && coarse->k >= 0 && nl <= 6 && m->march_prolong >= 1 && coarse->sg->nx >= 2 * MARCH_HALO && coarse->sg->ny >= 2 * MARCH_HALO;
-    if (coarse && n >= 3 && kmax >= 3 && (!L.tiled || pl_tiled) && m->march_prolong) {
+    const bool pl_tiled = deep && coarse && coarse->k >= 0 && nl <= 6 && m->march_prolong >= 1 && coarse->sg->nx >= 2 * MARCH_HALO && coarse->sg->ny >= 2 * MARCH_HALO;
+    if (coarse && n >= 3 && kmax >= 3 && (!deep || pl_tiled) && m->march_prolong) {
       // whole levels: the prolongation rides in the first PASS (its input is interpolated from the coarse level on
       // the fly), so the 2 nrelax half-sweeps are 4 + 4 instead of (red + prolongation) + 4 + 3
       int K = n < kmax ? n : kmax;
       if (n - K == 1 && K > 3) K--;
       MarchHalo ch{nullptr, nullptr, nullptr, nullptr, 0, MARCH_HALO};
-      if (L.tiled) {   // deep halo of the coarse correction: pads W / E, halo arrays S / N (those of the coarse level's own passes)
+      if (deep) {   // deep halo of the coarse correction: pads W / E, halo arrays S / N (those of the coarse level's own passes)
         const int ck = coarse->k;
         SplitGeom chg = make_split(coarse->sg->nx, MARCH_HALO);
         if (!m->mh_da_s[ck]) {
@@ -1135,13 +1157,13 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
             hipMemsetAsync((*v)[ck], 0, chg.ls * nl * sizeof(double), m->st);
           }
         }
-        STICKY(m, exch_split_deep(m, *coarse->da, *coarse->sg, m->mh_da_s[ck], m->mh_da_n[ck], chg, nl));
+        deep_halo(*coarse->da, *coarse->sg, m->mh_da_s[ck], m->mh_da_n[ck], chg);
         ch.ls = chg.ls;
-        ch.in_s = m->nb[DIR_S] >= 0 ? m->mh_da_s[ck] : nullptr; ch.in_n = m->nb[DIR_N] >= 0 ? m->mh_da_n[ck] : nullptr;
+        ch.in_s = has_nb(DIR_S) ? m->mh_da_s[ck] : nullptr; ch.in_n = has_nb(DIR_N) ? m->mh_da_n[ck] : nullptr;
       }
       if (prof) prof_begin(m, m->prof_march_pl);
-      if (launch_relax_march(m->st, nullptr, *L.da_alt, L.res, *L.sg, nl, *L.rc, 0, K, L.walls, g_march_rows, L.tiled ? &mh : nullptr, *coarse->da, coarse->sg, nullptr,
-                             m->march_partial && n - K >= 1, L.tiled ? &ch : nullptr))
+      if (launch_relax_march(m->st, nullptr, *L.da_alt, L.res, *L.sg, nl, *L.rc, 0, K, kwalls, g_march_rows, deep ? &mh : nullptr, *coarse->da, coarse->sg, nullptr,
+                             m->march_partial && n - K >= 1, deep ? &ch : nullptr))
         m->sticky = MSOM_ERR_ARG;
       if (prof) prof_end(m, m->prof_march_pl);
       std::swap(*L.da, *L.da_alt);
@@ -1155,12 +1177,12 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
     while (n >= 2) {
       int K = n < kmax ? n : kmax;
       if (n - K == 1 && K > 2) K--;
-      if (L.tiled) STICKY(m, exch_split_deep(m, *L.da, *L.sg, m->mh_da_s[L.k], m->mh_da_n[L.k], hg, nl));
+      if (deep) deep_halo(*L.da, *L.sg, m->mh_da_s[L.k], m->mh_da_n[L.k], hg);
       // the very last pass of the finest level can apply the correction itself: psi_alt = psi + da (mg_solve swaps)
       const bool corr = m->corr_req && L.fine && n == K;
       MarchCorrect mc{m->f[MSOM_PSI], m->psi_alt, m->g};
       if (prof) prof_begin(m, corr ? m->prof_march_corr : m->prof_march[K]);
-      if (launch_relax_march(m->st, *L.da, *L.da_alt, L.res, *L.sg, nl, *L.rc, c, K, L.walls, g_march_rows, L.tiled ? &mh : nullptr, nullptr, nullptr,
+      if (launch_relax_march(m->st, *L.da, *L.da_alt, L.res, *L.sg, nl, *L.rc, c, K, kwalls, g_march_rows, deep ? &mh : nullptr, nullptr, nullptr,
                              corr ? &mc : nullptr, m->march_partial && n - K >= 1))
         m->sticky = MSOM_ERR_ARG;
       if (prof) prof_end(m, corr ? m->prof_march_corr : m->prof_march[K]);
@@ -1168,6 +1190,8 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
       if (corr) { m->corr_done = 1; return; }  // da of this level was consumed in registers; nothing reads it any more
       std::swap(*L.da, *L.da_alt);
     }
+    // periodic single tile: the passes wrote no ghost cell; boundary_level(da, l) = the wrapped copies, corners included
+    if (wrap) launch_split_wrap(m->st, *L.da, *L.sg, nullptr, nullptr, hg, nl, MARCH_HALO, 2);
     if (n == 1) {
       if (L.tiled) STICKY(m, exch_split(m, *L.da, *L.sg, nl, 0));
       launch_relax_color(m->st, *L.da, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, c, L.walls, L.fine);
@@ -1379,6 +1403,7 @@ static int mg_solve(msom *m, const double *b, msom_mgstats *s) {
     if (m->corr_done) {  // a_new = a + da already sits in psi_alt (last smoother pass): boundary(a), then max |res|, max |u|
       std::swap(m->f[MSOM_PSI], m->psi_alt);
       if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], m->nl, m->bc, 1));
+      else if (m->bc == BC_PERIODIC) launch_fill_periodic(m->st, m->f[MSOM_PSI], m->g, m->nl, 1);
       else launch_fill_ghost(m->st, m->f[MSOM_PSI], m->g, m->nl, m->bc, m->walls);   // the LDS-DMA pass leaves the wall ghosts to this
       residual2(m, 8, b, SC_RES1, 0);
       m->umax_ready = 1;

@@ -24,8 +24,10 @@ def run(txt, strict, nl, ny, nx, steps=2, **opts):
     opts.setdefault("uniform_S", 1)
     for k, v in opts.items():
         g.option(k, v)
-    if opts.get("march") and opts["uniform_S"] == 1 and "sbc = -1" not in txt:
+    if opts.get("march") and opts["uniform_S"] == 1 and nl > 1:
         assert g.param("uniform_S") == 1.0
+    if opts.get("march") and opts["uniform_S"] == 1:
+        assert g.param("march_levels") >= 1     # the pass really runs (an ignored option would compare a path with itself)
     for _ in range(steps):
         g.step()
     st = g.mgstats()
@@ -72,13 +74,60 @@ def test_march_against_oracle():
     assert rel(g.get(F["PSI"]), o.get(orc.PSI)) <= 1e-10
 
 
-def test_march_off_where_it_does_not_apply():
-    """periodic domain / general S field: the option is ignored (no error, same result as march = 0)"""
-    nx, ny, nl = 512, 64, 2
-    txt = orc.double_gyre_params(nx, nl, extra=f"Ny = {ny}\nsbc = -1\n")
+PERIODIC = "sbc = -1\ntau0 = 0\n"   # a periodic box cannot absorb the mean of the double-gyre wind curl
+
+
+@pytest.mark.parametrize("nx,ny,nl", [(512, 64, 2), (1024, 128, 6), (512, 512, 3), (2048, 64, 4)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_march_on_the_periodic_domain(nx, ny, nl, strict):
+    """sbc = -1 on one tile (round 3): the pass sees a tile without walls, its deep halo is the field's own other side
+    (launch_split_wrap); prolongation and correction riders included.  Equal to the half-sweep-per-launch path, whose
+    ghost cells are wrapped copies refreshed after every colour"""
+    txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else "") + PERIODIC)
+    a = run(txt, strict, nl, ny, nx, march=0)
+    b = run(txt, strict, nl, ny, nx, march=2)
+    if strict:
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    else:
+        assert rel(b[0], a[0]) <= 1e-10 and a[2][0] == b[2][0]
+
+
+@pytest.mark.parametrize("k,prolong", [(2, 0), (3, 1), (4, 2), (4, 3), (3, 3)])
+def test_march_periodic_pass_lengths_and_riders(k, prolong):
+    nx, ny, nl = 512, 128, 3
+    txt = orc.double_gyre_params(nx, nl, extra=f"Ny = {ny}\n" + PERIODIC)
     a = run(txt, True, nl, ny, nx, march=0)
-    b = run(txt, True, nl, ny, nx, march=2)
-    assert np.array_equal(a[0], b[0])
+    b = run(txt, True, nl, ny, nx, march=2, march_k=k, march_prolong=prolong & 1, march_correct=prolong >> 1)
+    assert np.array_equal(a[0], b[0]) and a[2] == b[2]
+
+
+def test_march_periodic_against_oracle():
+    """product build, periodic box, chained smoother forced on, against the CPU oracle (red-black): 4 steps at TOLERANCE 1e-12"""
+    nx, ny, nl = 512, 64, 3
+    o, g = make_pair(nx, ny, nl, strict=False, extra=PERIODIC, TOLERANCE=1e-12)
+    g.option("march", 2)
+    for _ in range(4):
+        o.step(); g.step()
+    assert rel(g.get(F["Q"]), o.get(orc.Q)) <= 1e-10
+    assert rel(g.get(F["PSI"]), o.get(orc.PSI)) <= 1e-10
+
+
+@pytest.mark.parametrize("nx,ny,extra", [(512, 64, ""), (1024, 128, ""), (512, 128, PERIODIC), (2048, 64, SLIP)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_march_with_one_layer(nx, ny, extra, strict):
+    """nl = 1 (round 3): no vertical coupling, the column system is x = rhs / 4; walls and the periodic box"""
+    txt = orc.double_gyre_params(nx, 1, extra=f"Ny = {ny}\n" + extra)
+    a = run(txt, strict, 1, ny, nx, march=0)
+    b = run(txt, strict, 1, ny, nx, march=2)
+    if strict:
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    else:
+        assert rel(b[0], a[0]) <= 1e-10 and a[2][0] == b[2][0]
+
+
+def test_march_off_where_it_does_not_apply():
+    """general S field: the option is ignored (no error, same result as march = 0)"""
+    nx, ny, nl = 512, 64, 2
     txt = orc.double_gyre_params(nx, nl, extra=f"Ny = {ny}\n")
     a = run(txt, True, nl, ny, nx, march=0, uniform_S=0)
     b = run(txt, True, nl, ny, nx, march=2, uniform_S=0)

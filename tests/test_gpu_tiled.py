@@ -547,3 +547,31 @@ def test_serial_noise_stream_is_refused_on_tiles():
 
     out = run_tiled(params, 2, 1, psi, nsteps=0, strict=False, opts={"stochastic": 1, "noise_mode": 0}, fn=step)
     assert all("noise_mode = 1" in o["extra"] for o in out), [o["extra"] for o in out]
+
+
+@pytest.mark.parametrize("px,py,tx,ty,nl", [(2, 1, 512, 64, 3), (2, 2, 512, 64, 2), (1, 2, 512, 128, 6), (2, 2, 512, 128, 6)])
+def test_march_on_periodic_tiles(px, py, tx, ty, nl):
+    """periodic tiles have no walls, so big ones take the chained smoother by default, yet every periodic
+    tiled test stayed below march_min.  Forced here (march = 2): sbc = -1 on 2 x 1 / 2 x 2 / 1 x 2 tiles through the in-process
+    transport -- both neighbours of an axis are the same rank or the tile itself, deep halos of the residual, the correction
+    and the coarse correction (prolongation rider), correction rider on the finest level (the nl = 6 cases have a coarse level
+    of >= 8 cells) -- equal to the periodic single tile bit for bit in the strict build"""
+    gnx, gny = tx * px, ty * py
+    extra = (f"Ny = {gny}\n" if gny != gnx else "") + "sbc = -1\ntau0 = 0\n" + f"MGLEVELS = {int(np.log2(min(tx, ty)))}\n"
+    params = orc.double_gyre_params(gnx, nl, extra=extra)
+    psi = orc.synthetic_psi(nl, gny, gnx)
+    opts = {"march": 2, "uniform_S": 1, "TOLERANCE": 1e-8}
+    out = run_tiled(params, px, py, psi, nsteps=2, strict=True, opts=opts)
+    g = QG(params, strict=True)
+    g.option("quiet", 1)
+    g.set(F["PSI"], psi)
+    g.set_const()
+    for k_, v_ in opts.items():
+        g.option(k_, v_)
+    g.set_tnext(float("inf"))
+    dts = [g.step() for _ in range(2)]
+    for r in range(px * py):
+        assert out[r]["dts"] == dts, r
+        assert (out[r]["st"].i, out[r]["st"].resa) == (g.mgstats().i, g.mgstats().resa)
+    assert np.array_equal(assemble(out, "q", px, py), g.get(F["Q"]))
+    assert np.array_equal(assemble(out, "psi", px, py), g.get(F["PSI"]))
