@@ -78,13 +78,13 @@ void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const 
                       double *umax_partial, double *umax_out, const NatGeom &g, int nl, int walls, int uniformS, const double *Su,
                       int have_qforc, double D, double beta, double iRe, double iRe4, double cs, double cb, double slip_c,
                       const LayerCoef &lc, int variant, const double *q_in = nullptr, double *q_out = nullptr, double dt = 0.,
-                      const RhsResid *rr = nullptr);
+                      const RhsResid *rr = nullptr, int region = 0);
 int rhs_pipe_blocks(const NatGeom &g);
 // ---- kernels_lpw.hip: same pass, one layer per wavefront, register windows + DPP (chunk_rows <= 0: automatic)
 void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq, const NatGeom &g,
                     int nl, int walls, int uniformS, const double *Su, int have_qforc, double D, double beta, double iRe, double iRe4, double cs,
                     double cb, double slip_c, const LayerCoef &lc, const double *q_in, double *q_out, double dt, int chunk_rows, int stoch = 0,
-                    const double *q_stage = nullptr, const double *noise = nullptr, double crelax = 0., double dts = 0.);
+                    const double *q_stage = nullptr, const double *noise = nullptr, double crelax = 0., double dts = 0., int region = 0);
 
 // ---- kernels_mg.hip
 // coarse part of the multigrid cycle in one launch (k_mg_coarse): lev[0] = finest of the group
@@ -128,7 +128,7 @@ struct MarchCorrect { const double *psi; double *psi_out; NatGeom g; };
 struct MarchHalo { const double *in_s, *in_n, *res_s, *res_n; size_t ls; int rows; };
 int launch_relax_march(hipStream_t st, const double *in, double *out, const double *res, const SplitGeom &sg, int nl, const RelaxCoef &rc, int c1,
                        int K, int walls, int chunk_rows = 0, const MarchHalo *h = nullptr, const double *coarse = nullptr, const SplitGeom *cg = nullptr,
-                       const MarchCorrect *mc = nullptr, int more_follow = 0, const MarchHalo *coarse_halo = nullptr);
+                       const MarchCorrect *mc = nullptr, int more_follow = 0, const MarchHalo *coarse_halo = nullptr, int region = 0);
 
 // ---- kernels_wavelet.hip
 void launch_wv_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl);

@@ -45,6 +45,7 @@ struct LpwArgs {
   NatGeom g;
   int nl, walls, uniformS, have_qforc, H, NS;  // NS strips per workgroup
   int noedge_off;  // every wavefront takes the EDGE instantiation (cross-check)
+  int region;  // tiles, overlap with the psi halo exchange: 0 all, 1 only the wavefronts that read no halo cell, 2 only the others
   int dbg;  // timing experiments only (results wrong): 1 = no stores, 2 = every load hits the chunk's first row (no HBM reads)
   double D, beta, iRe, iRe4, cs, cb, slip_c;
   LayerCoef lc;
@@ -344,6 +345,12 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
   const bool xwall = ((a.walls & WALL_W) && x0 == 0) || ((a.walls & WALL_E) && nx - x0 + 3 <= 63);
   const int nblk = (y1 - y0 + R - 1) / R;
   const bool ywall = y0 == 0 || y0 + nblk * R + 2 > ny;
+  if (a.region) {
+    // psi is read on lanes x0 - 3 .. x0 + 60 and rows y0 - 3 .. y0 + nblk R + R + 2: inside the tile = no halo cell.  All wavefronts
+    // of a workgroup share the chunk; strips differ, and a wavefront that has ended leaves the workgroup's barriers
+    const bool inner = strip < nstrips && x0 - 3 >= 0 && x0 + 60 < nx && y0 - 3 >= 0 && y0 + nblk * R + R + 2 < ny;   // (+ R: the last interval's prefetch)
+    if ((a.region == 1) != inner) return;
+  }
   if (xwall || ywall || a.noedge_off) lpw_body<R, UNI, QF, ADV, STOCH, true>(a, ring);
   else lpw_body<R, UNI, QF, ADV, STOCH, false>(a, ring);
 }
@@ -353,8 +360,9 @@ int g_lpw_dbg = 0;  // option lpw_dbg: bits 1, 2 timing experiments; 4: every wa
 void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq, const NatGeom &g,
                     int nl, int walls, int uniformS, const double *Su, int have_qforc, double D, double beta, double iRe, double iRe4, double cs,
                     double cb, double slip_c, const LayerCoef &lc, const double *q_in, double *q_out, double dt, int chunk_rows, int stoch,
-                    const double *q_stage, const double *noise, double crelax, double dts) {
+                    const double *q_stage, const double *noise, double crelax, double dts, int region) {
   LpwArgs a;
+  a.region = region;
   a.q_stage = q_stage; a.noise = noise; a.crelax = crelax; a.dts = dts;
   a.psi = psi; a.S = S; a.qforc = qforc; a.wind = wind; a.q_in = q_in; a.dq = dq; a.q_out = q_out; a.dt = dt;
   extern int g_lpw_dbg;

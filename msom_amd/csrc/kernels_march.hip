@@ -89,6 +89,7 @@ struct MarchArgs {
   int partial;  // another half-sweep follows this pass: the colour updated by half-sweep K - 1 is overwritten before anybody reads it, only the last colour is stored
   int dbg;  // timing experiments only (results wrong): 1 = no stores, 2 = no loads after the first step
   int lean; // interior chunks take the lean body (march_lean below)
+  int region;  // tiles, overlap with the deep halo exchange: 0 all chunks, 1 only those that read no halo cell, 2 only the others
   RelaxCoef rc;
 };
 
@@ -105,6 +106,11 @@ __global__ void __launch_bounds__(64, 2) k_relax_march(MarchArgs p) {
   const int kx = (int)bx * OW - HL + lane;
   const int y0 = by * p.H, y1 = min(p.g.ny, y0 + p.H);
   const int hk = p.g.hk, ny = p.g.ny, hp = p.g.hp;
+  if (p.region) {   // see k_relax_march_dma
+    const int kxa = (int)bx * OW - HL;
+    const bool inner = y0 - K >= 0 && y1 + K <= ny && kxa >= 0 && kxa + 63 <= hk - 1;
+    if ((p.region == 1) != inner) return;
+  }
   // Odd chunks march DOWN.  A colour half-sweep does not depend on the order of its cells, so the direction changes
   // nothing in the result; but two vertically adjacent chunks now reach their common edge at the same time (both at
   // their start or both at their end), so the 2 K rows they both read there are one HBM read and one L2 hit instead of
@@ -725,7 +731,12 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_relax_march_dma(MarchArgs p) {
   const bool down = p.flip && (by & 1);
   // interior chunks (no wall, no tile edge within reach of any row or lane; an even number of rows): the lean body.  All
   // wavefronts of a workgroup share by, hence the number of steps and of barriers
-  if (p.lean && y0 - K >= 0 && y1 + K <= ny && !((y1 - y0) & 1) && kx0 >= 0 && kx0 + 63 <= hk - 1) {
+  // chunks that read nothing beyond the tile: every row y0 - K .. y1 + K - 1 and every lane inside it.  On tiles they run
+  // while the deep halo exchange is in flight (region 1), the others once it has arrived (region 2); a wavefront that has
+  // ended no longer takes part in the workgroup's barriers
+  const bool inner = y0 - K >= 0 && y1 + K <= ny && kx0 >= 0 && kx0 + 63 <= hk - 1;
+  if (p.region && (p.region == 1) != inner) return;
+  if (p.lean && inner && !((y1 - y0) & 1)) {
     if constexpr (!CORR) {
       if (p.lean >= 2) { march_lean<NL, K, HL, WPB, PL, CORR, true>(p, ring, lane, kx0, y0, y1, down); return; }
     }
@@ -1055,7 +1066,12 @@ static void march_launch(hipStream_t st, Kern kern, MarchArgs a, int ow, int chu
   // L2 hits (vertically adjacent chunks reach their common edge together, march_flip), and many short workgroups even out
   // the memory traffic and the tail of the launch.  4096^2 x 6 (tools/ab_prof.py): 12-14 rows PL 0.388 / CORR 0.584 ms,
   // 16: 0.390 / 0.590, 20: 0.399 / 0.592, 26 (the round-2 rule below): 0.414 / 0.596, 32: 0.43 / 0.61, 48: 0.49 / 0.66
-  if (H == 0 && a.lean) H = 14;
+  if (H == 0 && a.lean) {
+    H = 14;
+    // levels with fewer chunks than the chip has wavefront slots (2 per SIMD): shorter chunks until one round is full -- a
+    // marching wavefront is latency-bound, so concurrency buys more than the re-computed rows cost
+    while (H > 6 && (size_t)strips * ((a.g.ny + H - 1) / H) * (nthreads / 64) < 2048) H -= 2;
+  }
   if (H <= 0) {
     // occupancy per (device, instantiation), asked once; tiled tests drive this from several host threads
     static std::mutex mu;
@@ -1148,8 +1164,10 @@ static int march_dispatch(hipStream_t st, const MarchArgs &a, int K, int rows) {
 
 // K (2..4) half-sweeps starting with colour c1, in -> out; returns -1 if (nl, K) has no instantiation
 int launch_relax_march(hipStream_t st, const double *in, double *out, const double *res, const SplitGeom &sg, int nl, const RelaxCoef &rc, int c1,
-                       int K, int walls, int chunk_rows, const MarchHalo *h, const double *coarse, const SplitGeom *cg, const MarchCorrect *mc, int more_follow, const MarchHalo *ch) {
+                       int K, int walls, int chunk_rows, const MarchHalo *h, const double *coarse, const SplitGeom *cg, const MarchCorrect *mc, int more_follow, const MarchHalo *ch,
+                       int region) {
   MarchArgs a;
+  a.region = region;
   a.coarse_s = ch ? ch->in_s : nullptr; a.coarse_n = ch ? ch->in_n : nullptr; a.chls = ch ? ch->ls : 0; a.cKR = ch ? ch->rows : 0;
   a.partial = more_follow != 0;
   a.psi = mc ? mc->psi : nullptr; a.psi_out = mc ? mc->psi_out : nullptr;

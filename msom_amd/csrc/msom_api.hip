@@ -56,6 +56,7 @@ struct msom {
   int walls = WALL_ALL;
   Comm *comm = nullptr;
   int sticky = MSOM_OK;  // first error of a void helper (exchange inside fill_bc / mg_cycle)
+  int comm_hold = 0;     // see comm_begin
   int nb[8];  // neighbour ranks by direction (DIR_*), -1 = none
   int nl = 1, nlm = 1;
   int bc = BC_DIRICHLET0;
@@ -237,11 +238,15 @@ static const int OPP[8] = {DIR_E, DIR_W, DIR_N, DIR_S, DIR_NE, DIR_NW, DIR_SE, D
 #define AXIS(dir) (dir)
 
 // communication stream <-> compute stream ordering (tiled runs)
+// comm_hold: the caller has opened the window itself (comm_begin), queues independent kernels on the compute stream while
+// the exchanges it calls run on the communication stream, and closes it (comm_end) before the kernels that need the halos
 static void comm_begin(msom *m) {  // st2 continues after everything queued on st so far
+  if (m->comm_hold) return;
   hipEventRecord(m->ev_c2x, m->st);
   hipStreamWaitEvent(m->st2, m->ev_c2x, 0);
 }
 static void comm_end(msom *m) {    // st continues after everything queued on st2 so far
+  if (m->comm_hold) return;
   hipEventRecord(m->ev_x2c, m->st2);
   hipStreamWaitEvent(m->st, m->ev_x2c, 0);
 }
@@ -1137,8 +1142,18 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
       mh.ls = hg.ls;
       mh.in_s = has_nb(DIR_S) ? m->mh_da_s[k] : nullptr; mh.in_n = has_nb(DIR_N) ? m->mh_da_n[k] : nullptr;
       mh.res_s = has_nb(DIR_S) ? m->mh_res_s[k] : nullptr; mh.res_n = has_nb(DIR_N) ? m->mh_res_n[k] : nullptr;
-      deep_halo(const_cast<double *>(L.res), *L.sg, m->mh_res_s[k], m->mh_res_n[k], hg);  // constant during the sweeps
     }
+    // Tiles (option overlap): a pass is two launches -- the chunks that read nothing beyond the tile (region 1) are queued on
+    // the compute stream FIRST, the deep halo exchanges of the pass then run beside them on the communication stream, the
+    // chunks along the tile edges (region 2) follow once the halos have arrived.  Chunks are independent (out of place), so
+    // the order changes no bit.  The residual's deep halo is constant during the sweeps: it rides with the first pass.
+    const bool ovl = L.tiled && m->overlap;
+    bool res_halo_done = !deep;
+    auto residual_halo = [&]() {
+      if (res_halo_done) return;
+      deep_halo(const_cast<double *>(L.res), *L.sg, m->mh_res_s[L.k], m->mh_res_n[L.k], hg);
+      res_halo_done = true;
+    };
     const int kmax = nl >= 7 && m->march_k > 3 ? 3 : m->march_k;
     // tiles: the pass then needs MARCH_HALO cells / rows of the COARSE correction beyond the tile edges too (LDS-DMA kernel, nl <= 6)
     const bool pl_tiled = deep && coarse && coarse->k >= 0 && nl <= 6 && m->march_prolong >= 1 && coarse->sg->nx >= 2 * MARCH_HALO && coarse->sg->ny >= 2 * MARCH_HALO;
@@ -1157,14 +1172,29 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
             hipMemsetAsync((*v)[ck], 0, chg.ls * nl * sizeof(double), m->st);
           }
         }
-        deep_halo(*coarse->da, *coarse->sg, m->mh_da_s[ck], m->mh_da_n[ck], chg);
         ch.ls = chg.ls;
         ch.in_s = has_nb(DIR_S) ? m->mh_da_s[ck] : nullptr; ch.in_n = has_nb(DIR_N) ? m->mh_da_n[ck] : nullptr;
       }
+      auto pl_pass = [&](int region) {
+        if (launch_relax_march(m->st, nullptr, *L.da_alt, L.res, *L.sg, nl, *L.rc, 0, K, kwalls, g_march_rows, deep ? &mh : nullptr, *coarse->da, coarse->sg, nullptr,
+                               m->march_partial && n - K >= 1, deep ? &ch : nullptr, region))
+          m->sticky = MSOM_ERR_ARG;
+      };
+      auto pl_halos = [&]() {
+        residual_halo();
+        if (deep) deep_halo(*coarse->da, *coarse->sg, m->mh_da_s[coarse->k], m->mh_da_n[coarse->k], make_split(coarse->sg->nx, MARCH_HALO));
+      };
       if (prof) prof_begin(m, m->prof_march_pl);
-      if (launch_relax_march(m->st, nullptr, *L.da_alt, L.res, *L.sg, nl, *L.rc, 0, K, kwalls, g_march_rows, deep ? &mh : nullptr, *coarse->da, coarse->sg, nullptr,
-                             m->march_partial && n - K >= 1, deep ? &ch : nullptr))
-        m->sticky = MSOM_ERR_ARG;
+      if (ovl) {
+        comm_begin(m); m->comm_hold = 1;
+        pl_pass(1);
+        pl_halos();
+        m->comm_hold = 0; comm_end(m);
+        pl_pass(2);
+      } else {
+        pl_halos();
+        pl_pass(0);
+      }
       if (prof) prof_end(m, m->prof_march_pl);
       std::swap(*L.da, *L.da_alt);
       n -= K; c = K & 1;
@@ -1177,14 +1207,29 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
     while (n >= 2) {
       int K = n < kmax ? n : kmax;
       if (n - K == 1 && K > 2) K--;
-      if (deep) deep_halo(*L.da, *L.sg, m->mh_da_s[L.k], m->mh_da_n[L.k], hg);
       // the very last pass of the finest level can apply the correction itself: psi_alt = psi + da (mg_solve swaps)
       const bool corr = m->corr_req && L.fine && n == K;
       MarchCorrect mc{m->f[MSOM_PSI], m->psi_alt, m->g};
+      auto pass = [&](int region) {
+        if (launch_relax_march(m->st, *L.da, *L.da_alt, L.res, *L.sg, nl, *L.rc, c, K, kwalls, g_march_rows, deep ? &mh : nullptr, nullptr, nullptr,
+                               corr ? &mc : nullptr, m->march_partial && n - K >= 1, nullptr, region))
+          m->sticky = MSOM_ERR_ARG;
+      };
+      auto halos = [&]() {
+        residual_halo();
+        if (deep) deep_halo(*L.da, *L.sg, m->mh_da_s[L.k], m->mh_da_n[L.k], hg);
+      };
       if (prof) prof_begin(m, corr ? m->prof_march_corr : m->prof_march[K]);
-      if (launch_relax_march(m->st, *L.da, *L.da_alt, L.res, *L.sg, nl, *L.rc, c, K, kwalls, g_march_rows, deep ? &mh : nullptr, nullptr, nullptr,
-                             corr ? &mc : nullptr, m->march_partial && n - K >= 1))
-        m->sticky = MSOM_ERR_ARG;
+      if (ovl) {
+        comm_begin(m); m->comm_hold = 1;
+        pass(1);
+        halos();
+        m->comm_hold = 0; comm_end(m);
+        pass(2);
+      } else {
+        halos();
+        pass(0);
+      }
       if (prof) prof_end(m, corr ? m->prof_march_corr : m->prof_march[K]);
       n -= K; c = (c + K) & 1;
       if (corr) { m->corr_done = 1; return; }  // da of this level was consumed in registers; nothing reads it any more
@@ -1497,8 +1542,9 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
 #endif
   if (m->fused && !m->have_pg && !m->have_zpg && !m->flag_topo && (!m->stochastic || stoch_fused) &&
       (m->nranks == 1 || (m->nx >= 4 && m->ny >= 4))) {
-    // tiles: the fused kernel needs psi on a 3-cell halo (zeta on 2, lap(zeta) on 1)
-    if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], nl, m->bc, 3));
+    // tiles: the fused kernel needs psi on a 3-cell halo (zeta on 2, lap(zeta) on 1).  With the one-layer-per-wavefront
+    // kernel (option overlap) the wavefronts that read no halo cell are queued first and run beside the exchange, the
+    // strips and chunks along the tile edges follow once it has arrived (each cell is written by exactly one wavefront)
     if (m->bc == BC_PERIODIC && m->nranks == 1) launch_fill_periodic(m->st, m->f[MSOM_PSI], m->g, nl, 3);
     if (!m->adv_fused) adv_out = -1;
     // the advance rides along: the pass can also emit the first residual of the inversion of q[adv_out]
@@ -1510,6 +1556,19 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
       rr.res = m->res[0]; rr.res_c = m->res[1]; rr.res_max = m->d_scal + SC_RESF; rr.bsum_partial = m->partial_rr;
       rr.sg = m->sg[0]; rr.cg = m->sg[1];
     }
+    // the psi halo exchange of a tile around the launch(es) of the pass; splittable: the kernel takes a region argument
+    auto with_psi_halo = [&](bool splittable, auto launch) {
+      if (m->nranks > 1 && m->overlap && splittable) {
+        comm_begin(m); m->comm_hold = 1;
+        launch(1);
+        STICKY(m, exch_nat(m, m->f[MSOM_PSI], nl, m->bc, 3));
+        m->comm_hold = 0; comm_end(m);
+        launch(2);
+      } else {
+        if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], nl, m->bc, 3));
+        launch(0);
+      }
+    };
     // one pass over psi: zeta, Jacobians, beta, dissipation, drag, forcing, max|u| (kernels_fused.hip)
     if (stoch_fused) {
       extern int g_rhs_dbg;
@@ -1519,20 +1578,24 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
       m->res_ready = -1;
       // the relaxation -q_stage / tau and the noise are read in the finalisation of the pass: q_out = q_in - (dt / tau) q_stage + dts n + dt dq
       prof_begin(m, m->prof_rhs);
-      launch_rhs_lpw(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, nullptr, m->g, nl, m->walls & WALL_ALL, m->uniformS,
-                     m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe, iRe4, Eks / (p.Rom * 2 * m->dhf[0]),
-                     Ekb / (p.Rom * 2 * m->dhf[nl - 1]), p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, m->f[adv_in],
-                     m->f[adv_out], adv_dt, g_rhs_dbg >> 8, 1, m->f[qfield], m->f[MSOM_NOISE], -adv_dt * p.itr_stoch, dts);
+      with_psi_halo(true, [&](int region) {
+        launch_rhs_lpw(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, nullptr, m->g, nl, m->walls & WALL_ALL, m->uniformS,
+                       m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe, iRe4, Eks / (p.Rom * 2 * m->dhf[0]),
+                       Ekb / (p.Rom * 2 * m->dhf[nl - 1]), p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, m->f[adv_in],
+                       m->f[adv_out], adv_dt, g_rhs_dbg >> 8, 1, m->f[qfield], m->f[MSOM_NOISE], -adv_dt * p.itr_stoch, dts, region);
+      });
       prof_end(m, m->prof_rhs);
       if (advanced) *advanced = 1;
       return MSOM_OK;
     }
     prof_begin(m, m->prof_rhs);
-    launch_rhs_fused(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, m->f[dqfield], nullptr,
-                     nullptr, m->g, nl, m->walls & WALL_ALL, m->uniformS, m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe,
-                     iRe4, Eks / (p.Rom * 2 * m->dhf[0]), Ekb / (p.Rom * 2 * m->dhf[nl - 1]),
-                     p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, variant, adv_out >= 0 ? m->f[adv_in] : nullptr,
-                     adv_out >= 0 ? m->f[adv_out] : nullptr, adv_dt, use_rr ? &rr : nullptr);
+    with_psi_halo(variant == 6, [&](int region) {
+      launch_rhs_fused(m->st, m->f[MSOM_PSI], m->f[MSOM_S], m->f[MSOM_QFORC], m->d_wind, m->f[dqfield], nullptr,
+                       nullptr, m->g, nl, m->walls & WALL_ALL, m->uniformS, m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe,
+                       iRe4, Eks / (p.Rom * 2 * m->dhf[0]), Ekb / (p.Rom * 2 * m->dhf[nl - 1]),
+                       p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, variant, adv_out >= 0 ? m->f[adv_in] : nullptr,
+                       adv_out >= 0 ? m->f[adv_out] : nullptr, adv_dt, use_rr ? &rr : nullptr, region);
+    });
     prof_end(m, m->prof_rhs);
     if (use_rr) m->res_ready = adv_out;
     if (advanced && adv_out >= 0) *advanced = 1;
