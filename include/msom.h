@@ -30,7 +30,9 @@ extern "C" {
 #define MSOM_ERR_COMM (-5)     /* RCCL error                                           */
 #define MSOM_ERR_STATE (-6)    /* call order violated (e.g. step before set_const)     */
 
-#define MSOM_MAXNL 8           /* layers supported by the register-resident column solver */
+#define MSOM_MAXNL 16          /* layers supported (msqg/poisson_layer.h:77 sizes its column arrays by nl) */
+#define MSOM_FASTNL 8          /* up to here: the register-resident kernels (chained smoother, one-launch coarse levels, fused
+                                  tendency pass); 9 .. MSOM_MAXNL: one kernel per reference loop, same arithmetic */
 
 /* field ids, mirroring the reference's global layer lists (msqg/qg.h:22-57) */
 enum {

@@ -595,7 +595,7 @@ void launch_residual2(hipStream_t st, int mode, const double *a, const double *d
     case 6: hipLaunchKernelGGL((k_residual2<false, true, true>), gr, block2d(), 0, st, p); break;
     case 0: hipLaunchKernelGGL((k_residual2<false, false, false>), gr, block2d(), 0, st, p); break;
     case 8:  // max |res(a)| and max |u(a)| of an a that is already corrected
-      if (uniformS && g.nx >= 64 && g.ny >= 16 && g_resmax_rows >= 0) {
+      if (uniformS && g.nx >= 64 && g.ny >= 16 && g_resmax_rows >= 0 && nl <= MSOM_FASTNL) {
         gr = launch_resmax_march(st, p, g_resmax_rows ? g_resmax_rows : 32);
       } else if (g.nx % 2 == 0 && g.nx >= CR_TW && g.ny >= CR_TR && !(p.dbg & 128)) {
         gr = dim3((g.nx + CR_TW - 1) / CR_TW, (g.ny + CR_TR - 1) / CR_TR);
@@ -1371,6 +1371,12 @@ static void relax_dispatch(hipStream_t st, const RelaxArgs &p, int uniformS, int
   }
 }
 template <int NL>
+static void relax_dispatch_wide(hipStream_t st, const RelaxArgs &p, int uniformS) {
+  dim3 gr = grid2d(p.g.hk, p.g.ny);
+  if (uniformS) hipLaunchKernelGGL((k_relax_color<NL, true, false>), gr, block2d(), 0, st, p);
+  else hipLaunchKernelGGL((k_relax_color<NL, false, false>), gr, block2d(), 0, st, p);
+}
+template <int NL>
 static void relax_ring_dispatch(hipStream_t st, const RelaxArgs &p, int uniformS) {
   const int n = 2 * p.g.hk + p.g.ny - 2;
   if (uniformS) hipLaunchKernelGGL((k_relax_ring<NL, true>), dim3((n + 255) / 256), dim3(256), 0, st, p);
@@ -1389,6 +1395,14 @@ void launch_relax_ring(hipStream_t st, double *da, const double *res, const doub
     case 6: relax_ring_dispatch<6>(st, p, uniformS); break;
     case 7: relax_ring_dispatch<7>(st, p, uniformS); break;
     case 8: relax_ring_dispatch<8>(st, p, uniformS); break;
+    case 9: relax_ring_dispatch<9>(st, p, uniformS); break;
+    case 10: relax_ring_dispatch<10>(st, p, uniformS); break;
+    case 11: relax_ring_dispatch<11>(st, p, uniformS); break;
+    case 12: relax_ring_dispatch<12>(st, p, uniformS); break;
+    case 13: relax_ring_dispatch<13>(st, p, uniformS); break;
+    case 14: relax_ring_dispatch<14>(st, p, uniformS); break;
+    case 15: relax_ring_dispatch<15>(st, p, uniformS); break;
+    case 16: relax_ring_dispatch<16>(st, p, uniformS); break;
     default: break;
   }
 }
@@ -1405,6 +1419,15 @@ void launch_relax_color(hipStream_t st, double *da, const double *res, const dou
     case 6: relax_dispatch<6>(st, p, uniformS, fine); break;
     case 7: relax_dispatch<7>(st, p, uniformS, fine); break;
     case 8: relax_dispatch<8>(st, p, uniformS, fine); break;
+    // nl > MSOM_FASTNL (round 3): the one-column-per-thread kernel only, column systems of up to MSOM_MAXNL layers in registers
+    case 9: relax_dispatch_wide<9>(st, p, uniformS); break;
+    case 10: relax_dispatch_wide<10>(st, p, uniformS); break;
+    case 11: relax_dispatch_wide<11>(st, p, uniformS); break;
+    case 12: relax_dispatch_wide<12>(st, p, uniformS); break;
+    case 13: relax_dispatch_wide<13>(st, p, uniformS); break;
+    case 14: relax_dispatch_wide<14>(st, p, uniformS); break;
+    case 15: relax_dispatch_wide<15>(st, p, uniformS); break;
+    case 16: relax_dispatch_wide<16>(st, p, uniformS); break;
     default: break;  // rejected at create time (MSOM_MAXNL)
   }
 }

@@ -734,7 +734,7 @@ extern "C" double msom_get_param(msom_t *m, const char *key) {
   if (!strcmp(key, "uniform_S")) return m->uniformS;
   if (!strcmp(key, "agg_level")) return m->agg_level;
   // which kernels the dispatch picks for this handle (bench.py names what ran from these, not from a table)
-  if (!strcmp(key, "resmax_marching")) { extern int g_resmax_rows; return m->uniformS && m->g.nx >= 64 && m->g.ny >= 16 && g_resmax_rows >= 0; }
+  if (!strcmp(key, "resmax_marching")) { extern int g_resmax_rows; return m->uniformS && m->nl <= MSOM_FASTNL && m->g.nx >= 64 && m->g.ny >= 16 && g_resmax_rows >= 0; }
   if (!strcmp(key, "march_lean")) { extern int g_march_lean; return g_march_lean; }
   if (!strcmp(key, "march_levels")) return march_levels(m);   // tile levels whose half-sweeps are chained (kernels_march.hip)
   auto idx = [](const char *s, int n) { const int k = atoi(s); return k >= 0 && k < n ? k : -1; };
@@ -906,7 +906,7 @@ static int setup_agglomeration(msom *m) {
 // this tile's own levels (single tile); levels that need halo exchanges stay on the per-kernel path
 static int setup_mg_coarse(msom *m) {
   m->mgc_first = -1;
-  if (!m->mgc_opt || m->block_sweeps || m->nlev < 1) return MSOM_OK;
+  if (!m->mgc_opt || m->block_sweeps || m->nlev < 1 || m->nl > MSOM_FASTNL) return MSOM_OK;
   const bool glob = m->agg_level >= 0;
   if (!glob && m->nranks > 1) return MSOM_OK;
   const int klo = glob ? m->agg_level : 0;
@@ -1075,7 +1075,7 @@ static Lev glob_lev(msom *m, int k) {
 // can the level use the temporally blocked smoother (k_relax_block: 2 sweeps per pass)?
 static bool block_ok(msom *m, const Lev &L) {
   const bool want = m->block_sweeps || (m->block_small && L.sg->nx <= m->block_small);
-  return want && m->uniformS && !L.tiled && !(m->walls & WALL_PER) && L.sg->nx >= 64 && L.sg->ny >= 16;
+  return want && m->uniformS && m->nl <= MSOM_FASTNL && !L.tiled && !(m->walls & WALL_PER) && L.sg->nx >= 64 && L.sg->ny >= 16;
 }
 // can the level chain its half-sweeps in registers (k_relax_march)?  One GPU (no halo exchange between half-sweeps),
 // walls, uniform S, and a level big enough to be HBM-bound: a marching wavefront pays one memory latency per row, which
@@ -1085,7 +1085,7 @@ static bool march_ok(msom *m, const Lev &L) {
   // round 3: one layer (no vertical coupling: the column system is x = rhs / 4) and the doubly periodic single tile (deep
   // halo = the field's own other side, launch_split_wrap) take the pass too
   const bool walls_ok = L.tiled || L.walls == WALL_ALL || L.walls == WALL_PER;
-  if (!m->march || m->block_sweeps || !(m->uniformS || m->nl == 1) || !walls_ok || L.sg->nx < 512 || L.sg->ny < 64) return false;
+  if (!m->march || m->block_sweeps || !(m->uniformS || m->nl == 1) || m->nl > MSOM_FASTNL || !walls_ok || L.sg->nx < 512 || L.sg->ny < 64) return false;
   if (!L.tiled && L.walls == WALL_PER && L.k < 0) return false;   // gathered coarse levels keep their per-colour launches
   return m->march >= 2 || (size_t)L.sg->nx * L.sg->ny * m->nl >= ((size_t)1 << m->march_min);
 }
@@ -1100,7 +1100,7 @@ static int march_levels(msom *m) {
 // is the prolongation coarse -> L folded into the first smoothing pass of L?
 static bool fuse_prolong(msom *m, const Lev &L, int nrelax) {
   if (block_ok(m, L) && nrelax >= 2) return true;
-  return m->prolong_fused && nrelax >= 1 && L.sg->nx >= 4 && L.sg->ny >= 4;
+  return m->prolong_fused && m->nl <= MSOM_FASTNL && nrelax >= 1 && L.sg->nx >= 4 && L.sg->ny >= 4;
 }
 
 // nrelax red-black relaxations of L.da against L.res (each followed by boundary_level).
@@ -1540,7 +1540,7 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
 #else
   const bool stoch_fused = m->stochastic && m->stoch_fused && m->adv_fused && adv_out >= 0 && m->rhs_variant == 6 && !m->rhs_resid;
 #endif
-  if (m->fused && !m->have_pg && !m->have_zpg && !m->flag_topo && (!m->stochastic || stoch_fused) &&
+  if (m->fused && m->nl <= MSOM_FASTNL && !m->have_pg && !m->have_zpg && !m->flag_topo && (!m->stochastic || stoch_fused) &&
       (m->nranks == 1 || (m->nx >= 4 && m->ny >= 4))) {
     // tiles: the fused kernel needs psi on a 3-cell halo (zeta on 2, lap(zeta) on 1).  With the one-layer-per-wavefront
     // kernel (option overlap) the wavefronts that read no halo cell are queued first and run beside the exchange, the

@@ -208,7 +208,7 @@ static int node_alloc(msomn *m) {
 }
 
 static msomn *node_create(const NodeParams &p, const char *text) {
-  if (p.nl < 1 || p.nl > MSOM_MAXNL) { msom_set_error("nl = %d outside the supported range 1..%d", p.nl, MSOM_MAXNL); return nullptr; }
+  if (p.nl < 1 || p.nl > MSOM_FASTNL) { msom_set_error("nl = %d outside the supported range 1..%d", p.nl, MSOM_FASTNL); return nullptr; }
   if (p.N < 2 || (p.N & (p.N - 1))) { msom_set_error("N = %d must be a power of two >= 2", p.N); return nullptr; }
   if (p.bc_fac == -1) { msom_set_error("bc_fac = -1 (periodic vertex grid) is not supported"); return nullptr; }
   if (p.sqg && p.nl < 2) { msom_set_error("sqg = 1 needs nl >= 2 (qg-node/sqg_baroclinic_ms.h is the multi-layer model)"); return nullptr; }

@@ -33,6 +33,22 @@ LAYERS = {
 }
 
 
+def _split_layers(nl):
+    """nl > 8 (build-defined, like the nl = 6 split of BASELINE.md): the three Verron layers cut into equal sub-layers, the
+    interface Froude numbers of the layer the upper neighbour belongs to"""
+    cnt = [max(1, round(nl * f)) for f in (0.25, 0.25)]
+    cnt.append(nl - sum(cnt))
+    dh, fr = [], []
+    for h, fr_below, c in zip((0.06, 0.14, 0.8), (0.0023669, 0.0076173, 0.0076173), cnt):
+        dh += [h / c] * c
+        fr += [fr_below] * c
+    return "[" + ",".join(f"{v:.7g}" for v in fr[:nl - 1]) + "]", "[" + ",".join(f"{v:.7g}" for v in dh) + "]"
+
+
+for _nl in range(9, 17):
+    LAYERS[_nl] = _split_layers(_nl)
+
+
 def double_gyre_params(N, nl, extra="", L0=80.0):
     """Verron double gyre with N, nl overridden; Re4 ~ Delta^-4 keeps the viscous
     clamp of msqg/qg.h:746 at DT = 0.025 for every resolution."""

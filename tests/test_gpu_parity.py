@@ -328,7 +328,7 @@ def test_error_convention():
     with pytest.raises(MsomError):
         QG("N = 48\nnl = 2\n")            # not a power of two
     with pytest.raises(MsomError):
-        QG("N = 32\nnl = 9\n")            # more layers than the column solver supports
+        QG("N = 32\nnl = 17\n")           # more layers than the column solver supports
     g = QG("N = 32\nnl = 2\nFr = [0.1]\ndh = [0.5,0.0]\nRom = 0.1\n")
     with pytest.raises(MsomError, match="thickness"):
         g.set_const()                      # reference: "thickness = 0: aborting", qg.h:990-996
@@ -671,10 +671,11 @@ def test_passive_tracers_bit_exact(nx, ny, nl, nptr, extra):
     assert np.abs(g.get(F["PTR"]) - c0).max() > 0
 
 
-@pytest.mark.parametrize("nl", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("nl", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 16])
 def test_every_supported_layer_count(nl):
     """nl = 1 ... MSOM_MAXNL: three RK2 steps at 256 x 128 (wide-level kernels, LDS-tiled correction, fused
-    tendency + advance, one-launch coarse levels), strict build bit-exact against the oracle, product build
+    tendency + advance, one-launch coarse levels; from nl = 9 on the generic column solver, one kernel per reference loop:
+    msqg/poisson_layer.h:77 sizes its column arrays by nl), strict build bit-exact against the oracle, product build
     within 1e-9."""
     nx, ny = 256, 128
     for strict in (True, False):
@@ -690,7 +691,7 @@ def test_every_supported_layer_count(nl):
 
 def test_more_layers_than_supported_is_rejected():
     from msom_amd import MsomError
-    txt = orc.double_gyre_params(32, 8).replace("nl = 8", "nl = 9")
+    txt = orc.double_gyre_params(32, 16).replace("nl = 16", "nl = 17")
     with pytest.raises(MsomError, match="supported range"):
         QG(txt)
 
