@@ -305,6 +305,28 @@ def vertex_sqg_leg(N=2048, nl=3, steps=6):
     out = {"grid": f"{N + 1}x{N + 1}x{nl} vertices", "value": (N + 1) ** 2 * nl * steps / el, "unit": "vertex-updates/s", "ms_per_step": el / steps * 1e3,
            "steps": steps, "mg_cycles_per_solve": g.mgstats().i,
            "variant": "qg-node vertex model, sqg = 1 (surface buoyancy prescribed), island mask, no-slip, 5 sweeps per level and cycle"}
+    # finest-level launches, HIP-event timed in two more (untimed) steps; bytes = compulsory HBM bytes of the launch with
+    # wv = 8 (N + 1)^2 nl: each distinct array once per read and once per write (mask: one layer; S2: row tables, no field read)
+    g.set_option("profile", 1); g.profile_reset()
+    for _ in range(2):
+        g.step(True)
+    g.set_option("profile", 0)
+    wv = 8.0 * (N + 1) ** 2 * nl
+    spec = {"relax_fine": ("k_n_relax_s<nl> (one colour half-sweep, split layout, S2 row tables)", (1.5 + 0.5 / nl) * wv, "other colour w/2 + own residual w/2 + own mask w/(2 nl) -> own colour w/2"),
+            "relax_prolong_fine": ("k_n_relax_prolong_s<nl> (prolongation + first colour half-sweep)", (1.75 + 0.5 / nl) * wv, "coarse w/4 + residual w/2 + mask -> both colours w"),
+            "residual": ("k_n_residual (residual to the split layout + max)", (3.0 + 1.0 / nl) * wv, "psi, q, mask in; residual out"),
+            "correct": ("k_n_correct (psi += da, boundary value)", 3.0 * wv, "psi, da in; psi out"),
+            "rhs": ("rhs_pv chain: mask, del2, Jacobians + beta + drag + topography, two stretch / del2 pairs, forcing, mask (11 launches)", None, "11 passes; no single compulsory figure"),
+            "coarse": ("k_n_mg_coarse<nl> (levels of <= 33^2 vertices in one launch)", None, "launch-latency bound")}
+    ks = {}
+    for slot, (name, nbytes, what) in spec.items():
+        ms, n = g.profile_read(slot)
+        if n:
+            ks[slot] = {"kernel": name, "avg_launch_ms": ms, "launches_per_step": n / 2.0, "bytes_are": what}
+            if nbytes:
+                ks[slot].update({"compulsory_bytes_per_launch": nbytes, "achieved_GBs": nbytes / (ms * 1e-3) / 1e9, "frac_hbm": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    out["kernels"] = ks
+    out["finest_level_ms_per_step"] = sum(v["avg_launch_ms"] * v["launches_per_step"] for v in ks.values())
     g.close()
     return out
 

@@ -303,6 +303,10 @@ double msomn_dt(msomn_t *m);
 int msomn_iter(msomn_t *m);
 int msomn_ke(msomn_t *m, double *ke);                                      /* event writestdout qg.c:171-178 */
 int msomn_last_mgstats(msomn_t *m, msom_mgstats *stats);
+/* measurement only (option "profile" = 1): HIP-event timing of the finest-level launches; slots "relax_fine", "relax_prolong_fine",
+ * "residual", "correct", "rhs" (the whole rhs_pv chain), "coarse" (the one-launch coarse levels) */
+int msomn_profile_read(msomn_t *m, const char *slot, double *avg_ms, long *launches);
+int msomn_profile_reset(msomn_t *m);
 int msomn_diag1d(msomn_t *m, double *out3);                                /* event write_1d_diag qg.h:361-399: ke, dissipation, forcing */
 /* NetCDF-3 output / restart of vertex fields (qg-node/netcdf_vertex_bas.h:95-424): one record of
  * "psi" and "q" appended to `path`; msomn_read_nc loads variable `varname` into `field` */

@@ -119,6 +119,8 @@ def load_library(strict=False):
         "msomn_iter": (ci, [vp]),
         "msomn_ke": (ci, [vp, _dp]),
         "msomn_last_mgstats": (ci, [vp, C.POINTER(MGStats)]),
+        "msomn_profile_read": (ci, [vp, cs, _dp, C.POINTER(C.c_long)]),
+        "msomn_profile_reset": (ci, [vp]),
         "msomn_diag1d": (ci, [vp, _dp]),
         "msomn_write_nc": (ci, [vp, cs]),
         "msomn_read_nc": (ci, [vp, ci, cs, cs, ci]),
@@ -497,6 +499,14 @@ class NodeQG:
 
     def set_option(self, key, v):
         self._chk(self.L.msomn_set_option(self.h, key.encode(), float(v)))
+
+    def profile_read(self, slot):
+        ms, n = C.c_double(), C.c_long()
+        self._chk(self.L.msomn_profile_read(self.h, slot.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def profile_reset(self):
+        self._chk(self.L.msomn_profile_reset(self.h))
 
     def layers(self, f):
         return self.L.msomn_field_layers(self.h, self._fid(f))

@@ -41,8 +41,20 @@ struct NLevel {
 };
 enum { NSC_RES = 0, NSC_UMAX = 1, NSC_KE = 2, NSC_DIAG = 3 /* 3 slots */, NSC_COUNT = 8 };
 
+// option profile: HIP-event pairs around the finest-level launches of the vertex model (bench.py's per-kernel entries)
+struct NProf {
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+  double total_ms = 0;
+  long launches = 0;
+};
+enum { NP_RELAX, NP_RELAX_PROLONG, NP_RESIDUAL, NP_CORRECT, NP_RHS, NP_COARSE, NP_COUNT };
+static const char *const NP_NAMES[NP_COUNT] = {"relax_fine", "relax_prolong_fine", "residual", "correct", "rhs", "coarse"};
+
 struct msomn {
   NodeParams p;
+  int profile = 0;
+  NProf prof[NP_COUNT];
   std::string params_text;
   int N = 0, nl = 1, nlm = 1;
   double D = 0, psi_bc = 0., iRd2_low = 0.;
@@ -82,6 +94,31 @@ struct msomn {
   int iter = 0;
   msom_mgstats mg = {0, 0, 0, 0, 0};
 };
+
+static void nprof_begin(msomn *m, int slot) {
+  if (!m->profile) return;
+  NProf &ps = m->prof[slot];
+  if (ps.used + 2 > ps.ev.size()) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    ps.ev.push_back(a); ps.ev.push_back(b);
+  }
+  hipEventRecord(ps.ev[ps.used], m->st);
+}
+static void nprof_end(msomn *m, int slot) {
+  if (!m->profile) return;
+  NProf &ps = m->prof[slot];
+  hipEventRecord(ps.ev[ps.used + 1], m->st);
+  ps.used += 2;
+}
+static void nprof_collect(msomn *m, NProf &ps) {
+  hipStreamSynchronize(m->st);
+  for (size_t k = 0; k + 1 < ps.used; k += 2) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ps.ev[k], ps.ev[k + 1]) == hipSuccess) { ps.total_ms += ms; ps.launches++; }
+  }
+  ps.used = 0;
+}
 
 static NatGeom node_geom(int n) {
   NatGeom g;
@@ -262,6 +299,7 @@ extern "C" int msomn_set_option(msomn_t *m, const char *key, double v) {
   else if (!strcmp(key, "NITERMIN")) m->nitermin = (int)v;
   else if (!strcmp(key, "DT")) m->p.DT = v;
   else if (!strcmp(key, "quiet")) m->quiet = (int)v;
+  else if (!strcmp(key, "profile")) m->profile = (int)v;
   else if (!strcmp(key, "tiled_relax")) m->tiled_relax = (int)v;
   else if (!strcmp(key, "node_pfused")) m->node_pfused = (int)v;
   else if (!strcmp(key, "s2_rows")) { m->s2_rows = (int)v; if (m->const_set) return choose_layouts(m); }
@@ -272,6 +310,25 @@ extern "C" int msomn_set_option(msomn_t *m, const char *key, double v) {
   else if (!strcmp(key, "stochastic")) m->stochastic = (int)v;
   else if (!strcmp(key, "seed")) srand((unsigned)v);
   else { msom_set_error("unknown option %s", key); return MSOM_ERR_ARG; }
+  return MSOM_OK;
+}
+// average duration of a profile slot ("relax_fine", "relax_prolong_fine", "residual", "correct", "rhs", "coarse") since the last reset
+extern "C" int msomn_profile_read(msomn_t *m, const char *slot, double *avg_ms, long *launches) {
+  if (!m || !slot) return MSOM_ERR_ARG;
+  for (int k = 0; k < NP_COUNT; k++)
+    if (!strcmp(slot, NP_NAMES[k])) {
+      nprof_collect(m, m->prof[k]);
+      if (avg_ms) *avg_ms = m->prof[k].launches ? m->prof[k].total_ms / m->prof[k].launches : 0.;
+      if (launches) *launches = m->prof[k].launches;
+      return MSOM_OK;
+    }
+  msom_set_error("unknown profile slot %s", slot);
+  return MSOM_ERR_ARG;
+}
+extern "C" int msomn_profile_reset(msomn_t *m) {
+  if (!m) return MSOM_ERR_ARG;
+  hipStreamSynchronize(m->st);
+  for (auto &ps : m->prof) { ps.used = 0; ps.total_ms = 0; ps.launches = 0; }
   return MSOM_OK;
 }
 extern "C" double msomn_get_param(msomn_t *m, const char *k) {
@@ -337,7 +394,14 @@ static int comp_q(msomn *m, const double *psi, double *q) {
 }
 
 // rhs_pv_baroclinic qg_baroclinic_ms.h:104-196 / rhs_pv_barotropic qg_barotropic.h:16-29
+static int rhs_pv_body(msomn *m, double *q, double *dq);
 static int rhs_pv(msomn *m, double *q, double *dq) {
+  nprof_begin(m, NP_RHS);
+  const int r = rhs_pv_body(m, q, dq);
+  nprof_end(m, NP_RHS);
+  return r;
+}
+static int rhs_pv_body(msomn *m, double *q, double *dq) {
   const NodeParams &p = m->p;
   const int nl = m->nl;
   const double drag = p.hEkb * p.f0 / (2 * p.dh[nl - 1]);
@@ -373,8 +437,10 @@ static int rhs_pv(msomn *m, double *q, double *dq) {
 static void relax_level(msomn *m, int k, double *da, const double *res) {
   NLevel &L = m->lev[k];
   for (int c = 0; c < 2; c++) {
+    if (k == 0) nprof_begin(m, NP_RELAX);
     if (L.sp) launch_n_relax(m->st, da, res, L.mask_s, L.S2_s, L.ga, m->nl, c, L.D, m->iRd2_low, m->lc, 1, L.S2row);
     else launch_n_relax(m->st, da, res, L.mask, L.S2, L.g, m->nl, c, L.D, m->iRd2_low, m->lc, 0, L.S2row);
+    if (k == 0) nprof_end(m, NP_RELAX);
   }
 }
 // nsweeps red-black sweeps of level k on L.da.  Wide levels: LDS-tiled passes of 2 (or 1) sweeps, out of place
@@ -386,8 +452,11 @@ static void relax_sweeps(msomn *m, int k, int nsweeps, int prolong = 0) {
     for (int s = 0; s < nsweeps; s++) {
       if (prolong && s == 0) {
         const NLevel &C = m->lev[k + 1];
+        if (k == 0) nprof_begin(m, NP_RELAX_PROLONG);
         launch_n_relax_prolong(m->st, L.da, L.res, L.mask_s, L.S2_s, L.ga, m->nl, L.D, m->iRd2_low, m->lc, L.S2row, C.da, C.ga, C.sp);
+        if (k == 0) { nprof_end(m, NP_RELAX_PROLONG); nprof_begin(m, NP_RELAX); }
         launch_n_relax(m->st, L.da, L.res, L.mask_s, L.S2_s, L.ga, m->nl, 1, L.D, m->iRd2_low, m->lc, 1, L.S2row);
+        if (k == 0) nprof_end(m, NP_RELAX);
       } else relax_level(m, k, L.da, L.res);
     }
     return;
@@ -470,8 +539,10 @@ static int vpoisson(msomn *m, double *a, const double *b) {
   const int nl = m->nl, nlev = m->nlev;
   for (mg.i = 0; mg.i < m->nitermax; mg.i++) {
     HIPCHK(hipMemsetAsync(m->d_scal + NSC_RES, 0, sizeof(double), m->st));
+    nprof_begin(m, NP_RESIDUAL);
     launch_n_residual(m->st, a, b, m->lev[0].mask, m->lev[0].S2, m->lev[0].res, m->d_scal + NSC_RES, m->g, nl, m->D, m->iRd2_low, m->lc,
                       m->lev[0].sp ? &m->lev[0].ga : nullptr, m->lev[0].S2row);
+    nprof_end(m, NP_RESIDUAL);
     double max;
     int r = read_scalar(m, NSC_RES, &max);
     if (r) return r;
@@ -497,7 +568,9 @@ static int vpoisson(msomn *m, double *a, const double *b) {
         NLevel &L = m->lev[k];
         ca.lev[k - kc] = NCoarseLev{L.da, L.res, L.mask, L.S2, L.g, L.D * L.D};
       }
+      nprof_begin(m, NP_COARSE);
       launch_n_mg_coarse(m->st, ca, mg.nrelax, nl);
+      nprof_end(m, NP_COARSE);
     } else HIPCHK(hipMemsetAsync(m->lev[nlev - 1].da, 0, m->lev[nlev - 1].g.ls * nl * sizeof(double), m->st));
     // prolongation into level kf: a launch, or (split levels) left to the first colour pass of that level
     auto prolong_into = [&](int kf) -> int {
@@ -510,7 +583,9 @@ static int vpoisson(msomn *m, double *a, const double *b) {
       relax_sweeps(m, k, mg.nrelax, pending);
       pending = k > 0 ? prolong_into(k - 1) : 0;
     }
+    nprof_begin(m, NP_CORRECT);
     launch_n_correct(m->st, a, m->lev[0].da, m->g, nl, m->psi_bc, m->lev[0].sp ? &m->lev[0].ga : nullptr);
+    nprof_end(m, NP_CORRECT);
   }
   HIPCHK(hipGetLastError());
   if (mg.resa > m->tolerance && !m->quiet)

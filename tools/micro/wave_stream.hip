@@ -47,7 +47,13 @@ __global__ void __launch_bounds__(64) k_stream(Args a) {
         const char *p = lin ? a.base + linpos : row + (size_t)s * a.sstride;
         const unsigned off = lin ? lane * ((a.mode & 4) ? 16 : 8) : offl;
         linpos += 1024;
-        if (a.mode & 4) {   // LDS-DMA, 16 bytes per lane
+        if (a.mode & 16) {  // LDS-DMA as the passes issue it: lanes 0-31 one 512-byte piece, lanes 32-63 the piece of the NEXT stream (two layer-rows per instruction)
+          unsigned keep;
+          const unsigned off2 = (unsigned)(strip * 480 + (lane & 31) * 16) ;
+          const char *p2 = p + (size_t)(lane >> 5) * a.sstride;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(p2 + off2), "s"(0), "s"(lds0 + (unsigned)(s & 7) * 1024u) : "memory");
+          s++;
+        } else if (a.mode & 4) {   // LDS-DMA, 16 bytes per lane
           unsigned keep;
           asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(off), "s"(p), "s"(lds0 + (unsigned)(s & 7) * 1024u) : "memory");
         } else {
@@ -113,8 +119,8 @@ int main(int argc, char **argv) {
   float ms;
   CHK(hipEventElapsedTime(&ms, e0, e1));
   ms /= reps;
-  const double ninstr = (double)nwaves * steps * (((mode & 1) ? nl : 0) + ((mode & 2) ? nst : 0));
-  const double bytes = (double)nwaves * steps * ((((mode & 1) ? nl : 0) * (double)((mode & 4) ? 1024 : 64 * 8)) + ((mode & 2) ? nst : 0) * 64.0 * bpl);
+  const double ninstr = (double)nwaves * steps * (((mode & 1) ? ((mode & 16) ? nl / 2 : nl) : 0) + ((mode & 2) ? nst : 0));
+  const double bytes = (double)nwaves * steps * ((((mode & 1) ? nl : 0) * (double)((mode & 16) ? 512 : (mode & 4) ? 1024 : 64 * 8)) + ((mode & 2) ? nst : 0) * 64.0 * bpl);
   printf("mode=%d nl=%d nst=%d bpl=%d cap=%d wpc=%d steps=%d waves=%d: %.4f ms  %.2f TB/s  %.2f G instr/s\n", mode, nl, nst, bpl, cap, wpc, steps, nwaves, ms,
          bytes / ms * 1e-9, ninstr / ms * 1e-6);
   return 0;
