@@ -579,6 +579,150 @@ static int n_relax_march_dispatch(hipStream_t st, const NRelaxArgs &p, const dou
   }
   return -1;
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// k_n_relax_march_s (round 3): K colour half-sweeps of a SPLIT level chained in one pass, the scheme of kernels_march.hip on
+// the vertex grid.  A colour pass of the finest level already runs at 0.63 of the HBM peak on its own bytes (bench.py,
+// C5_vertex_sqg.kernels.relax_fine), so what is left is the bytes: 10 passes of 1.67 w per cycle against ~2.7 w per 4 chained
+// half-sweeps.  Lane k holds the vertex pair (2 k, 2 k + 1) of every row -- one vertex of each colour, ALL lanes busy in every
+// half-sweep (the natural-layout kernel above kept both colours per lane and idled half of them); windows, whole-wave shifts
+// and the one-row lag between half-sweeps as in k_relax_march; the column solve is n_col_solve_vals, the very function of the
+// colour-per-launch kernels (mask, unmasked bottom sub-diagonal, one reciprocal per layer in the product build) => bit-identical.
+// Residual and mask of the updated colour are read ONCE and wait in register delay lines; S2 comes from the row tables (the
+// pass is only used when S2 does not depend on x, which is always so in the reference).  Boundary vertices (i, j = 0, n) are
+// never relaxed: the correction's boundary value is 0 before and after every colour.  Rows are software-prefetched one step ahead.
+template <int NL, int K>
+__global__ void __launch_bounds__(64) k_n_relax_march_s(NRelaxArgs p, const double *__restrict__ a_in, int H, int partial) {
+  constexpr int HL = (K + 1) / 2, OW = 64 - 2 * HL;
+  constexpr int D1 = K >= 3 ? 3 : 1, D2 = K >= 4 ? 3 : 1;
+  const int lane = threadIdx.x;
+  const int n = p.g.nx - 1;                                  // vertices 0 .. n, n even
+  const int kx = (int)blockIdx.x * OW - HL + lane;           // the lane's pair: vertices 2 kx, 2 kx + 1
+  const int y0 = blockIdx.y * H, y1 = min(n + 1, y0 + H);
+  const int hp = (p.g.pitch - 2 * MSOM_XP) >> 1;
+  const size_t ls = p.g.ls;
+  const int kxc = min(max(kx, -2), (n >> 1) + 2);            // spare slots of the halves beyond the grid: read, never used
+  const bool own = lane >= HL && lane < 64 - HL && 2 * kx <= n;
+  auto off = [&](int half, int r) -> size_t { return (size_t)(min(max(r, -1), n + 1) + MSOM_YP) * p.g.pitch + MSOM_XP + (size_t)half * hp + kxc; };
+  const int c1 = p.color, c0 = 1 - c1;                       // colours of half-sweep 1 and of the input values
+  double W[K][3][NL];
+#pragma unroll
+  for (int s = 0; s < K; s++)
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int l = 0; l < NL; l++) W[s][q][l] = 0.;
+  double R1[D1][NL], R2[D2][NL], M1[D1], M2[D2];
+#pragma unroll
+  for (int d = 0; d < D1; d++) { M1[d] = 0.;
+#pragma unroll
+    for (int l = 0; l < NL; l++) R1[d][l] = 0.; }
+#pragma unroll
+  for (int d = 0; d < D2; d++) { M2[d] = 0.;
+#pragma unroll
+    for (int l = 0; l < NL; l++) R2[d][l] = 0.; }
+  // software pipeline, PF steps deep: what step t + PF consumes is requested at the top of step t (a marching wavefront pays a
+  // memory round trip per step otherwise: 86 us per pass at 2049^2 x 3 with one step of lead whatever the chunk height);
+  // the loop is unrolled by PF so that the slot of a step is a compile-time index
+  constexpr int PF = NL <= 4 ? 3 : 2;
+  double na[PF][NL], nr1[PF][NL], nr2[PF][NL], nm1[PF], nm2[PF];
+  const int tb = y1 + K - 2;
+  auto request = [&](int t, int u) {
+    const size_t oa = off((t + 1 + c0) & 1, t + 1), o1 = off((t + c1) & 1, t), o2 = off((t - 1 + c0) & 1, t - 1);
+#pragma unroll
+    for (int l = 0; l < NL; l++) { na[u][l] = a_in[oa + l * ls]; nr1[u][l] = p.b[o1 + l * ls]; nr2[u][l] = p.b[o2 + l * ls]; }
+    nm1[u] = p.mk[o1]; nm2[u] = p.mk[o2];
+  };
+  {
+    const int ta = y0 - K + 1;
+    const size_t oA = off((ta - 1 + c0) & 1, ta - 1), oB = off((ta + c0) & 1, ta);
+#pragma unroll
+    for (int l = 0; l < NL; l++) { W[0][1][l] = a_in[oA + l * ls]; W[0][2][l] = a_in[oB + l * ls]; }
+#pragma unroll
+    for (int u = 0; u < PF; u++) request(ta + u, u);
+  }
+  for (int tt = y0 - K + 1; tt <= tb; tt += PF)
+#pragma unroll
+  for (int u = 0; u < PF; u++) {
+    const int t = tt + u;
+    if (t > tb) break;
+#pragma unroll
+    for (int s = 0; s < K; s++)
+#pragma unroll
+      for (int l = 0; l < NL; l++) { W[s][0][l] = W[s][1][l]; W[s][1][l] = W[s][2][l]; }
+#pragma unroll
+    for (int d = D1 - 1; d > 0; d--) { M1[d] = M1[d - 1];
+#pragma unroll
+      for (int l = 0; l < NL; l++) R1[d][l] = R1[d - 1][l]; }
+#pragma unroll
+    for (int d = D2 - 1; d > 0; d--) { M2[d] = M2[d - 1];
+#pragma unroll
+      for (int l = 0; l < NL; l++) R2[d][l] = R2[d - 1][l]; }
+#pragma unroll
+    for (int l = 0; l < NL; l++) { W[0][2][l] = na[u][l]; R1[0][l] = nr1[u][l]; R2[0][l] = nr2[u][l]; }
+    M1[0] = nm1[u]; M2[0] = nm2[u];
+    if (t + PF <= tb) request(t + PF, u);
+    const int px = (t + c1) & 1;                             // x parity of the vertices updated in this step (all K half-sweeps)
+#pragma unroll
+    for (int s = 1; s <= K; s++) {
+      const int r = t - (s - 1);                             // row of half-sweep s
+      const int i = 2 * kx + px;
+      double ew[NL], ns[NL], bv[NL], sv[NL], x[NL];
+      // residual / mask of this half-sweep's row: loaded in this step (slot 0) or two steps ago (slot 2 of the delay line)
+      const int i1 = (D1 == 3 && s == 3) ? 2 : 0, i2 = (D2 == 3 && s == 4) ? 2 : 0;
+      const double mv = (s & 1) ? M1[i1] : M2[i2];
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        const double a = W[s - 1][1][l];
+        ew[l] = px ? lane_above(a) + a : a + lane_below(a);  // a_E + a_W
+        ns[l] = W[s - 1][2][l] + W[s - 1][0][l];             // a_N + a_S
+        bv[l] = (s & 1) ? R1[i1][l] : R2[i2][l];
+        sv[l] = (NL > 1 && l < NL - 1) ? p.S2row[l * p.g.ny + min(max(r, 0), n)] : 0.;
+      }
+      n_col_solve_vals<NL>(p, bv, mv, sv, ew, ns, x);
+      const bool inner = r >= 1 && r <= n - 1 && i >= 1 && i <= n - 1;
+#pragma unroll
+      for (int l = 0; l < NL; l++) x[l] = inner ? x[l] : 0.;  // boundary vertices (and everything beyond the grid) stay 0
+      if (s < K) {
+#pragma unroll
+        for (int l = 0; l < NL; l++) W[s][2][l] = x[l];
+      }
+      if (s >= K - 1 && r >= y0 && r < y1 && own && i <= n && (s == K || !partial)) {
+        double *dst = p.a + off(px, r);
+#pragma unroll
+        for (int l = 0; l < NL; l++) dst[l * ls] = x[l];
+      }
+    }
+  }
+}
+template <int NL>
+static int n_relax_march_s_dispatch(hipStream_t st, const NRelaxArgs &p, const double *a_in, int K, int partial) {
+  extern int g_node_march_rows;
+  const int n = p.g.nx - 1, H = g_node_march_rows > 0 ? g_node_march_rows : 12;
+  auto launch = [&](auto kern, int ow) { hipLaunchKernelGGL(kern, dim3(((n >> 1) + 1 + ow - 1) / ow, (n + 1 + H - 1) / H), dim3(64), 0, st, p, a_in, H, partial); };
+  switch (K) {
+    case 2: launch(k_n_relax_march_s<NL, 2>, 62); return 0;
+    case 3: launch(k_n_relax_march_s<NL, 3>, 60); return 0;
+    case 4: launch(k_n_relax_march_s<NL, 4>, 60); return 0;
+  }
+  return -1;
+}
+// K (2..4) half-sweeps of a split level starting with colour `color`, a_in -> a_out (both in the split layout g); S2 by row tables
+int launch_n_relax_march_s(hipStream_t st, const double *a_in, double *a_out, const double *b, const double *mk, const NatGeom &g, int nl, int color, int K,
+                           double D, double iRd2, const LayerCoef &lc, const double *S2row, int partial) {
+  NRelaxArgs p;
+  p.a = a_out; p.b = b; p.mk = mk; p.S2 = nullptr; p.g = g; p.color = color; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc; p.S2row = S2row;
+  if (nl > 1 && !S2row) return -1;
+  switch (nl) {
+    case 1: return n_relax_march_s_dispatch<1>(st, p, a_in, K, partial);
+    case 2: return n_relax_march_s_dispatch<2>(st, p, a_in, K, partial);
+    case 3: return n_relax_march_s_dispatch<3>(st, p, a_in, K, partial);
+    case 4: return n_relax_march_s_dispatch<4>(st, p, a_in, K, partial);
+    case 5: return n_relax_march_s_dispatch<5>(st, p, a_in, K, partial);
+    case 6: return n_relax_march_s_dispatch<6>(st, p, a_in, K, partial);
+  }
+  return -1;
+}
+
 // K (2..4) half-sweeps starting with colour `color`, a_in -> a_out; returns -1 if K is not supported
 int launch_n_relax_march(hipStream_t st, const double *a_in, double *a_out, const double *b, const double *mk, const double *S2, const NatGeom &g, int nl,
                          int color, int K, double D, double iRd2, const LayerCoef &lc) {

@@ -34,7 +34,8 @@
 
 // device scalar slots
 // RES0, RES1 and UMAX[nl] are contiguous: one max all-reduce / one copy brings them to the host
-enum { SC_BSUM = 2, SC_KE = 3, SC_SCRATCH = 4, SC_RES0 = 6, SC_RES1 = 7, SC_UMAX = 8 /* MAXNL */, SC_RESF = 16 /* max|res| from the fused tendency pass */, SC_LSUM = 32 /* MAXNL */, SC_COUNT = 64 };
+enum { SC_BSUM = 2, SC_KE = 3, SC_SCRATCH = 4, SC_RES0 = 6, SC_RES1 = 7, SC_UMAX = 8 /* MAXNL */, SC_RESF = 8 + MSOM_MAXNL /* max|res| from the fused tendency pass */, SC_LSUM = 32 /* MAXNL */, SC_COUNT = 64 };
+static_assert(SC_RESF < SC_LSUM && SC_LSUM + MSOM_MAXNL <= SC_COUNT, "scalar slots overlap");
 
 static int g_dbg_interleave = 0;  // timing experiment of msom_bench_kernel (march passes)
 static int g_march_rows = 0;  // tuning knob: chunk height of k_relax_march (0 = automatic)

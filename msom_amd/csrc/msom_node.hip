@@ -48,8 +48,8 @@ struct NProf {
   double total_ms = 0;
   long launches = 0;
 };
-enum { NP_RELAX, NP_RELAX_PROLONG, NP_RESIDUAL, NP_CORRECT, NP_RHS, NP_COARSE, NP_COUNT };
-static const char *const NP_NAMES[NP_COUNT] = {"relax_fine", "relax_prolong_fine", "residual", "correct", "rhs", "coarse"};
+enum { NP_RELAX, NP_RELAX_PROLONG, NP_RESIDUAL, NP_CORRECT, NP_RHS, NP_COARSE, NP_MARCH, NP_COUNT };
+static const char *const NP_NAMES[NP_COUNT] = {"relax_fine", "relax_prolong_fine", "residual", "correct", "rhs", "coarse", "march_fine"};
 
 struct msomn {
   NodeParams p;
@@ -77,6 +77,10 @@ struct msomn {
                         // half the bytes, but in the natural layout half of the lanes idle in every half-sweep and the vertex column
                         // solve (vertex-dependent coefficients, one reciprocal per layer) is arithmetic-bound: off
   int node_pfused = 1;   // option: prolongation folded into the first colour pass of the split levels
+  int node_march_s = 2049;  // option: split levels of >= node_march_s vertices per side chain up to 4 colour half-sweeps per pass (k_n_relax_march_s,
+                            // round 3).  2049^2 x 3, 9 cycles per solve (tools/ab_node_prof.py): 3 passes of 83 us replace 9 colour launches of 33 us:
+                            // 17.3 -> 16.6 ms per step; on the 1025^2 and 513^2 levels the pass loses (17.4 / 18.4): too few chunks for a
+                            // marching wavefront; three steps of software prefetch instead of one and chunk heights 8 .. 24 change nothing
   int s2_xuniform = 0;   // set_const: S2 does not depend on x
   int s2_rows = 1;       // option: use row tables of S2 in the smoother and the residual when S2 does not depend on x
   int node_split = 65;   // option: levels of >= node_split vertices per side keep da / res / mask / S2 copies in the x-parity split layout (0: off)
@@ -215,7 +219,7 @@ static int node_alloc(msomn *m) {
     int r;
     // da and res are sized for either layout (the layout is chosen in build_levels from the option node_split)
     const size_t lsa = std::max(L.g.ls, node_geom_split(L.n).ls);
-    if ((r = dalloc(&L.da, lsa * m->nl)) || (r = dalloc(&L.da2, L.g.ls * m->nl)) || (r = dalloc(&L.res, lsa * m->nl))) return r;
+    if ((r = dalloc(&L.da, lsa * m->nl)) || (r = dalloc(&L.da2, lsa * m->nl)) || (r = dalloc(&L.res, lsa * m->nl))) return r;
     if (k == 0) { L.mask = m->f[MSOMN_MASK]; L.S2 = m->f[MSOMN_S2]; }
     else if ((r = dalloc(&L.mask, L.g.ls)) || (r = dalloc(&L.S2, L.g.ls * m->nlm))) return r;
   }
@@ -305,6 +309,7 @@ extern "C" int msomn_set_option(msomn_t *m, const char *key, double v) {
   else if (!strcmp(key, "s2_rows")) { m->s2_rows = (int)v; if (m->const_set) return choose_layouts(m); }
   else if (!strcmp(key, "node_split")) { m->node_split = (int)v; if (m->const_set) return choose_layouts(m); }
   else if (!strcmp(key, "node_march")) m->node_march = (int)v;
+  else if (!strcmp(key, "node_march_s")) m->node_march_s = (int)v;
   else if (!strcmp(key, "node_march_rows")) { extern int g_node_march_rows; g_node_march_rows = (int)v; }
   else if (!strcmp(key, "mg_coarse")) { m->mg_coarse = (int)v; if (m->const_set) return choose_layouts(m); }
   else if (!strcmp(key, "stochastic")) m->stochastic = (int)v;
@@ -448,6 +453,31 @@ static void relax_level(msomn *m, int k, double *da, const double *res) {
 // prolong = 1: the correction of level k + 1 has not been prolongated yet; the first colour pass does it on the fly (split levels)
 static void relax_sweeps(msomn *m, int k, int nsweeps, int prolong = 0) {
   NLevel &L = m->lev[k];
+  if (L.sp && m->node_march_s && L.n + 1 >= m->node_march_s && m->nl <= 6 && (m->nl == 1 || L.S2row)) {
+    // chained colour half-sweeps (round 3): the first colour may ride with the prolongation as before; the remaining 2 nsweeps - 1
+    // (or 2 nsweeps) half-sweeps go in passes of up to 4, ping-ponging between the two correction buffers; a pass that is
+    // followed by more half-sweeps stores only the colour of its last one; a single left-over half-sweep runs in place
+    int nh = 2 * nsweeps, c = 0;
+    if (prolong && nsweeps >= 1) {
+      const NLevel &C = m->lev[k + 1];
+      if (k == 0) nprof_begin(m, NP_RELAX_PROLONG);
+      launch_n_relax_prolong(m->st, L.da, L.res, L.mask_s, L.S2_s, L.ga, m->nl, L.D, m->iRd2_low, m->lc, L.S2row, C.da, C.ga, C.sp);
+      if (k == 0) nprof_end(m, NP_RELAX_PROLONG);
+      nh--; c = 1;
+    }
+    while (nh >= 2) {
+      const int kmax = m->nl <= 4 ? 4 : (m->nl <= 6 ? 3 : 2);   // windows of K stages x nl layers in registers
+      int K = nh < kmax ? nh : kmax;
+      if (nh - K == 1 && K > 2) K--;            // never leave a single half-sweep behind unless it cannot be helped
+      if (k == 0) nprof_begin(m, NP_MARCH);
+      launch_n_relax_march_s(m->st, L.da, L.da2, L.res, L.mask_s, L.ga, m->nl, c, K, L.D, m->iRd2_low, m->lc, L.S2row, nh - K >= 1);
+      if (k == 0) nprof_end(m, NP_MARCH);
+      std::swap(L.da, L.da2);
+      nh -= K; c = (c + K) & 1;
+    }
+    if (nh == 1) launch_n_relax(m->st, L.da, L.res, L.mask_s, L.S2_s, L.ga, m->nl, c, L.D, m->iRd2_low, m->lc, 1, L.S2row);
+    return;
+  }
   if (L.sp) {  // split layout: a colour pass already moves only the bytes it uses
     for (int s = 0; s < nsweeps; s++) {
       if (prolong && s == 0) {

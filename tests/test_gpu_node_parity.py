@@ -370,3 +370,44 @@ def test_split_layout_levels(nl, N, split, s2x, strict):
     for name, _ in FIELDS:
         assert np.array_equal(g2.get(name), g.get(name))
     assert (g2.mgstats().i, g2.mgstats().resa) == (g.mgstats().i, g.mgstats().resa)
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nl,N", [(1, 128), (3, 256), (6, 128), (2, 512), (3, 1024)])
+def test_chained_half_sweeps_in_the_split_layout(nl, N, strict):
+    """k_n_relax_march_s (round 3): K = 2..4 colour half-sweeps of a split level per pass, lane = vertex pair, residual and mask in
+    register delay lines, S2 by row tables.  1, 2, 3 and 5 sweeps against the oracle's colour-by-colour sweeps and against the
+    colour-per-launch kernels, level by level; then whole RK2 steps (prolongation folded into the first colour, then passes of
+    4 + 4 + one single colour) against the oracle and against the run without the pass"""
+    if nl not in orn.NODE_LAYERS:
+        orn.NODE_LAYERS[nl] = ("[" + ",".join(["%.3f" % (1.0 / nl)] * nl) + "]", "[" + ",".join(["%d." % (9000 - 900 * l) for l in range(nl - 1)]) + "]")
+    o, g = make_pair(N, nl, strict, mask=True, bc_fac=0.5, extra="gp_low = 0.02\n")
+    g.set_option("node_split", 65)
+    rng = np.random.default_rng(33)
+    for k in (0, 1):
+        n1 = (N >> k) + 1
+        if n1 < 65:
+            continue
+        da, res = rng.standard_normal((nl, n1, n1)), rng.standard_normal((nl, n1, n1))
+        da[:, 0, :] = da[:, -1, :] = da[:, :, 0] = da[:, :, -1] = 0      # the correction's boundary vertices are 0 (boundary_level)
+        for ns in (1, 2, 3, 5):
+            g.set_option("node_march_s", 65)
+            got, ref = g.dbg_relax(k, da, res, ns), o.relax(k, da, res, ns)
+            same(got, ref, strict, 1e-10)
+            g.set_option("node_march_s", 0)
+            plain = g.dbg_relax(k, da, res, ns)
+            assert np.array_equal(got, plain) or not strict
+    g.set_option("node_march_s", 65)
+    o.set_tnext(float("inf")); g.set_tnext(float("inf"))
+    for _ in range(2):
+        o.step(True); g.step(True)
+    for name, idx in FIELDS:
+        same(g.get(name), o.get(idx), strict, 1e-6)
+    o2, g2 = make_pair(N, nl, strict, mask=True, bc_fac=0.5, extra="gp_low = 0.02\n")
+    g2.set_option("node_split", 65)
+    g2.set_tnext(float("inf"))
+    for _ in range(2):
+        g2.step(True)
+    for name, _ in FIELDS:
+        assert np.array_equal(g2.get(name), g.get(name)) or not strict
+    assert g2.mgstats().i == g.mgstats().i
