@@ -125,7 +125,9 @@ __device__ __forceinline__ void lpw_body(const LpwArgs &a, double (&ring)[2][LPW
     pnext[r] = qnext[r] = qreg[r] = fqreg[r] = 0.;
   }
 
-  auto ld = [&](const double *base, int j) -> double { return base[(ptrdiff_t)((a.dbg & 2) ? y0 : min(j, ny + 2)) * pitch]; };
+  // EDGE = false: every row the wavefront touches, the last interval's prefetch included, lies inside the padded layer: no clamps,
+  // so that the row offsets are plain induction variables
+  auto ld = [&](const double *base, int j) -> double { return base[(ptrdiff_t)((a.dbg & 2) ? y0 : (EDGE ? min(j, ny + 2) : j)) * pitch]; };
 #ifdef MSOM_STRICT
   auto lap5 = [&](double c, double w, double e, double n, double s) -> double { return DIVC(e + w + n + s - 4 * c, D2, rD2); };
 #else
@@ -311,7 +313,7 @@ __device__ __forceinline__ void lpw_body(const LpwArgs &a, double (&ring)[2][LPW
       // the inputs of the NEXT finalisation first: they are the oldest loads in flight when it starts
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        const size_t c = nat_idx(a.g, l, (a.dbg & 2) ? y0 : min(j0 + r, ny - 1), gic);
+        const size_t c = nat_idx(a.g, l, (a.dbg & 2) ? y0 : (EDGE ? min(j0 + r, ny - 1) : j0 + r), gic);
         if (ADV) qreg[r] = a.q_in[c];
         if (QF) fqreg[r] = a.qforc[c];
         if (STOCH) { qsreg[r] = a.q_stage[c]; nzreg[r] = a.noise[c]; }
@@ -344,7 +346,7 @@ __global__ void __launch_bounds__(64 * LPW_MAXW) k_rhs_lpw(LpwArgs a) {
   const int x0 = min(strip, nstrips - 1) * LPW_W, y0 = blockIdx.y * a.H, y1 = min(ny, y0 + a.H);
   const bool xwall = ((a.walls & WALL_W) && x0 == 0) || ((a.walls & WALL_E) && nx - x0 + 3 <= 63);
   const int nblk = (y1 - y0 + R - 1) / R;
-  const bool ywall = y0 == 0 || y0 + nblk * R + 2 > ny;
+  const bool ywall = y0 == 0 || y0 + nblk * R + R > ny;   // (+ R: the rows the last interval prefetches stay inside the pad rows)
   if (a.region) {
     // psi is read on lanes x0 - 3 .. x0 + 60 and rows y0 - 3 .. y0 + nblk R + R + 2: inside the tile = no halo cell.  All wavefronts
     // of a workgroup share the chunk; strips differ, and a wavefront that has ended leaves the workgroup's barriers
