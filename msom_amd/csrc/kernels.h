@@ -78,13 +78,14 @@ void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const 
                       double *umax_partial, double *umax_out, const NatGeom &g, int nl, int walls, int uniformS, const double *Su,
                       int have_qforc, double D, double beta, double iRe, double iRe4, double cs, double cb, double slip_c,
                       const LayerCoef &lc, int variant, const double *q_in = nullptr, double *q_out = nullptr, double dt = 0.,
-                      const RhsResid *rr = nullptr, int region = 0);
+                      const RhsResid *rr = nullptr, int region = 0, const double *dt_ptr = nullptr);
 int rhs_pipe_blocks(const NatGeom &g);
 // ---- kernels_lpw.hip: same pass, one layer per wavefront, register windows + DPP (chunk_rows <= 0: automatic)
 void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq, const NatGeom &g,
                     int nl, int walls, int uniformS, const double *Su, int have_qforc, double D, double beta, double iRe, double iRe4, double cs,
                     double cb, double slip_c, const LayerCoef &lc, const double *q_in, double *q_out, double dt, int chunk_rows, int stoch = 0,
-                    const double *q_stage = nullptr, const double *noise = nullptr, double crelax = 0., double dts = 0., int region = 0);
+                    const double *q_stage = nullptr, const double *noise = nullptr, double crelax = 0., double dts = 0., int region = 0,
+                    const double *dt_ptr = nullptr);
 
 // ---- kernels_mg.hip
 // coarse part of the multigrid cycle in one launch (k_mg_coarse): lev[0] = finest of the group

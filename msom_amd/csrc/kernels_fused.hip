@@ -642,11 +642,11 @@ int rhs_fused_blocks(const NatGeom &g) { return ((g.nx + FTX - 1) / FTX) * ((g.n
 void launch_rhs_fused(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq,
                       double *umax_partial, double *umax_out, const NatGeom &g, int nl, int walls, int uniformS, const double *Su,
                       int have_qforc, double D, double beta, double iRe, double iRe4, double cs, double cb, double slip_c,
-                      const LayerCoef &lc, int variant, const double *q_in, double *q_out, double dt, const RhsResid *rr, int region) {
+                      const LayerCoef &lc, int variant, const double *q_in, double *q_out, double dt, const RhsResid *rr, int region, const double *dt_ptr) {
   extern int g_rhs_dbg;
   if (variant == 6) {
     launch_rhs_lpw(st, psi, S, qforc, wind, dq, g, nl, walls, uniformS, Su, have_qforc, D, beta, iRe, iRe4, cs, cb, slip_c, lc, q_in, q_out, dt,
-                   g_rhs_dbg >> 8, 0, nullptr, nullptr, 0., 0., region);  // tuning: rhs_dbg = rows << 8 overrides the chunk height
+                   g_rhs_dbg >> 8, 0, nullptr, nullptr, 0., 0., region, dt_ptr);  // tuning: rhs_dbg = rows << 8 overrides the chunk height
     return;
   }
   RhsArgs a;

@@ -42,6 +42,7 @@ struct LpwArgs {
   double crelax, dts;
   double *dq, *q_out;  // q_out != 0: q_out = q_in + dt * dq (msqg/qg.h:602), dq not stored
   double dt;
+  const double *dt_ptr;  // non-null: dt is read from device memory (written by k_step_dt while the host has not seen max|u| yet)
   NatGeom g;
   int nl, walls, uniformS, have_qforc, H, NS;  // NS strips per workgroup
   int noedge_off;  // every wavefront takes the EDGE instantiation (cross-check)
@@ -73,6 +74,7 @@ __device__ __forceinline__ void lpw_body(const LpwArgs &a, double (&ring)[2][LPW
   const int strip = blockIdx.x * a.NS + wv / nl, nstrips = (nx + LPW_W - 1) / LPW_W;
   const int x0 = min(strip, nstrips - 1) * LPW_W, y0 = blockIdx.y * a.H, y1 = min(ny, y0 + a.H);
   const int gi = x0 - 3 + lane, gic = min(gi, nx + 2);  // lanes past the padded row re-read its last column (never stored)
+  const double dtv = a.dt_ptr ? *a.dt_ptr : a.dt;
   const double D = a.D, D2 = D * D, rD2 = 1. / D2, D12 = 12. * D * D, rD12 = 1. / D12, D2x = 2 * D, rD2x = 1. / D2x;
   const bool lower = l + 1 < nl, upper = l > 0;
   // lanes / rows that hold the first ghost line of a wall
@@ -253,10 +255,10 @@ __device__ __forceinline__ void lpw_body(const LpwArgs &a, double (&ring)[2][LPW
     if (QF) dq += fq;
 #ifdef MSOM_STRICT
     if (STOCH) return (qreg[r] + qsreg[r] * a.crelax + nzreg[r] * a.dts) + dq * a.dt;
-    return ADV ? qreg[r] + dq * a.dt : dq;
+    return ADV ? qreg[r] + dq * dtv : dq;
 #else
     if (STOCH) return fma(dq, a.dt, fma(nzreg[r], a.dts, fma(qsreg[r], a.crelax, qreg[r])));
-    return ADV ? fma(dq, a.dt, qreg[r]) : dq;
+    return ADV ? fma(dq, dtv, qreg[r]) : dq;
 #endif
   };
 
@@ -362,9 +364,10 @@ int g_lpw_dbg = 0;  // option lpw_dbg: bits 1, 2 timing experiments; 4: every wa
 void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const double *qforc, const double *wind, double *dq, const NatGeom &g,
                     int nl, int walls, int uniformS, const double *Su, int have_qforc, double D, double beta, double iRe, double iRe4, double cs,
                     double cb, double slip_c, const LayerCoef &lc, const double *q_in, double *q_out, double dt, int chunk_rows, int stoch,
-                    const double *q_stage, const double *noise, double crelax, double dts, int region) {
+                    const double *q_stage, const double *noise, double crelax, double dts, int region, const double *dt_ptr) {
   LpwArgs a;
   a.region = region;
+  a.dt_ptr = dt_ptr;
   a.q_stage = q_stage; a.noise = noise; a.crelax = crelax; a.dts = dts;
   a.psi = psi; a.S = S; a.qforc = qforc; a.wind = wind; a.q_in = q_in; a.dq = dq; a.q_out = q_out; a.dt = dt;
   extern int g_lpw_dbg;

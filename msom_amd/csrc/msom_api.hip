@@ -13,10 +13,12 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <sys/types.h>
+#include <time.h>
 
 #include <algorithm>
 #include <string>
 #include <utility>
+#include <functional>
 #include <map>
 #include <vector>
 
@@ -34,8 +36,8 @@
 
 // device scalar slots
 // RES0, RES1 and UMAX[nl] are contiguous: one max all-reduce / one copy brings them to the host
-enum { SC_BSUM = 2, SC_KE = 3, SC_SCRATCH = 4, SC_RES0 = 6, SC_RES1 = 7, SC_UMAX = 8 /* MAXNL */, SC_RESF = 8 + MSOM_MAXNL /* max|res| from the fused tendency pass */, SC_LSUM = 32 /* MAXNL */, SC_COUNT = 64 };
-static_assert(SC_RESF < SC_LSUM && SC_LSUM + MSOM_MAXNL <= SC_COUNT, "scalar slots overlap");
+enum { SC_BSUM = 2, SC_KE = 3, SC_SCRATCH = 4, SC_RES0 = 6, SC_RES1 = 7, SC_UMAX = 8 /* MAXNL */, SC_RESF = 8 + MSOM_MAXNL /* max|res| from the fused tendency pass */, SC_LSUM = 32 /* MAXNL */, SC_SPEC = 48 /* k_step_dt: dt limit, dt, tnext, dt / 2 */, SC_COUNT = 64 };
+static_assert(SC_RESF < SC_LSUM && SC_LSUM + MSOM_MAXNL <= SC_SPEC && SC_SPEC + 4 <= SC_COUNT, "scalar slots overlap");
 
 static int g_dbg_interleave = 0;  // timing experiment of msom_bench_kernel (march passes)
 static int g_march_rows = 0;  // tuning knob: chunk height of k_relax_march (0 = automatic)
@@ -58,6 +60,22 @@ struct msom {
   Comm *comm = nullptr;
   int sticky = MSOM_OK;  // first error of a void helper (exchange inside fill_bc / mg_cycle)
   int comm_hold = 0;     // see comm_begin
+  int dbg_nosync = 0;    // option dbg_nosync (timing experiment)
+  // Speculative tendency pass (round 3, one tile): right after the first multigrid cycle of a solve the tendency kernel is queued
+  // BEFORE the host has read max|res| and max|u| -- with dt computed on the device (k_step_dt) in the first RK stage -- so the
+  // GPU works through the host round trip instead of idling (0.49 -> 0.43 ms per step at 256^2 x 3 with the read skipped
+  // altogether, tools/ab_nosync.py).  If the solve turns out to need another cycle the pass is simply run again afterwards:
+  // its output went to the predictor (stage 1) or to a spare buffer that only replaces q when the solve had converged (stage 2).
+  int async_solve = 1;               // option
+  std::function<void(const std::function<void()> &)> spec_hook;   // queued by mg_solve after the first cycle's residual pass; calls its
+                                     // argument (the host's read of the scalars) between the dt kernel and the tendency pass
+  int spec_launched = 0, spec_valid = 0;
+  hipEvent_t ev_spec = nullptr;
+  double *h_pub = nullptr, *d_pub = nullptr;   // coherent pinned host block the device publishes the scalars into (+ a sequence word), and its device address
+  long pub_seq = 0;
+  double *q_alt = nullptr;           // stage 2 writes q + dt dq here
+  double *adv_out_override = nullptr;
+  const double *dt_dev = nullptr;
   int nb[8];  // neighbour ranks by direction (DIR_*), -1 = none
   int nl = 1, nlm = 1;
   int bc = BC_DIRICHLET0;
@@ -226,6 +244,11 @@ static void prof_collect(msom *m, ProfSlot &ps) {
   ps.used = 0;
 }
 
+static double wall_seconds() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
 static int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 
@@ -260,6 +283,7 @@ static int reduce_scal(msom *m, int slot, int n, int op) {
     comm_end(m);
     return r;
   }
+  if (m->dbg_nosync) return MSOM_OK;   // timing experiment: the host keeps the numbers of the last real read (results meaningless)
   HIPCHK(hipMemcpyAsync(m->h_scal + slot, m->d_scal + slot, n * sizeof(double), hipMemcpyDeviceToHost, m->st));
   HIPCHK(hipStreamSynchronize(m->st));
   return MSOM_OK;
@@ -409,6 +433,10 @@ static int exch_split_deep(msom *m, double *f, const SplitGeom &sg, double *fs, 
 
 static int alloc_all(msom *m) {
   HIPCHK(hipStreamCreate(&m->st));
+  HIPCHK(hipEventCreateWithFlags(&m->ev_spec, hipEventDisableTiming));
+  HIPCHK(hipHostMalloc(&m->h_pub, (SC_COUNT + 1) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(m->h_pub, 0, (SC_COUNT + 1) * sizeof(double));
+  HIPCHK(hipHostGetDevicePointer((void **)&m->d_pub, m->h_pub, 0));
   if (m->nranks > 1) {
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -620,6 +648,9 @@ extern "C" int msom_destroy(msom_t *m) {
     if (m->wv_sig[k]) hipFree(m->wv_sig[k]);
   }
   if (m->psi_alt) hipFree(m->psi_alt);
+  if (m->q_alt) hipFree(m->q_alt);
+  if (m->ev_spec) hipEventDestroy(m->ev_spec);
+  if (m->h_pub) hipHostFree(m->h_pub);
   if (m->staging) hipFree(m->staging);
   if (m->partial) hipFree(m->partial);
   if (m->partial_rr) hipFree(m->partial_rr);
@@ -671,6 +702,8 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "march_dma")) { extern int g_march_dma; g_march_dma = (int)v; }
   else if (!strcmp(key, "march_dbg")) { extern int g_march_dbg; g_march_dbg = (int)v; }
   else if (!strcmp(key, "dbg_interleave")) g_dbg_interleave = (int)v;
+  else if (!strcmp(key, "dbg_nosync")) m->dbg_nosync = (int)v;
+  else if (!strcmp(key, "async_solve")) m->async_solve = (int)v;
   else if (!strcmp(key, "march_lean")) { extern int g_march_lean; g_march_lean = (int)v; }
   else if (!strcmp(key, "march_k")) m->march_k = (int)v < 2 ? 2 : ((int)v > 4 ? 4 : (int)v);
   else if (!strcmp(key, "block_small")) m->block_small = (int)v;
@@ -1393,6 +1426,26 @@ static void residual2(msom *m, int mode, const double *b, int slot, int want_sum
 // max-residual slots (RES0, RES1) and the rhs sum (BSUM) -> host, reduced over the tiles
 // (the reference's foreach(reduction(max:maxres)) / reduction(+:sum) are MPI all-reduces)
 static int read_residuals(msom *m) {
+  if (m->nranks == 1) {
+    // one copy of the whole scalar block (sums, residuals, max|u|, the device's dt) and one wait
+    if (m->dbg_nosync) return MSOM_OK;
+    if (m->spec_launched) {   // the scalars were published by k_step_dt in front of the speculative pass: spin on its sequence word
+      volatile long *seq = reinterpret_cast<volatile long *>(m->h_pub + SC_COUNT);
+      const double t0 = wall_seconds();
+      while (*seq != m->pub_seq) {
+        if (wall_seconds() - t0 > 5.) {   // the device is stuck or faulted: let the runtime report it
+          HIPCHK(hipStreamSynchronize(m->st));
+          if (*seq != m->pub_seq) { msom_set_error("the device did not publish the solver's scalars"); return MSOM_ERR_HIP; }
+        }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      memcpy(m->h_scal, m->h_pub, SC_COUNT * sizeof(double));
+      return MSOM_OK;
+    }
+    HIPCHK(hipMemcpyAsync(m->h_scal, m->d_scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    return MSOM_OK;
+  }
   int r = reduce_scal(m, SC_RES0, 2 + m->nl, RED_MAX);  // RES0, RES1, UMAX[nl]
   if (r) return r;
   // mgstats.sum is informational (the reference never prints it, msqg/qg.h:61): with tiles it
@@ -1463,8 +1516,17 @@ static int mg_solve(msom *m, const double *b, msom_mgstats *s) {
       if (m->nranks > 1) STICKY(m, exch_nat(m, m->f[MSOM_PSI], m->nl, m->bc, 1));  // boundary(a)
       residual(m, m->f[MSOM_PSI], b, SC_RES1, 0);
     }
+    if (s->i == 0 && m->spec_hook && m->umax_ready && m->nranks == 1) {   // the tendency pass, queued before the host knows the residual
+      m->spec_hook([&]() {});
+      m->spec_launched = 1;
+    }
     int rr = read_residuals(m);
-    if (rr) return rr;
+    if (rr) { m->spec_launched = 0; return rr; }
+    if (m->spec_launched) {   // its output counts only if this solve ends here
+      const double ra = m->h_scal[SC_RES1];
+      m->spec_valid = !(s->i + 1 < p.nitermax && (s->i + 1 < p.nitermin || ra > p.tolerance));
+      m->spec_launched = 0;
+    }
     if (!have_first) {
       resb = s->resb = m->h_scal[SC_RES0];
       s->sum = m->h_scal[SC_BSUM];
@@ -1595,7 +1657,8 @@ static int rhs_terms(msom *m, int qfield, int dqfield, int with_qforcing, double
                        nullptr, m->g, nl, m->walls & WALL_ALL, m->uniformS, m->rc[0].S, with_qforcing && m->have_qforc, D, p.beta, iRe,
                        iRe4, Eks / (p.Rom * 2 * m->dhf[0]), Ekb / (p.Rom * 2 * m->dhf[nl - 1]),
                        p.sbc > 0 ? p.sbc / ((0.5 * p.sbc + 1) * D * D) : 0., m->lc, variant, adv_out >= 0 ? m->f[adv_in] : nullptr,
-                       adv_out >= 0 ? m->f[adv_out] : nullptr, adv_dt, use_rr ? &rr : nullptr, region);
+                       adv_out >= 0 ? (m->adv_out_override ? m->adv_out_override : m->f[adv_out]) : nullptr, adv_dt, use_rr ? &rr : nullptr, region,
+                       variant == 6 ? m->dt_dev : nullptr);
     });
     prof_end(m, m->prof_rhs);
     if (use_rr) m->res_ready = adv_out;
@@ -1626,9 +1689,61 @@ static int tracer_update(msom *m, int cfield);
 // advection_pv (:383-391): 2*nl limiter calls (psi_l then psipg_l) sharing one static
 // `previous`.  max|u| of psi comes out of the solver's last pass (k_residual2<CORRECT>), so dt
 // is known BEFORE the tendency pass and the advance can ride in it.
+// The same on the device, for the speculative tendency pass of the first RK stage: the 2 nl limiter calls of advection_pv
+// (timestep(), newqg/qg.h:202-219) on max|u| of psi (d_scal) and of psi_pg, then dtnext() of run().  Same operations in the
+// same order as limiter() / dtnext() on the host, no contraction, correctly rounded divisions: the same numbers.
+// The kernel also PUBLISHES the scalar block to the host: 64 threads copy the 64 slots into coherent pinned memory, a system-scope
+// fence, then a sequence word the host spins on -- no copy command and no event between the residual pass and the tendency pass.
+struct StepDtArgs { double umax_pg[MSOM_MAXNL]; double D, CFL, previous, dtmax, t, tnext; int nl, with_dt; long seq; };
+__global__ void __launch_bounds__(64) k_step_dt(double *scal, StepDtArgs a, double *pub) {
+#pragma clang fp contract(off)
+  if (threadIdx.x == 0 && a.with_dt) {
+  const double *umax = scal + SC_UMAX;
+  double *out = scal + SC_SPEC;
+  double dtmax = a.dtmax, previous = a.previous;
+  for (int k = 0; k < 2 * a.nl; k++) {
+    const double u = (k & 1) ? a.umax_pg[k >> 1] : umax[k >> 1];
+    dtmax /= a.CFL;
+    if (u != 0.) {
+      const double dt = a.D / u;
+      if (dt < dtmax) dtmax = dt;
+    }
+    dtmax *= a.CFL;
+    if (dtmax > previous) dtmax = (previous + 0.1 * dtmax) / 1.1;
+    previous = dtmax;
+  }
+  double dt = dtmax, tnext = a.tnext;
+  if (tnext != HUGE_VAL && tnext > a.t) {
+    const unsigned int n = (unsigned int)((tnext - a.t) / dt);
+    if (n == 0) dt = tnext - a.t;
+    else {
+      const double dt1 = (tnext - a.t) / n;
+      if (dt1 > dt * (1. + 1e-9)) dt = (tnext - a.t) / (n + 1);
+      else if (dt1 < dt) dt = dt1;
+      tnext = a.t + dt;
+    }
+  } else
+    tnext = a.t + dt;
+  out[0] = dtmax; out[1] = dt; out[2] = tnext; out[3] = dt / 2.;
+  }
+  __syncthreads();
+  if (pub) {
+    pub[threadIdx.x] = scal[threadIdx.x];      // SC_COUNT = 64 slots
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __atomic_store_n(reinterpret_cast<long *>(pub + SC_COUNT), a.seq, __ATOMIC_RELEASE);
+  }
+}
+static_assert(SC_COUNT == 64, "k_step_dt publishes one slot per thread");
+
 static double solve_and_dt(msom *m, int qfield, double dtmax) {
   const int nl = m->nl;
+  m->spec_valid = 0;
   if (invertq(m, m->f[qfield])) return -1;
+  if (m->spec_valid && m->dt_dev) {   // the device ran the limiter (first RK stage): adopt its state
+    m->previous = m->h_scal[SC_SPEC];
+    return m->h_scal[SC_SPEC];
+  }
   if (!m->umax_ready) {
     launch_umax(m->st, m->f[MSOM_PSI], m->partial_umax, m->d_scal + SC_UMAX, m->g, nl, m->p.L0 / m->gnx);
     if (reduce_scal(m, SC_UMAX, nl, RED_MAX)) return -1;
@@ -1864,21 +1979,76 @@ static int tracer_advance(msom *m, int out, int in, double dt) {
 //   update(predictor, updates, dt); advance(evolving, evolving, updates, dt)
 // dt is known right after each inversion, so both advances ride in the tendency kernel
 // (q_out = q_in + dt * dq) whenever the fused kernel applies; dq is then never stored.
+// can a stage's tendency pass be queued speculatively?  One tile, the fused one-layer-per-wavefront kernel with the advance
+// folded in, max|u| out of the solver's last pass, nothing with side effects in the pass (noise draws, tracers)
+static bool spec_ok(msom *m) {
+  return m->async_solve && m->nranks == 1 && m->fused && m->adv_fused && m->rhs_variant == 6 && !m->rhs_resid && m->mg_fused && m->nlev > 1 &&
+         m->nl <= MSOM_FASTNL && !m->have_pg && !m->have_zpg && !m->flag_topo && !m->stochastic && m->p.nptr == 0 && m->p.nitermin >= 1 && !m->dbg_nosync;
+}
+
 extern "C" int msom_step(msom_t *m, double *dt_used) {
   NEED_CONST(m);
   const Params &p = m->p;
   double tnext;
   int r, advanced = 0;
+  const bool spec = spec_ok(m);
+  int spec_rc = 0;
+  if (spec) {   // stage 1: dt on the device, predictor = q + dt/2 dq
+    m->dt_dev = m->d_scal + SC_SPEC + 3;
+    m->spec_hook = [&](const std::function<void()> &host_read) {
+      StepDtArgs a;
+      for (int l = 0; l < MSOM_MAXNL; l++) a.umax_pg[l] = m->umax_pg[l];
+      a.D = p.L0 / m->gnx; a.CFL = p.CFL; a.previous = m->previous; a.dtmax = p.DT; a.t = m->t; a.tnext = m->tnext; a.nl = m->nl;
+      a.with_dt = 1; a.seq = ++m->pub_seq;
+      hipLaunchKernelGGL(k_step_dt, dim3(1), dim3(64), 0, m->st, m->d_scal, a, m->d_pub);
+      host_read();
+      int adv = 0;
+      spec_rc = rhs_terms(m, MSOM_Q, MSOM_DQ, 1, p.iRe, p.iRe4, p.Eks, p.Ekb, MSOM_QPRED, MSOM_Q, 0., &adv);
+      if (!adv && !spec_rc) spec_rc = MSOM_ERR_STATE;
+    };
+  }
   const double d = solve_and_dt(m, MSOM_Q, p.DT);
+  m->spec_hook = nullptr;
+  const bool hit1 = spec && m->spec_valid && !spec_rc;
+  m->dt_dev = nullptr;
   if (d < 0) return m->sticky ? m->sticky : MSOM_ERR_HIP;
-  m->dt = dtnext(m, d, &tnext);
-  if ((r = rhs_terms(m, MSOM_Q, MSOM_DQ, 1, p.iRe, p.iRe4, p.Eks, p.Ekb, MSOM_QPRED, MSOM_Q, m->dt / 2., &advanced))) return r;
-  if (!advanced && (r = advance_qg(m, MSOM_QPRED, MSOM_Q, MSOM_DQ, m->dt / 2.))) return r;
+  if (hit1) {
+    m->dt = m->h_scal[SC_SPEC + 1];
+    tnext = m->h_scal[SC_SPEC + 2];
+  } else {
+    m->dt = dtnext(m, d, &tnext);
+    if ((r = rhs_terms(m, MSOM_Q, MSOM_DQ, 1, p.iRe, p.iRe4, p.Eks, p.Ekb, MSOM_QPRED, MSOM_Q, m->dt / 2., &advanced))) return r;
+    if (!advanced && (r = advance_qg(m, MSOM_QPRED, MSOM_Q, MSOM_DQ, m->dt / 2.))) return r;
+  }
   const bool tracers = m->p.nptr > 0;
   if (tracers && ((r = tracer_update(m, MSOM_PTR)) || (r = tracer_advance(m, MSOM_PTR_PRED, MSOM_PTR, m->dt / 2.)))) return r;
-  if (solve_and_dt(m, MSOM_QPRED, m->dt) < 0) return m->sticky ? m->sticky : MSOM_ERR_HIP;
-  if ((r = rhs_terms(m, MSOM_QPRED, MSOM_DQ, 1, p.iRe, p.iRe4, p.Eks, p.Ekb, MSOM_Q, MSOM_Q, m->dt, &advanced))) return r;
-  if (!advanced && (r = advance_qg(m, MSOM_Q, MSOM_Q, MSOM_DQ, m->dt))) return r;
+  spec_rc = 0;
+  if (spec) {   // stage 2: dt is known; q + dt dq goes to a spare buffer that replaces q only if the solve ends after its first cycle
+    if (!m->q_alt) {   // pads and ghost cells as q has them: the pass writes interior cells only
+      HIPCHK(hipMalloc(&m->q_alt, m->g.ls * m->nl * sizeof(double)));
+      HIPCHK(hipMemcpyAsync(m->q_alt, m->f[MSOM_Q], m->g.ls * m->nl * sizeof(double), hipMemcpyDeviceToDevice, m->st));
+    }
+    m->spec_hook = [&](const std::function<void()> &host_read) {
+      StepDtArgs a;
+      memset(&a, 0, sizeof a);
+      a.with_dt = 0; a.seq = ++m->pub_seq;
+      hipLaunchKernelGGL(k_step_dt, dim3(1), dim3(64), 0, m->st, m->d_scal, a, m->d_pub);   // publish only
+      host_read();
+      int adv = 0;
+      m->adv_out_override = m->q_alt;
+      spec_rc = rhs_terms(m, MSOM_QPRED, MSOM_DQ, 1, p.iRe, p.iRe4, p.Eks, p.Ekb, MSOM_Q, MSOM_Q, m->dt, &adv);
+      m->adv_out_override = nullptr;
+      if (!adv && !spec_rc) spec_rc = MSOM_ERR_STATE;
+    };
+  }
+  const double d2 = solve_and_dt(m, MSOM_QPRED, m->dt);
+  m->spec_hook = nullptr;
+  if (d2 < 0) return m->sticky ? m->sticky : MSOM_ERR_HIP;
+  if (spec && m->spec_valid && !spec_rc) std::swap(m->f[MSOM_Q], m->q_alt);
+  else {
+    if ((r = rhs_terms(m, MSOM_QPRED, MSOM_DQ, 1, p.iRe, p.iRe4, p.Eks, p.Ekb, MSOM_Q, MSOM_Q, m->dt, &advanced))) return r;
+    if (!advanced && (r = advance_qg(m, MSOM_Q, MSOM_Q, MSOM_DQ, m->dt))) return r;
+  }
   if (tracers && ((r = tracer_update(m, MSOM_PTR_PRED)) || (r = tracer_advance(m, MSOM_PTR, MSOM_PTR, m->dt)))) return r;
   if ((r = sync_stream(m))) return r;
   m->t = tnext;

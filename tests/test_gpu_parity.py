@@ -768,3 +768,30 @@ def test_graph_replay_of_the_cycle_equals_eager_launches(nx, nl):
     for a, b in zip(*outs):
         assert a[2] == b[2]
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nx,ny,nl,extra,tol", [(64, 64, 3, "", 1e-3), (256, 128, 6, "sbc = 1.5\nRe = 300\nEks = 0.001\n", 1e-3), (128, 128, 2, "sbc = -1\ntau0 = 0\n", 1e-3),
+                                               (64, 64, 3, "", 1e-9), (512, 512, 3, "", 1e-3), (32, 32, 1, "", 1e-3)])
+def test_speculative_tendency_pass_changes_nothing(nx, ny, nl, extra, tol, strict):
+    """option async_solve (round 3): after the first multigrid cycle of a solve the tendency kernel is queued before the host has
+    read max|res| and max|u| -- dt from k_step_dt on the device in the first RK stage, a spare q buffer in the second -- and run
+    again the ordinary way if the solve needs more cycles (tol 1e-9: always).  Same numbers as with the option off, step by
+    step, in both builds; with output times ahead (dtnext() shortens dt) and with none"""
+    outs = []
+    for async_solve in (0, 1):
+        txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else "") + extra)
+        g = QG(txt, strict=strict)
+        g.option("quiet", 1); g.option("TOLERANCE", tol); g.option("async_solve", async_solve)
+        g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx)); g.set_const()
+        rec = []
+        for k in range(6):
+            g.set_tnext(float("inf") if k < 3 else g.t + 0.0371)      # an output event ahead: dtnext() cuts dt to land on it
+            dt = g.step()
+            st = g.mgstats()
+            rec.append((dt, g.t, g.get(F["Q"]), g.get(F["PSI"]), (st.i, st.resa)))
+        outs.append(rec)
+        g.close()
+    for a, b in zip(*outs):
+        assert a[0] == b[0] and a[1] == b[1] and a[4] == b[4]
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
