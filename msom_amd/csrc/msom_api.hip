@@ -132,6 +132,7 @@ struct msom {
                        // bound by the duration of their ~5-us kernels on the GPU, not by the host's launch rate: option "graph", off
   std::map<long, hipGraphExec_t> cyc_graph;
   int march_partial = 1; // a pass that is followed by more half-sweeps stores only the colour of its last half-sweep
+  int march_min_tiled = 22;  // the same threshold on tiles (see march_ok)
   int march_min = 23;    // log2 of the cell-layers a level needs for the chained pass (2^23: 2048^2 x 3 1.83 -> 1.78 ms/step, and the 2048 x 1024 x 6 tiles of BASELINE's 2 x 4 layout qualify; 2^22 loses: 1024^2 x 6 2.76 -> 2.87)
   int march_correct = 1; // the last pass of the finest level writes psi + da instead of da (psi rows by LDS-DMA, deferred write): 7.02 -> 6.86 ms per step at 4096^2 x 6
   int corr_req = 0, corr_done = 0;  // set around mg_cycle_levels by mg_solve / by the pass that did it
@@ -694,6 +695,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "march")) m->march = (int)v;
   else if (!strcmp(key, "march_rows")) g_march_rows = (int)v;
   else if (!strcmp(key, "march_min")) m->march_min = (int)v;
+  else if (!strcmp(key, "march_min_tiled")) m->march_min_tiled = (int)v;
   else if (!strcmp(key, "march_partial")) m->march_partial = (int)v;
   else if (!strcmp(key, "march_prolong")) m->march_prolong = (int)v;
   else if (!strcmp(key, "march_correct")) m->march_correct = (int)v;
@@ -1121,7 +1123,11 @@ static bool march_ok(msom *m, const Lev &L) {
   const bool walls_ok = L.tiled || L.walls == WALL_ALL || L.walls == WALL_PER;
   if (!m->march || m->block_sweeps || !(m->uniformS || m->nl == 1) || m->nl > MSOM_FASTNL || !walls_ok || L.sg->nx < 512 || L.sg->ny < 64) return false;
   if (!L.tiled && L.walls == WALL_PER && L.k < 0) return false;   // gathered coarse levels keep their per-colour launches
-  return m->march >= 2 || (size_t)L.sg->nx * L.sg->ny * m->nl >= ((size_t)1 << m->march_min);
+  // tiles: one level more (2^22 cell-layers: 1024^2 x 6) -- on one GPU marching that level is neutral with the round-3 body (6.69 vs
+  // 6.66 ms per step at 4096^2 x 6, 1.57 vs 1.56 at 2048^2 x 3), on tiles it replaces 8 per-colour halo exchanges of a level visit
+  // by 3 deep ones; unmeasured on more than one GPU (none available), so the threshold is a separate option
+  const int lg = L.tiled ? m->march_min_tiled : m->march_min;
+  return m->march >= 2 || (size_t)L.sg->nx * L.sg->ny * m->nl >= ((size_t)1 << lg);
 }
 static int march_levels(msom *m) {
   int n = 0;
