@@ -158,6 +158,12 @@ void launch_n_sqg_rhs(hipStream_t st, const double *q, const double *S2S, const 
 void launch_n_rhs_main(hipStream_t st, const double *psi, const double *zeta, const double *pg, const double *S2, const double *topo, double *dq,
                        const NatGeom &g, int nl, int have_pg, int have_topo, double D, double beta, double drag, double f0, double dhb, const LayerCoef &lc);
 void launch_n_axpy(hipStream_t st, double *dq, const double *x, const NatGeom &g, int nl, double c);
+void launch_n_rhs_pre(hipStream_t st, double *q, const double *psi, double *psi_out, double *zeta, const double *mk, const NatGeom &g, int nl, double D,
+                      double bc, double gbc);
+void launch_n_del2_bnd(hipStream_t st, const double *in, double *out, const NatGeom &g, int nl, double D, double bc, int use_bnd, double gbc);
+void launch_n_rhs_all(hipStream_t st, const double *psi, const double *zeta, const double *tmp, const double *pg, const double *S2, const double *topo,
+                      const double *qf, const double *qf3d, const double *mk, const double *d2bs, const double *S2S, double *dq, const NatGeom &g, int nl,
+                      double D, double beta, double drag, double f0, double dhb, double nu, double mnu4, const LayerCoef &lc, int have_pg, int have_topo);
 void launch_n_add2d(hipStream_t st, double *dq, const double *qf, const NatGeom &g);
 void launch_n_rhs_barotropic(hipStream_t st, const double *psi, const double *q, const double *qf, double *dq, const NatGeom &g, double D, double beta,
                              double drag, double nu);
@@ -184,6 +190,9 @@ void launch_n_mg_coarse(hipStream_t st, const NCoarseArgs &a, int nrelax, int nl
 void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind, int fsp = 0, int csp = 0);
 void launch_n_prolong(hipStream_t st, const double *c, const NatGeom &cg, double *f, const NatGeom &fg, int nl, int csp = 0, int fsp = 0);
 void launch_n_correct(hipStream_t st, double *a, const double *da, const NatGeom &g, int nl, double bcv, const NatGeom *gda = nullptr);
+void launch_n_correct_residual(hipStream_t st, const double *a, double *a_out, const double *da, const NatGeom *gda, double bcv, const double *b, const double *mk,
+                               const double *S2, double *res, double *maxres, const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc,
+                               const NatGeom *gres, const double *S2row);
 void launch_n_row_table(hipStream_t st, const double *f, const NatGeom &g, int nl, double *out);
 void launch_n_relax_prolong(hipStream_t st, double *a, const double *b, const double *mk, const double *S2, const NatGeom &g, int nl, double D,
                             double iRd2, const LayerCoef &lc, const double *S2row, const double *coarse, const NatGeom &cg, int csp);

@@ -252,6 +252,158 @@ __global__ void k_n_add2d(double *dq, const double *__restrict__ qf, NatGeom g) 
   dq[k] += qf[k];
 }
 void launch_n_add2d(hipStream_t st, double *dq, const double *qf, const NatGeom &g) { hipLaunchKernelGGL(k_n_add2d, grid2d(g.nx, g.ny), block2d(), 0, st, dq, qf, g); }
+// ---- the baroclinic tendency in three passes (round 3) instead of the twelve launches of the reference's loop sequence.  The
+// expressions and their order per vertex are those of the kernels above, so the strict build gives the same bits.
+// Pass 1: q *= mask; psi_out = psi * mask (second buffer: the neighbours of other threads read the unmasked one and mask it
+// themselves); zeta = laplacian of the masked psi inside, the set_bc_ms rule c (psi_first_interior - psi_bc) on the sides
+// (k_n_mul_mask + k_n_del2 + k_n_bnd_from).
+__global__ void k_n_rhs_pre(double *q, const double *__restrict__ psi, double *__restrict__ psi_out, double *__restrict__ zeta, const double *__restrict__ mk,
+                            NatGeom g, int nl, double D2, double rD2, double bc, double gbc) {
+  VTX(g, i, j);
+  const int n = g.nx - 1, pitch = g.pitch;
+  const size_t c0 = nat_idx(g, 0, j, i);
+  const double m = mk[c0];
+  const bool ys = j == 0 || j == n, xs = i == 0 || i == n;
+  // the vertex whose masked psi the side rule reads (y sides first: a corner takes the y rule)
+  const ptrdiff_t off = ys ? (j == 0 ? pitch : -pitch) : (i == 0 ? 1 : -1);
+  const double me = mk[c0 + 1], mw = mk[c0 - 1], mn = mk[c0 + pitch], ms = mk[c0 - pitch];
+  size_t c = c0;
+  for (int l = 0; l < nl; l++, c += g.ls) {
+    q[c] *= m;
+    const double pc = psi[c] * m;
+    psi_out[c] = pc;
+    if (ys || xs) zeta[c] = bc * (psi[c + off] * mk[c0 + off] - gbc);
+    else {
+      const double lap = DIVC(psi[c + 1] * me + psi[c - 1] * mw + psi[c + pitch] * mn + psi[c - pitch] * ms - 4 * pc, D2, rD2);
+      zeta[c] = 1. * lap;
+    }
+  }
+}
+void launch_n_rhs_pre(hipStream_t st, double *q, const double *psi, double *psi_out, double *zeta, const double *mk, const NatGeom &g, int nl, double D,
+                      double bc, double gbc) {
+  hipLaunchKernelGGL(k_n_rhs_pre, grid2d(g.nx, g.ny), block2d(), 0, st, q, psi, psi_out, zeta, mk, g, nl, D * D, 1. / (D * D), bc, gbc);
+}
+// Pass 2: out = laplacian(in) inside, c (in_first_interior - (use_bnd ? in_boundary : gbc)) on the sides (k_n_del2 + k_n_bnd_from)
+__global__ void k_n_del2_bnd(const double *__restrict__ in, double *__restrict__ out, NatGeom g, int nl, double D2, double rD2, double bc, int use_bnd, double gbc) {
+  VTX(g, i, j);
+  const int n = g.nx - 1, pitch = g.pitch;
+  const bool ys = j == 0 || j == n, xs = i == 0 || i == n;
+  const ptrdiff_t off = ys ? (j == 0 ? pitch : -pitch) : (i == 0 ? 1 : -1);
+  size_t c = nat_idx(g, 0, j, i);
+  for (int l = 0; l < nl; l++, c += g.ls) {
+    if (ys || xs) out[c] = bc * (in[c + off] - (use_bnd ? in[c] : gbc));
+    else out[c] = 1. * DIVC(LAPN(in, c, pitch), D2, rD2);
+  }
+}
+void launch_n_del2_bnd(hipStream_t st, const double *in, double *out, const NatGeom &g, int nl, double D, double bc, int use_bnd, double gbc) {
+  hipLaunchKernelGGL(k_n_del2_bnd, grid2d(g.nx, g.ny), block2d(), 0, st, in, out, g, nl, D * D, 1. / (D * D), bc, use_bnd, gbc);
+}
+// Pass 3: k_n_rhs_main, + nu stretch(zeta) (k_n_stretch / k_n_stretch_sqg), + nu tmp (k_n_axpy), - nu4 stretch(tmp), - nu4 laplacian(tmp)
+// (k_n_del2 with add = 1), + surface forcing (k_n_add2d), + 3-d forcing, times the mask (k_n_mul_mask) -- one thread per vertex, the
+// layers in sequence as in every one of those kernels, the partial sums in a register instead of dq.
+struct NRhsTailArgs {
+  const double *tmp, *qf, *qf3d, *mk, *d2bs, *S2S;
+  double nu, mnu4;
+  int sqg;
+};
+__device__ __forceinline__ double n_stretch_val(int sqg, int l, int nl, double fac, double pm, double pc, double pp, double s0, double s1, double sb,
+                                                const LayerCoef &lc) {
+  if (sqg) {
+    if (l == 0) return fac * (sb * lc.idh0[0] - s1 * (pc - pp) * lc.idh1[l]);
+    if (l < nl - 1) return fac * (s0 * (pm - pc) * lc.idh0[l] - s1 * (pc - pp) * lc.idh1[l]);
+    return fac * (-s0 * (pc - pm)) * lc.idh0[l];
+  }
+  if (l == 0) return fac * s1 * (pp - pc) * lc.idh1[l];
+  if (l < nl - 1) return fac * (s0 * (pm - pc) * lc.idh0[l] + s1 * (pp - pc) * lc.idh1[l]);
+  return fac * s0 * (pm - pc) * lc.idh0[l];
+}
+// 3 x 3 neighbourhoods in registers: every value of psi and zeta is loaded once per vertex and layer (the psi window of layer
+// l + 1 becomes that of layer l), jacn's expression on them
+__device__ __forceinline__ void n_ld9(const double *__restrict__ f, size_t c, int pitch, double (&w)[9]) {
+#pragma unroll
+  for (int b = -1; b <= 1; b++)
+#pragma unroll
+    for (int x = -1; x <= 1; x++) w[(b + 1) * 3 + x + 1] = f[c + x + (ptrdiff_t)b * pitch];
+}
+__device__ __forceinline__ double n_jacw(const double (&p)[9], const double (&q)[9], double D12, double rD12) {
+#define P(a, b) p[((b) + 1) * 3 + (a) + 1]
+#define Q(a, b) q[((b) + 1) * 3 + (a) + 1]
+  const double s = (P(1, 0) - P(-1, 0)) * (Q(0, 1) - Q(0, -1)) + (P(0, -1) - P(0, 1)) * (Q(1, 0) - Q(-1, 0)) + P(1, 0) * (Q(1, 1) - Q(1, -1)) -
+                   P(-1, 0) * (Q(-1, 1) - Q(-1, -1)) - P(0, 1) * (Q(1, 1) - Q(-1, 1)) + P(0, -1) * (Q(1, -1) - Q(-1, -1)) +
+                   Q(0, 1) * (P(1, 1) - P(-1, 1)) - Q(0, -1) * (P(1, -1) - P(-1, -1)) - Q(1, 0) * (P(1, 1) - P(1, -1)) +
+                   Q(-1, 0) * (P(-1, 1) - P(-1, -1));
+#undef P
+#undef Q
+  return DIVC(s, D12, rD12);
+}
+// PG / TOPO: psi_pg / topo have been set (all-zero fields add +-0 to every term: skipped)
+template <bool PG, bool TOPO>
+__global__ void k_n_rhs_all(NRhsArgs a, NRhsTailArgs t) {
+  VTX(a.g, i, j);
+  const int nl = a.nl, pitch = a.g.pitch;
+  const size_t ls = a.g.ls;
+  const double D12 = 12. * a.D * a.D, rD12 = 1. / D12, D2x = 2 * a.D, rD2x = 1. / D2x, D2 = a.D * a.D, rD2 = 1. / D2;
+  size_t c = nat_idx(a.g, 0, j, i);
+  const size_t c0 = c;
+  const double m = t.mk[c0];
+  const double sb = t.sqg ? t.S2S[c0] * t.d2bs[c0] : 0.;
+  double ju = 0., jd = 0.;
+  double zm = 0., zp = 0., tm = 0., tc = t.tmp[c0], tp = 0., s0 = 0., s1 = 0.;
+  double P0[9], P1[9], Z[9];
+  n_ld9(a.psi, c0, pitch, P0);
+  for (int l = 0; l < nl; l++, c += ls) {
+    ju = -jd;
+    if (l < nl - 1) {
+      n_ld9(a.psi, c + ls, pitch, P1);
+      jd = n_jacw(P0, P1, D12, rD12);
+      if (PG) jd = jd + jacn(a.pg, a.psi + ls, c, pitch, D12, rD12) + jacn(a.psi, a.pg + ls, c, pitch, D12, rD12);
+      zp = a.zeta[c + ls]; tp = t.tmp[c + ls]; s1 = a.S2[c];
+    }
+    n_ld9(a.zeta, c, pitch, Z);
+    const double zc = Z[4];
+    double d = -n_jacw(P0, Z, D12, rD12);
+    if (PG) d = d - jacn(a.pg, a.zeta, c, pitch, D12, rD12);
+    if (l < nl - 1) d = d - s1 * jd * a.lc.idh1[l];
+    if (l > 0) d = d - s0 * ju * a.lc.idh0[l];
+    d = d - DIVC(a.beta * (P0[5] - P0[3]), D2x, rD2x);
+    if (l == nl - 1) {  // bottom friction and topography, :150
+      double e = -a.drag * zc;
+      if (TOPO) {
+        double T[9];
+        n_ld9(a.topo, c0, pitch, T);
+        const double jt = n_jacw(P0, T, D12, rD12);
+#ifdef MSOM_STRICT
+        e = e - jt * a.f0 / a.dhb;
+#else
+        e = e - jt * (a.f0 / a.dhb);
+#endif
+      }
+      d += e;
+    }
+    d = 1. * d + n_stretch_val(t.sqg, l, nl, t.nu, zm, zc, zp, s0, s1, sb, a.lc);
+    d += t.nu * tc;
+    d = 1. * d + n_stretch_val(t.sqg, l, nl, t.mnu4, tm, tc, tp, s0, s1, sb, a.lc);
+    d = 1. * d + t.mnu4 * DIVC(t.tmp[c + 1] + t.tmp[c - 1] + t.tmp[c + pitch] + t.tmp[c - pitch] - 4 * tc, D2, rD2);
+    if (l == 0) d += t.qf[c0];
+    if (t.qf3d) d += 1. * t.qf3d[c];
+    d *= m;
+    a.dq[c] = d;
+    zm = zc; tm = tc; tc = tp; s0 = s1;
+#pragma unroll
+    for (int k = 0; k < 9; k++) P0[k] = P1[k];
+  }
+}
+void launch_n_rhs_all(hipStream_t st, const double *psi, const double *zeta, const double *tmp, const double *pg, const double *S2, const double *topo,
+                      const double *qf, const double *qf3d, const double *mk, const double *d2bs, const double *S2S, double *dq, const NatGeom &g, int nl,
+                      double D, double beta, double drag, double f0, double dhb, double nu, double mnu4, const LayerCoef &lc, int have_pg, int have_topo) {
+  NRhsArgs a;
+  a.psi = psi; a.zeta = zeta; a.pg = pg; a.S2 = S2; a.topo = topo; a.dq = dq; a.g = g; a.nl = nl; a.have_pg = have_pg; a.have_topo = have_topo;
+  a.D = D; a.beta = beta; a.drag = drag; a.f0 = f0; a.dhb = dhb; a.lc = lc;
+  NRhsTailArgs t;
+  t.tmp = tmp; t.qf = qf; t.qf3d = qf3d; t.mk = mk; t.d2bs = d2bs; t.S2S = S2S; t.nu = nu; t.mnu4 = mnu4; t.sqg = d2bs != nullptr;
+  auto k = have_pg ? (have_topo ? k_n_rhs_all<true, true> : k_n_rhs_all<true, false>) : (have_topo ? k_n_rhs_all<false, true> : k_n_rhs_all<false, false>);
+  hipLaunchKernelGGL(k, grid2d(g.nx, g.ny), block2d(), 0, st, a, t);
+}
 __global__ void k_n_rhs_barotropic(const double *__restrict__ psi, const double *__restrict__ q, const double *__restrict__ qf, double *dq, NatGeom g,
                                    double D, double beta, double drag, double nu) {
   VTX(g, i, j);
@@ -901,6 +1053,61 @@ void launch_n_residual(hipStream_t st, const double *a, const double *b, const d
   p.a = a; p.b = b; p.mk = mk; p.S2 = S2; p.res = res; p.maxres = maxres; p.g = g; p.nl = nl; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc;
   p.sp = gres != nullptr; p.gr = gres ? *gres : g;
   hipLaunchKernelGGL(k_n_residual, grid_capped(g.nx, g.ny), block2d(), 0, st, p);
+}
+// Correction of cycle i and residual of cycle i + 1 in one pass (round 3): a_new = a + da (boundary vertices: the boundary value,
+// k_n_correct) is formed where the residual needs it -- at the vertex, its four neighbours and the layers above / below -- by the
+// same addition, the residual is k_n_residual's expression on those values, a_new goes to a second psi buffer (the neighbours of
+// other threads still read the old one).  Saves the read-modify-write pass of k_n_correct: 107 + 47 -> ~115 us per cycle at 2049^2 x 3.
+__global__ void k_n_correct_residual(NResArgs p, const double *__restrict__ da, NatGeom gd, int dsp, double *__restrict__ a_out, double bcv) {
+  const int i = blockIdx.x * BX + threadIdx.x;
+  const int n = p.g.nx - 1;
+  double mx = 0.;
+  for (int j = blockIdx.y * BY + threadIdx.y; i < p.g.nx && j < p.g.ny; j += gridDim.y * BY) {
+    const int nl = p.nl;
+    const size_t ls = p.g.ls, c0 = nat_idx(p.g, 0, j, i);
+    // vertices beyond the grid (pad cells next to a boundary vertex) are not corrected: they keep what the field holds there
+    auto anew = [&](int l, int jj, int ii) -> double {
+      const double av = p.a[nat_idx(p.g, l, jj, ii)];
+      if (ii < 0 || jj < 0 || ii > n || jj > n) return av;
+      if (ii == 0 || jj == 0 || ii == n || jj == n) return bcv;
+      return av + da[gidx(gd, dsp, l, jj, ii)];
+    };
+    const double m = p.mk[c0], sq = p.sqD, rsq = 1. / sq;
+    for (int l = 0; l < nl; l++) {
+      const size_t c = c0 + l * ls;
+      const double a1 = anew(l, j, i);
+      a_out[c] = a1;
+      double r;
+      const double s2m = (nl > 1 && l > 0) ? (p.S2row ? p.S2row[(l - 1) * p.g.ny + j] : p.S2[c - ls]) : 0.;
+      const double s2c = (nl > 1 && l < nl - 1) ? (p.S2row ? p.S2row[l * p.g.ny + j] : p.S2[c]) : 0.;
+      if (nl == 1) r = (p.b[c] - (-p.iRd2 * a1)) * m;
+      else if (l == 0) r = (p.b[c] + s2c * (a1 - anew(l + 1, j, i)) * p.lc.idh1[l]) * m;
+      else if (l < nl - 1) r = (p.b[c] + s2m * (a1 - anew(l - 1, j, i)) * p.lc.idh0[l] - s2c * (anew(l + 1, j, i) - a1) * p.lc.idh1[l]) * m;
+      else r = (p.b[c] + s2m * (a1 - anew(l - 1, j, i)) * p.lc.idh0[l]) * m;
+      r -= DIVC(anew(l, j, i - 1) - 2. * a1 + anew(l, j, i + 1), sq, rsq) * m;
+      r -= DIVC(anew(l, j - 1, i) - 2. * a1 + anew(l, j + 1, i), sq, rsq) * m;
+      p.res[p.sp ? gidx(p.gr, 1, l, j, i) : c] = r;
+      mx = fmax(mx, fabs(r));
+    }
+  }
+  __shared__ double sm[BY];
+  mx = wave_max_n(mx);
+  if (threadIdx.x == 0) sm[threadIdx.y] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    double v = sm[0];
+    for (int k = 1; k < BY; k++) v = fmax(v, sm[k]);
+    atomicMax((unsigned long long *)p.maxres, (unsigned long long)__double_as_longlong(v));
+  }
+}
+void launch_n_correct_residual(hipStream_t st, const double *a, double *a_out, const double *da, const NatGeom *gda, double bcv, const double *b, const double *mk,
+                               const double *S2, double *res, double *maxres, const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc,
+                               const NatGeom *gres, const double *S2row) {
+  NResArgs p;
+  p.S2row = S2row;
+  p.a = a; p.b = b; p.mk = mk; p.S2 = S2; p.res = res; p.maxres = maxres; p.g = g; p.nl = nl; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc;
+  p.sp = gres != nullptr; p.gr = gres ? *gres : g;
+  hipLaunchKernelGGL(k_n_correct_residual, grid_capped(g.nx, g.ny), block2d(), 0, st, p, da, gda ? *gda : g, gda != nullptr, a_out, bcv);
 }
 // restriction_coarsen_vert (residual), restriction_coarsen_vert2 (mask), restriction_vert (injection), my_vertex.h:49-75
 __device__ __forceinline__ void n_restrict_pt(const double *__restrict__ f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind, int I, int J) {

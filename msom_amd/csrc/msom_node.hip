@@ -62,6 +62,7 @@ struct msomn {
   int nitermax = 100, nitermin = 1, nrelax = 5, quiet = 0;  // nodal-poisson.h:19-23
   // stochastic forcing (-D_STOCHASTIC of the reference): cell-scalar noise n_stoch, wavelet-filtered (qg-node/qg_stochastic.h)
   int stochastic = 0, corrector_step = 0, cnlev = 0;
+  int pg_set = 0, topo_set = 0;   // psi_pg / topo have been set (zero until then: their terms of the tendency are skipped by k_n_rhs_all)
   int forcing_3d = 0;  // -DFORCING_3D: switched on by setting MSOMN_QFORC3D
   int sqg = 0;         // surface-QG variant (params key sqg): sqg_baroclinic_ms.h:77-98,502,545-547
   double *qeff = nullptr, *d2bs = nullptr;  // sqg scratch: rhs of the inversion, laplacian(bs)
@@ -77,6 +78,9 @@ struct msomn {
                         // half the bytes, but in the natural layout half of the lanes idle in every half-sweep and the vertex column
                         // solve (vertex-dependent coefficients, one reciprocal per layer) is arithmetic-bound: off
   int node_pfused = 1;   // option: prolongation folded into the first colour pass of the split levels
+  int node_rhs_fused = 1;   // option: the baroclinic tendency in three passes (k_n_rhs_pre, k_n_del2_bnd, k_n_rhs_all) instead of twelve
+  int node_corr_fused = 0;  // option: the correction a += da rides in the next cycle's residual pass (k_n_correct_residual)
+  double *psi_alt = nullptr;
   int node_march_s = 2049;  // option: split levels of >= node_march_s vertices per side chain up to 4 colour half-sweeps per pass (k_n_relax_march_s,
                             // round 3).  2049^2 x 3, 9 cycles per solve (tools/ab_node_prof.py): 3 passes of 83 us replace 9 colour launches of 33 us:
                             // 17.3 -> 16.6 ms per step; on the 1025^2 and 513^2 levels the pass loses (17.4 / 18.4): too few chunks for a
@@ -190,6 +194,7 @@ extern "C" void msomn_destroy(msomn_t *m) {
   }
   for (auto *v : {&m->ws, &m->wr, &m->wsig, &m->wmc})
     for (double *q : *v) if (q) (void)hipFree(q);
+  if (m->psi_alt) (void)hipFree(m->psi_alt);
   if (m->qeff) (void)hipFree(m->qeff);
   if (m->d2bs) (void)hipFree(m->d2bs);
   if (m->d_scal) (void)hipFree(m->d_scal);
@@ -306,6 +311,8 @@ extern "C" int msomn_set_option(msomn_t *m, const char *key, double v) {
   else if (!strcmp(key, "profile")) m->profile = (int)v;
   else if (!strcmp(key, "tiled_relax")) m->tiled_relax = (int)v;
   else if (!strcmp(key, "node_pfused")) m->node_pfused = (int)v;
+  else if (!strcmp(key, "node_corr_fused")) m->node_corr_fused = (int)v;
+  else if (!strcmp(key, "node_rhs_fused")) m->node_rhs_fused = (int)v;
   else if (!strcmp(key, "s2_rows")) { m->s2_rows = (int)v; if (m->const_set) return choose_layouts(m); }
   else if (!strcmp(key, "node_split")) { m->node_split = (int)v; if (m->const_set) return choose_layouts(m); }
   else if (!strcmp(key, "node_march")) m->node_march = (int)v;
@@ -362,6 +369,8 @@ extern "C" int msomn_set_field(msomn_t *m, int f, const double *a) {
   NEED_FIELD(m, f);
   if (!a) return MSOM_ERR_ARG;
   if (f == MSOMN_QFORC3D) m->forcing_3d = 1;
+  if (f == MSOMN_PSIPG) m->pg_set = 1;
+  if (f == MSOMN_TOPO) m->topo_set = 1;
   return upload_g(m, m->f[f], m->g, m->fl[f], a);
 }
 extern "C" int msomn_get_field(msomn_t *m, int f, double *a) {
@@ -398,6 +407,9 @@ static int comp_q(msomn *m, const double *psi, double *q) {
   return MSOM_OK;
 }
 
+// second psi buffer of the out-of-place passes (k_n_rhs_pre, k_n_correct_residual): the pad cells around the grid are written by
+// no kernel and no upload, they are zero in both
+static int need_psi_alt(msomn *m) { return m->psi_alt ? MSOM_OK : dalloc(&m->psi_alt, m->g.ls * m->nl); }
 // rhs_pv_baroclinic qg_baroclinic_ms.h:104-196 / rhs_pv_barotropic qg_barotropic.h:16-29
 static int rhs_pv_body(msomn *m, double *q, double *dq);
 static int rhs_pv(msomn *m, double *q, double *dq) {
@@ -416,6 +428,19 @@ static int rhs_pv_body(msomn *m, double *q, double *dq) {
     return MSOM_OK;
   }
   double *psi = m->f[MSOMN_PSI], *zeta = m->f[MSOMN_ZETA], *tmp = m->f[MSOMN_TMP], *S2 = m->f[MSOMN_S2];
+  if (m->node_rhs_fused) {   // the same arithmetic in three passes (four with the surface term of the SQG variant), kernels_node.hip
+    int ra = need_psi_alt(m);
+    if (ra) return ra;
+    launch_n_rhs_pre(m->st, q, psi, m->psi_alt, zeta, m->f[MSOMN_MASK], m->g, nl, m->D, bcc(m), m->psi_bc);
+    std::swap(m->f[MSOMN_PSI], m->psi_alt);
+    psi = m->f[MSOMN_PSI];
+    launch_n_del2_bnd(m->st, zeta, tmp, m->g, nl, m->D, bcc(m), m->sqg ? 0 : 1, m->sqg ? m->psi_bc : 0.);
+    if (m->sqg) launch_n_lap_bs(m->st, m->f[MSOMN_BS], m->d2bs, m->g, m->D);
+    launch_n_rhs_all(m->st, psi, zeta, tmp, m->f[MSOMN_PSIPG], S2, m->f[MSOMN_TOPO], m->f[MSOMN_QFORC], m->forcing_3d ? m->f[MSOMN_QFORC3D] : nullptr,
+                     m->f[MSOMN_MASK], m->sqg ? m->d2bs : nullptr, m->f[MSOMN_S2S], dq, m->g, nl, m->D, p.beta, drag, p.f0, p.dh[nl - 1], p.nu, -p.nu4, m->lc, m->pg_set, m->topo_set);
+    HIPCHK(hipGetLastError());
+    return MSOM_OK;
+  }
   launch_n_mul_mask(m->st, q, psi, m->f[MSOMN_MASK], m->g, nl);                 // :110-116
   launch_n_del2(m->st, psi, zeta, m->g, nl, 0., 1., m->D);                      // comp_del2(psi, zeta, 0, 1)
   bnd_q(m, zeta);
@@ -563,16 +588,34 @@ static int download_lev(msomn *m, NLevel &L, const double *src, double *a) {
   return download_g(m, L.da2, L.g, m->nl, a);
 }
 // vpoisson, nodal-poisson.h:19-143: residual first, then (unless converged) one cycle
-static int vpoisson(msomn *m, double *a, const double *b) {
+static int vpoisson(msomn *m, double *&a, const double *b) {
   msom_mgstats mg;
   mg.sum = HUGE_VAL; mg.resa = HUGE_VAL; mg.resb = 0; mg.nrelax = m->nrelax;
   const int nl = m->nl, nlev = m->nlev;
+  bool pending_correct = false;
   for (mg.i = 0; mg.i < m->nitermax; mg.i++) {
     HIPCHK(hipMemsetAsync(m->d_scal + NSC_RES, 0, sizeof(double), m->st));
-    nprof_begin(m, NP_RESIDUAL);
-    launch_n_residual(m->st, a, b, m->lev[0].mask, m->lev[0].S2, m->lev[0].res, m->d_scal + NSC_RES, m->g, nl, m->D, m->iRd2_low, m->lc,
-                      m->lev[0].sp ? &m->lev[0].ga : nullptr, m->lev[0].S2row);
-    nprof_end(m, NP_RESIDUAL);
+    // the correction of the previous cycle rides in this residual pass (option node_corr_fused; a second psi buffer)
+    if (pending_correct && m->node_corr_fused) {
+      int ra = need_psi_alt(m);
+      if (ra) return ra;
+      nprof_begin(m, NP_RESIDUAL);
+      launch_n_correct_residual(m->st, a, m->psi_alt, m->lev[0].da, m->lev[0].sp ? &m->lev[0].ga : nullptr, m->psi_bc, b, m->lev[0].mask, m->lev[0].S2,
+                                m->lev[0].res, m->d_scal + NSC_RES, m->g, nl, m->D, m->iRd2_low, m->lc, m->lev[0].sp ? &m->lev[0].ga : nullptr, m->lev[0].S2row);
+      nprof_end(m, NP_RESIDUAL);
+      std::swap(a, m->psi_alt);
+    } else {
+      if (pending_correct) {
+        nprof_begin(m, NP_CORRECT);
+        launch_n_correct(m->st, a, m->lev[0].da, m->g, nl, m->psi_bc, m->lev[0].sp ? &m->lev[0].ga : nullptr);
+        nprof_end(m, NP_CORRECT);
+      }
+      nprof_begin(m, NP_RESIDUAL);
+      launch_n_residual(m->st, a, b, m->lev[0].mask, m->lev[0].S2, m->lev[0].res, m->d_scal + NSC_RES, m->g, nl, m->D, m->iRd2_low, m->lc,
+                        m->lev[0].sp ? &m->lev[0].ga : nullptr, m->lev[0].S2row);
+      nprof_end(m, NP_RESIDUAL);
+    }
+    pending_correct = false;
     double max;
     int r = read_scalar(m, NSC_RES, &max);
     if (r) return r;
@@ -613,6 +656,9 @@ static int vpoisson(msomn *m, double *a, const double *b) {
       relax_sweeps(m, k, mg.nrelax, pending);
       pending = k > 0 ? prolong_into(k - 1) : 0;
     }
+    pending_correct = true;   // a += da: with the next residual, or below if the iteration count ends the loop
+  }
+  if (pending_correct) {
     nprof_begin(m, NP_CORRECT);
     launch_n_correct(m->st, a, m->lev[0].da, m->g, nl, m->psi_bc, m->lev[0].sp ? &m->lev[0].ga : nullptr);
     nprof_end(m, NP_CORRECT);
@@ -1130,6 +1176,8 @@ extern "C" int msomn_read_nc(msomn_t *m, int field, const char *path, const char
   const size_t n1 = m->N + 1;
   std::vector<double> h(n1 * n1 * m->fl[field]);
   if (msom_nc_read(path, varname, record, m->fl[field], (int)n1, (int)n1, h.data(), nullptr)) return MSOM_ERR_IO;
+  if (field == MSOMN_PSIPG) m->pg_set = 1;
+  if (field == MSOMN_TOPO) m->topo_set = 1;
   return upload_g(m, m->f[field], m->g, m->fl[field], h.data());
 }
 

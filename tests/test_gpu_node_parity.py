@@ -411,3 +411,32 @@ def test_chained_half_sweeps_in_the_split_layout(nl, N, strict):
     for name, _ in FIELDS:
         assert np.array_equal(g2.get(name), g.get(name)) or not strict
     assert g2.mgstats().i == g.mgstats().i
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nl,N,split,nitermax", [(1, 256, 65, 100), (3, 128, 65, 100), (3, 256, 65, 3), (4, 64, 0, 2), (6, 128, 65, 100)])
+def test_correction_riding_in_the_next_residual_pass(nl, N, split, nitermax, strict):
+    """k_n_correct_residual (round 3): a += da of cycle i is applied inside the residual pass of cycle i + 1 (second psi buffer,
+    swapped); the last correction of a solve that ends on the iteration count is the plain kernel.  TOLERANCE 1e-10: several cycles
+    per solve.  Against the oracle and (strict build: bit for bit) against the run with separate passes"""
+    if nl not in orn.NODE_LAYERS:
+        orn.NODE_LAYERS[nl] = ("[" + ",".join(["%.3f" % (1.0 / nl)] * nl) + "]", "[" + ",".join(["%d." % (9000 - 900 * l) for l in range(nl - 1)]) + "]")
+    kw = dict(mask=True, bc_fac=0.5, topo=True, extra="gp_low = 0.02\n", TOLERANCE=1e-10, NITERMAX=nitermax)
+    o, g = make_pair(N, nl, strict, **kw)
+    _, g2 = make_pair(N, nl, strict, **kw)
+    for h, on in ((g, 1), (g2, 0)):
+        h.set_option("node_split", split if split else 1 << 20)
+        h.set_option("node_corr_fused", on)
+        h.set_option("node_rhs_fused", on)         # and the tendency in three passes against the twelve loops
+        h.set_tnext(float("inf"))
+    o.set_tnext(float("inf"))
+    cyc = 0
+    for _ in range(3):
+        o.step(True); g.step(True); g2.step(True)
+        assert g.mgstats().i == g2.mgstats().i
+        assert g.mgstats().i == o.mgstats().i or not strict
+        cyc = max(cyc, g.mgstats().i)
+    assert cyc >= 2 or nl == 1          # the fused pass ran (the one-layer Helmholtz problem converges in one cycle)
+    for name, idx in FIELDS:
+        same(g.get(name), g2.get(name), strict, 1e-9)       # product build: the compiler contracts the merged expressions differently
+        same(g.get(name), o.get(idx), strict, 1e-6)
