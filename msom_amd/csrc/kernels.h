@@ -180,14 +180,14 @@ int launch_n_relax_tile(hipStream_t st, const double *a_in, double *a_out, const
                         int nl, int ns, double D, double iRd2, const LayerCoef &lc);
 void launch_n_residual(hipStream_t st, const double *a, const double *b, const double *mk, const double *S2, double *res, double *maxres,
                        const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc, const NatGeom *gres = nullptr,
-                       const double *S2row = nullptr);  // gres: res in the split layout; S2row: row table of an x-independent S2
+                       const double *S2row = nullptr, int zb = 0);  // gres: res in the split layout; S2row: row table of an x-independent S2; zb: 0 on the boundary vertices
 // coarse levels of a vpoisson cycle in one launch (k_n_mg_coarse): lev[0] = finest of the group
 #define NMGC_MAXLEV 8
 #define NMGC_NT 1024
 struct NCoarseLev { double *da, *res; const double *mask, *S2; NatGeom g; double sqD; };
 struct NCoarseArgs { NCoarseLev lev[NMGC_MAXLEV]; int n; double iRd2; LayerCoef lc; };
 void launch_n_mg_coarse(hipStream_t st, const NCoarseArgs &a, int nrelax, int nl);
-void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind, int fsp = 0, int csp = 0);
+void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind, int fsp = 0, int csp = 0, int zb = 0);
 void launch_n_prolong(hipStream_t st, const double *c, const NatGeom &cg, double *f, const NatGeom &fg, int nl, int csp = 0, int fsp = 0);
 void launch_n_correct(hipStream_t st, double *a, const double *da, const NatGeom &g, int nl, double bcv, const NatGeom *gda = nullptr);
 void launch_n_correct_residual(hipStream_t st, const double *a, double *a_out, const double *da, const NatGeom *gda, double bcv, const double *b, const double *mk,

@@ -1008,6 +1008,7 @@ struct NResArgs {
   NatGeom g, gr;  // gr, sp: geometry and layout of res
   const double *S2row;  // S2 independent of x: [l * g.ny + j], else null
   int nl, sp;
+  int zb;   // 1: the boundary vertices of res get 0 after the maximum took their value (boundary_level; formerly a launch of k_n_bnd_const)
   double sqD, iRd2;
   LayerCoef lc;
 };
@@ -1020,6 +1021,7 @@ __global__ void k_n_residual(NResArgs p) {
     const int nl = p.nl, pitch = p.g.pitch;
     const size_t ls = p.g.ls, c0 = nat_idx(p.g, 0, j, i);
     const double m = p.mk[c0], sq = p.sqD, rsq = 1. / sq;
+    const bool zb = p.zb && (i == 0 || j == 0 || i == p.g.nx - 1 || j == p.g.ny - 1);
     for (int l = 0; l < nl; l++) {
       const size_t c = c0 + l * ls;
       const double a1 = p.a[c];
@@ -1032,7 +1034,7 @@ __global__ void k_n_residual(NResArgs p) {
       else r = (p.b[c] + s2m * (a1 - p.a[c - ls]) * p.lc.idh0[l]) * m;
       r -= DIVC(p.a[c - 1] - 2. * a1 + p.a[c + 1], sq, rsq) * m;
       r -= DIVC(p.a[c - pitch] - 2. * a1 + p.a[c + pitch], sq, rsq) * m;
-      p.res[p.sp ? gidx(p.gr, 1, l, j, i) : c] = r;
+      p.res[p.sp ? gidx(p.gr, 1, l, j, i) : c] = zb ? 0. : r;
       mx = fmax(mx, fabs(r));
     }
   }
@@ -1047,8 +1049,9 @@ __global__ void k_n_residual(NResArgs p) {
   }
 }
 void launch_n_residual(hipStream_t st, const double *a, const double *b, const double *mk, const double *S2, double *res, double *maxres,
-                       const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc, const NatGeom *gres, const double *S2row) {
+                       const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc, const NatGeom *gres, const double *S2row, int zb) {
   NResArgs p;
+  p.zb = zb;
   p.S2row = S2row;
   p.a = a; p.b = b; p.mk = mk; p.S2 = S2; p.res = res; p.maxres = maxres; p.g = g; p.nl = nl; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc;
   p.sp = gres != nullptr; p.gr = gres ? *gres : g;
@@ -1073,6 +1076,7 @@ __global__ void k_n_correct_residual(NResArgs p, const double *__restrict__ da, 
       return av + da[gidx(gd, dsp, l, jj, ii)];
     };
     const double m = p.mk[c0], sq = p.sqD, rsq = 1. / sq;
+    const bool zb = p.zb && (i == 0 || j == 0 || i == p.g.nx - 1 || j == p.g.ny - 1);
     for (int l = 0; l < nl; l++) {
       const size_t c = c0 + l * ls;
       const double a1 = anew(l, j, i);
@@ -1086,7 +1090,7 @@ __global__ void k_n_correct_residual(NResArgs p, const double *__restrict__ da, 
       else r = (p.b[c] + s2m * (a1 - anew(l - 1, j, i)) * p.lc.idh0[l]) * m;
       r -= DIVC(anew(l, j, i - 1) - 2. * a1 + anew(l, j, i + 1), sq, rsq) * m;
       r -= DIVC(anew(l, j - 1, i) - 2. * a1 + anew(l, j + 1, i), sq, rsq) * m;
-      p.res[p.sp ? gidx(p.gr, 1, l, j, i) : c] = r;
+      p.res[p.sp ? gidx(p.gr, 1, l, j, i) : c] = zb ? 0. : r;
       mx = fmax(mx, fabs(r));
     }
   }
@@ -1104,6 +1108,7 @@ void launch_n_correct_residual(hipStream_t st, const double *a, double *a_out, c
                                const double *S2, double *res, double *maxres, const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc,
                                const NatGeom *gres, const double *S2row) {
   NResArgs p;
+  p.zb = 1;
   p.S2row = S2row;
   p.a = a; p.b = b; p.mk = mk; p.S2 = S2; p.res = res; p.maxres = maxres; p.g = g; p.nl = nl; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc;
   p.sp = gres != nullptr; p.gr = gres ? *gres : g;
@@ -1122,27 +1127,36 @@ __device__ __forceinline__ void n_restrict_pt(const double *__restrict__ f, cons
     c[nat_idx(cg, l, J, I)] = v;
   }
 }
-__global__ void k_n_restrict(const double *__restrict__ f, NatGeom fg, double *c, NatGeom cg, int nl, int kind) {
+// zb: the boundary vertices of the coarse level get 0 (boundary_level of the residual, formerly a launch of k_n_bnd_const)
+__global__ void k_n_restrict(const double *__restrict__ f, NatGeom fg, double *c, NatGeom cg, int nl, int kind, int zb) {
   VTX(cg, I, J);
+  if (zb && (I == 0 || J == 0 || I == cg.nx - 1 || J == cg.ny - 1)) {
+    for (int l = 0; l < nl; l++) c[nat_idx(cg, l, J, I)] = 0.;
+    return;
+  }
   n_restrict_pt(f, fg, c, cg, nl, kind, I, J);
 }
 // residual restriction (kind 0) with either side in the split layout: the five fine vertices of a coarse one are unit-stride
 // runs of the even half (2I) and of the odd half (2I +- 1)
-__global__ void k_n_restrict_s(const double *__restrict__ f, NatGeom fg, int fsp, double *c, NatGeom cg, int csp, int nl) {
+__global__ void k_n_restrict_s(const double *__restrict__ f, NatGeom fg, int fsp, double *c, NatGeom cg, int csp, int nl, int zb) {
   VTX(cg, I, J);
+  if (zb && (I == 0 || J == 0 || I == cg.nx - 1 || J == cg.ny - 1)) {
+    for (int l = 0; l < nl; l++) c[gidx(cg, csp, l, J, I)] = 0.;
+    return;
+  }
   for (int l = 0; l < nl; l++) {
     const double v = (f[gidx(fg, fsp, l, 2 * J, 2 * I + 1)] + 2 * f[gidx(fg, fsp, l, 2 * J, 2 * I)] + f[gidx(fg, fsp, l, 2 * J, 2 * I - 1)] +
                       f[gidx(fg, fsp, l, 2 * J + 1, 2 * I)] + f[gidx(fg, fsp, l, 2 * J - 1, 2 * I)]) / 6.;
     c[gidx(cg, csp, l, J, I)] = v;
   }
 }
-void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind, int fsp, int csp) {
+void launch_n_restrict(hipStream_t st, const double *f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind, int fsp, int csp, int zb) {
   if (fsp || csp) {
     if (kind != 0) { fprintf(stderr, "msom: launch_n_restrict: split layout only for the residual\n"); abort(); }
-    hipLaunchKernelGGL(k_n_restrict_s, grid2d(cg.nx, cg.ny), block2d(), 0, st, f, fg, fsp, c, cg, csp, nl);
+    hipLaunchKernelGGL(k_n_restrict_s, grid2d(cg.nx, cg.ny), block2d(), 0, st, f, fg, fsp, c, cg, csp, nl, zb);
     return;
   }
-  hipLaunchKernelGGL(k_n_restrict, grid2d(cg.nx, cg.ny), block2d(), 0, st, f, fg, c, cg, nl, kind);
+  hipLaunchKernelGGL(k_n_restrict, grid2d(cg.nx, cg.ny), block2d(), 0, st, f, fg, c, cg, nl, kind, zb);
 }
 // refine_vert my_vertex.h:82-105 followed by boundary_level(da) = 0 on the boundary vertices; one thread per FINE vertex
 __device__ __forceinline__ void n_prolong_pt(const double *__restrict__ c, const NatGeom &cg, double *f, const NatGeom &fg, int nl, int i, int j) {

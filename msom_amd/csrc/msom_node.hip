@@ -612,7 +612,7 @@ static int vpoisson(msomn *m, double *&a, const double *b) {
       }
       nprof_begin(m, NP_RESIDUAL);
       launch_n_residual(m->st, a, b, m->lev[0].mask, m->lev[0].S2, m->lev[0].res, m->d_scal + NSC_RES, m->g, nl, m->D, m->iRd2_low, m->lc,
-                        m->lev[0].sp ? &m->lev[0].ga : nullptr, m->lev[0].S2row);
+                        m->lev[0].sp ? &m->lev[0].ga : nullptr, m->lev[0].S2row, 1);
       nprof_end(m, NP_RESIDUAL);
     }
     pending_correct = false;
@@ -622,7 +622,7 @@ static int vpoisson(msomn *m, double *&a, const double *b) {
     mg.resa = max;
     if (mg.i == 0) mg.resb = max;
     if (max < m->tolerance && mg.i >= m->nitermin) break;
-    launch_n_bnd_const(m->st, m->lev[0].res, m->lev[0].ga, nl, 0., m->lev[0].sp);
+    // (boundary_level of the residual: its boundary vertices were stored as 0 by the pass above, zb = 1)
     // kc: first level of the group that one workgroup handles in one launch (<= 33^2 vertices, at least two levels)
     int kc = nlev;
     if (m->mg_coarse) {
@@ -631,8 +631,7 @@ static int vpoisson(msomn *m, double *&a, const double *b) {
       if (nlev - k0 >= 2 && nlev - k0 <= NMGC_MAXLEV) kc = k0;
     }
     for (int k = 1; k < nlev && k <= kc; k++) {  // the boundary vertices of every level end up 0 (boundary_level)
-      launch_n_restrict(m->st, m->lev[k - 1].res, m->lev[k - 1].ga, m->lev[k].res, m->lev[k].ga, nl, 0, m->lev[k - 1].sp, m->lev[k].sp);
-      launch_n_bnd_const(m->st, m->lev[k].res, m->lev[k].ga, nl, 0., m->lev[k].sp);
+      launch_n_restrict(m->st, m->lev[k - 1].res, m->lev[k - 1].ga, m->lev[k].res, m->lev[k].ga, nl, 0, m->lev[k - 1].sp, m->lev[k].sp, 1);
     }
     if (kc < nlev) {
       NCoarseArgs ca;
