@@ -192,7 +192,7 @@ void launch_n_prolong(hipStream_t st, const double *c, const NatGeom &cg, double
 void launch_n_correct(hipStream_t st, double *a, const double *da, const NatGeom &g, int nl, double bcv, const NatGeom *gda = nullptr);
 void launch_n_correct_residual(hipStream_t st, const double *a, double *a_out, const double *da, const NatGeom *gda, double bcv, const double *b, const double *mk,
                                const double *S2, double *res, double *maxres, const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc,
-                               const NatGeom *gres, const double *S2row);
+                               const NatGeom *gres, const double *S2row, int march);
 void launch_n_row_table(hipStream_t st, const double *f, const NatGeom &g, int nl, double *out);
 void launch_n_relax_prolong(hipStream_t st, double *a, const double *b, const double *mk, const double *S2, const NatGeom &g, int nl, double D,
                             double iRd2, const LayerCoef &lc, const double *S2row, const double *coarse, const NatGeom &cg, int csp);

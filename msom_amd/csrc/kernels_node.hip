@@ -1104,15 +1104,105 @@ __global__ void k_n_correct_residual(NResArgs p, const double *__restrict__ da, 
     atomicMax((unsigned long long *)p.maxres, (unsigned long long)__double_as_longlong(v));
   }
 }
+// The same pass marching down chunks of NCR_H rows (round 3): lane = one vertex column (lanes 1..62 own a vertex, 0 and 63 carry the
+// x neighbours of the strip: 62 vertices per wavefront), the corrected psi of rows j - 1, j, j + 1 in registers, x neighbours by
+// whole-wave DPP shifts: psi and the correction are read once (+ 2 rows per chunk), not five times through the L1.
+#define NCR_WPB 4
+#define NCR_H 16
+template <int NL>
+__global__ void __launch_bounds__(64 * NCR_WPB) k_n_correct_residual_m(NResArgs p, const double *__restrict__ da, NatGeom gd, int dsp, double *__restrict__ a_out,
+                                                                       double bcv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = p.g.nx - 1;
+  const int strip = blockIdx.x * NCR_WPB + wave;
+  const int i = strip * 62 - 1 + lane;
+  double mx = 0.;
+  if (strip * 62 <= n) {   // wave-uniform: the DPP shifts below run with every lane of a live wavefront
+    const int il = i < n + 1 ? i : n + 1;       // column loaded (the pad columns -1 and n + 1 are memory of the field)
+    const bool own = lane >= 1 && lane <= 62 && i <= n;
+    const bool xin = il >= 1 && il <= n - 1, xout = il < 0 || il > n;
+    const size_t ls = p.g.ls;
+    const int j0 = blockIdx.y * NCR_H, j1 = j0 + NCR_H < n + 1 ? j0 + NCR_H : n + 1;
+    // corrected psi of row j at column il: psi itself beyond the grid, the boundary value on the sides, psi + da inside (k_n_correct)
+    auto row = [&](int j, double (&v)[NL]) {
+      const bool yout = j < 0 || j > n, yin = j >= 1 && j <= n - 1;
+      const size_t k = nat_idx(p.g, 0, j, il), kd = gidx(gd, dsp, 0, yin ? j : 1, xin ? il : 1);
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        const double av = p.a[k + l * ls], d = da[kd + l * gd.ls];
+        v[l] = (xout || yout) ? av : ((xin && yin) ? av + d : bcv);
+      }
+    };
+    double prev[NL], cur[NL], next[NL];
+    row(j0 - 1, prev);
+    row(j0, cur);
+    const double sq = p.sqD, rsq = 1. / sq;
+    for (int j = j0; j < j1; j++) {
+      row(j + 1, next);
+      const size_t c0 = nat_idx(p.g, 0, j, il);
+      const double m = p.mk[c0];
+      const bool zb = i == 0 || j == 0 || i == n || j == n;
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        const double a1 = cur[l];
+        const double aw = lane_below(a1), ae = lane_above(a1);
+        if (own) {
+          const size_t c = c0 + l * ls;
+          a_out[c] = a1;
+          double r;
+          const double s2m = (NL > 1 && l > 0) ? (p.S2row ? p.S2row[(l - 1) * p.g.ny + j] : p.S2[c - ls]) : 0.;
+          const double s2c = (NL > 1 && l < NL - 1) ? (p.S2row ? p.S2row[l * p.g.ny + j] : p.S2[c]) : 0.;
+          if (NL == 1) r = (p.b[c] - (-p.iRd2 * a1)) * m;
+          else if (l == 0) r = (p.b[c] + s2c * (a1 - cur[l + 1 < NL ? l + 1 : l]) * p.lc.idh1[l]) * m;
+          else if (l < NL - 1) r = (p.b[c] + s2m * (a1 - cur[l - 1]) * p.lc.idh0[l] - s2c * (cur[l + 1 < NL ? l + 1 : l] - a1) * p.lc.idh1[l]) * m;
+          else r = (p.b[c] + s2m * (a1 - cur[l > 0 ? l - 1 : 0]) * p.lc.idh0[l]) * m;
+          r -= DIVC(aw - 2. * a1 + ae, sq, rsq) * m;
+          r -= DIVC(prev[l] - 2. * a1 + next[l], sq, rsq) * m;
+          p.res[p.sp ? gidx(p.gr, 1, l, j, i) : c] = zb ? 0. : r;
+          mx = fmax(mx, fabs(r));
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < NL; l++) { prev[l] = cur[l]; cur[l] = next[l]; }
+    }
+  }
+  __shared__ double sm[NCR_WPB];
+  mx = wave_max_n(mx);
+  if (lane == 0) sm[wave] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = sm[0];
+    for (int k = 1; k < NCR_WPB; k++) v = fmax(v, sm[k]);
+    atomicMax((unsigned long long *)p.maxres, (unsigned long long)__double_as_longlong(v));
+  }
+}
+template <int NL>
+static void ncr_launch(hipStream_t st, const NResArgs &p, const double *da, const NatGeom &gd, int dsp, double *a_out, double bcv) {
+  const int strips = (p.g.nx + 61) / 62;
+  hipLaunchKernelGGL(k_n_correct_residual_m<NL>, dim3((strips + NCR_WPB - 1) / NCR_WPB, (p.g.ny + NCR_H - 1) / NCR_H), dim3(64 * NCR_WPB), 0, st, p, da, gd, dsp,
+                     a_out, bcv);
+}
 void launch_n_correct_residual(hipStream_t st, const double *a, double *a_out, const double *da, const NatGeom *gda, double bcv, const double *b, const double *mk,
                                const double *S2, double *res, double *maxres, const NatGeom &g, int nl, double D, double iRd2, const LayerCoef &lc,
-                               const NatGeom *gres, const double *S2row) {
+                               const NatGeom *gres, const double *S2row, int march) {
   NResArgs p;
   p.zb = 1;
   p.S2row = S2row;
   p.a = a; p.b = b; p.mk = mk; p.S2 = S2; p.res = res; p.maxres = maxres; p.g = g; p.nl = nl; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc;
   p.sp = gres != nullptr; p.gr = gres ? *gres : g;
-  hipLaunchKernelGGL(k_n_correct_residual, grid_capped(g.nx, g.ny), block2d(), 0, st, p, da, gda ? *gda : g, gda != nullptr, a_out, bcv);
+  const NatGeom gd = gda ? *gda : g;
+  const int dsp = gda != nullptr;
+  switch (march ? nl : 0) {
+    case 1: ncr_launch<1>(st, p, da, gd, dsp, a_out, bcv); break;
+    case 2: ncr_launch<2>(st, p, da, gd, dsp, a_out, bcv); break;
+    case 3: ncr_launch<3>(st, p, da, gd, dsp, a_out, bcv); break;
+    case 4: ncr_launch<4>(st, p, da, gd, dsp, a_out, bcv); break;
+    case 5: ncr_launch<5>(st, p, da, gd, dsp, a_out, bcv); break;
+    case 6: ncr_launch<6>(st, p, da, gd, dsp, a_out, bcv); break;
+    case 7: ncr_launch<7>(st, p, da, gd, dsp, a_out, bcv); break;
+    case 8: ncr_launch<8>(st, p, da, gd, dsp, a_out, bcv); break;
+    default: hipLaunchKernelGGL(k_n_correct_residual, grid_capped(g.nx, g.ny), block2d(), 0, st, p, da, gd, dsp, a_out, bcv);
+  }
 }
 // restriction_coarsen_vert (residual), restriction_coarsen_vert2 (mask), restriction_vert (injection), my_vertex.h:49-75
 __device__ __forceinline__ void n_restrict_pt(const double *__restrict__ f, const NatGeom &fg, double *c, const NatGeom &cg, int nl, int kind, int I, int J) {

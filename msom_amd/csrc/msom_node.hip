@@ -79,7 +79,7 @@ struct msomn {
                         // solve (vertex-dependent coefficients, one reciprocal per layer) is arithmetic-bound: off
   int node_pfused = 1;   // option: prolongation folded into the first colour pass of the split levels
   int node_rhs_fused = 1;   // option: the baroclinic tendency in three passes (k_n_rhs_pre, k_n_del2_bnd, k_n_rhs_all) instead of twelve
-  int node_corr_fused = 0;  // option: the correction a += da rides in the next cycle's residual pass (k_n_correct_residual)
+  int node_corr_fused = 2;  // option: the correction a += da rides in the next cycle's residual pass (k_n_correct_residual)
   double *psi_alt = nullptr;
   int node_march_s = 2049;  // option: split levels of >= node_march_s vertices per side chain up to 4 colour half-sweeps per pass (k_n_relax_march_s,
                             // round 3).  2049^2 x 3, 9 cycles per solve (tools/ab_node_prof.py): 3 passes of 83 us replace 9 colour launches of 33 us:
@@ -601,7 +601,8 @@ static int vpoisson(msomn *m, double *&a, const double *b) {
       if (ra) return ra;
       nprof_begin(m, NP_RESIDUAL);
       launch_n_correct_residual(m->st, a, m->psi_alt, m->lev[0].da, m->lev[0].sp ? &m->lev[0].ga : nullptr, m->psi_bc, b, m->lev[0].mask, m->lev[0].S2,
-                                m->lev[0].res, m->d_scal + NSC_RES, m->g, nl, m->D, m->iRd2_low, m->lc, m->lev[0].sp ? &m->lev[0].ga : nullptr, m->lev[0].S2row);
+                                m->lev[0].res, m->d_scal + NSC_RES, m->g, nl, m->D, m->iRd2_low, m->lc, m->lev[0].sp ? &m->lev[0].ga : nullptr, m->lev[0].S2row,
+                                m->node_corr_fused >= 2);
       nprof_end(m, NP_RESIDUAL);
       std::swap(a, m->psi_alt);
     } else {

@@ -424,7 +424,8 @@ def test_correction_riding_in_the_next_residual_pass(nl, N, split, nitermax, str
     kw = dict(mask=True, bc_fac=0.5, topo=True, extra="gp_low = 0.02\n", TOLERANCE=1e-10, NITERMAX=nitermax)
     o, g = make_pair(N, nl, strict, **kw)
     _, g2 = make_pair(N, nl, strict, **kw)
-    for h, on in ((g, 1), (g2, 0)):
+    _, g3 = make_pair(N, nl, strict, **kw)
+    for h, on in ((g, 2), (g2, 0), (g3, 1)):       # 2 (default): the row-marching kernel, 1: one thread per vertex, 0: separate passes
         h.set_option("node_split", split if split else 1 << 20)
         h.set_option("node_corr_fused", on)
         h.set_option("node_rhs_fused", on)         # and the tendency in three passes against the twelve loops
@@ -432,11 +433,12 @@ def test_correction_riding_in_the_next_residual_pass(nl, N, split, nitermax, str
     o.set_tnext(float("inf"))
     cyc = 0
     for _ in range(3):
-        o.step(True); g.step(True); g2.step(True)
-        assert g.mgstats().i == g2.mgstats().i
+        o.step(True); g.step(True); g2.step(True); g3.step(True)
+        assert g.mgstats().i == g2.mgstats().i == g3.mgstats().i
         assert g.mgstats().i == o.mgstats().i or not strict
         cyc = max(cyc, g.mgstats().i)
     assert cyc >= 2 or nl == 1          # the fused pass ran (the one-layer Helmholtz problem converges in one cycle)
     for name, idx in FIELDS:
         same(g.get(name), g2.get(name), strict, 1e-9)       # product build: the compiler contracts the merged expressions differently
+        same(g3.get(name), g2.get(name), strict, 1e-9)
         same(g.get(name), o.get(idx), strict, 1e-6)
