@@ -176,6 +176,8 @@ int launch_n_relax_march(hipStream_t st, const double *a_in, double *a_out, cons
                          int color, int K, double D, double iRd2, const LayerCoef &lc);
 int launch_n_relax_march_s(hipStream_t st, const double *a_in, double *a_out, const double *b, const double *mk, const NatGeom &g, int nl, int color, int K,
                            double D, double iRd2, const LayerCoef &lc, const double *S2row, int partial);
+int launch_n_relax_tile_s(hipStream_t st, const double *a_in, double *a_out, const double *b, const double *mk, const NatGeom &g, int nl, int color, int K,
+                          double D, double iRd2, const LayerCoef &lc, const double *S2row);
 int launch_n_relax_tile(hipStream_t st, const double *a_in, double *a_out, const double *b, const double *mk, const double *S2, const NatGeom &g,
                         int nl, int ns, double D, double iRd2, const LayerCoef &lc);
 void launch_n_residual(hipStream_t st, const double *a, const double *b, const double *mk, const double *S2, double *res, double *maxres,

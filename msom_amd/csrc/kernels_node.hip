@@ -893,6 +893,87 @@ int launch_n_relax_march(hipStream_t st, const double *a_in, double *a_out, cons
   return -1;
 }
 
+// K (2..8) colour half-sweeps of a split level in one launch, for the levels whose colour passes are launch-bound (65 .. 1025 vertices
+// a side at 2049^2: ~4.5 us per pass whatever the size; round 3).  One 1024-thread workgroup per tile of T = 40 - 2 H vertices a side
+// (H = K rounded up to even: 32^2 for K <= 4, 24^2 for K = 8): the tile of the correction with a halo of H goes to LDS (40^2 vertices
+// per layer), half-sweep h updates the vertices of its colour inside tile +- (K - 1 - h) -- a vertex is
+// updated only where its four neighbours carry the values of the previous half-sweep, so every update is the one of the
+// colour-per-launch pass, bit for bit (the argument of k_n_relax_tile) -- then the tile is stored (out of place: a_in -> p.a).
+// A thread owns the vertex pair (2k, 2k + 1) of one row, one vertex of each colour: residual, mask and the S2 row values stay in
+// its registers for all K half-sweeps; the column solve is n_col_solve_vals.
+#define NTS_L 40
+#define NTS_KMAX 8
+#define NTS_NT 1024
+template <int NL>
+__global__ void __launch_bounds__(NTS_NT) k_n_relax_tile_s(NRelaxArgs p, const double *__restrict__ a_in, int K) {
+  __shared__ double A[NL][NTS_L][NTS_L + 1];
+  const int tid = threadIdx.x, n = p.g.nx - 1;
+  const int NTS_H = (K + 1) & ~1, NTS_T = NTS_L - 2 * NTS_H;
+  const int x0 = blockIdx.x * NTS_T - NTS_H, y0 = blockIdx.y * NTS_T - NTS_H;   // first vertex of the LDS region (x0 even)
+  for (int t = tid; t < NL * NTS_L * NTS_L; t += NTS_NT) {
+    const int l = t / (NTS_L * NTS_L), r = (t / NTS_L) % NTS_L, c = t % NTS_L;
+    const int gi = x0 + c, gj = y0 + r;
+    A[l][r][c] = (gi >= 0 && gi <= n && gj >= 0 && gj <= n) ? a_in[gidx(p.g, 1, l, gj, gi)] : 0.;
+  }
+  // this thread's vertex pair: row r, columns 2k, 2k + 1 of the region
+  const int r = tid / (NTS_L / 2), k2 = 2 * (tid % (NTS_L / 2));
+  const int gj = y0 + r;
+  const bool rowok = tid < NTS_L * (NTS_L / 2) && gj >= 1 && gj <= n - 1;
+  double bv[2][NL], mv[2], sv[NL];
+#pragma unroll
+  for (int v = 0; v < 2; v++) {
+    const int gi = x0 + k2 + v;
+    const bool ok = rowok && gi >= 1 && gi <= n - 1;
+    const size_t c = gidx(p.g, 1, 0, ok ? gj : 1, ok ? gi : 1);
+    mv[v] = p.mk[c];
+#pragma unroll
+    for (int l = 0; l < NL; l++) bv[v][l] = p.b[c + l * p.g.ls];
+  }
+#pragma unroll
+  for (int l = 0; l < NL; l++) sv[l] = (NL > 1 && l < NL - 1) ? p.S2row[l * p.g.ny + (rowok ? gj : 1)] : 0.;
+  __syncthreads();
+  for (int h = 0; h < K; h++) {
+    const int e = K - 1 - h, col = (p.color + h) & 1;
+    const int v = (gj + col) & 1;           // x0 + k2 is even: the vertex of colour col of the pair
+    const int lc = k2 + v, gi = x0 + lc;
+    const bool act = rowok && gi >= 1 && gi <= n - 1 && r >= NTS_H - e && r < NTS_H + NTS_T + e && lc >= NTS_H - e && lc < NTS_H + NTS_T + e;
+    if (act) {
+      double ew[NL], ns[NL], x[NL], b1[NL];
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        ew[l] = A[l][r][lc + 1] + A[l][r][lc - 1];
+        ns[l] = A[l][r + 1][lc] + A[l][r - 1][lc];
+        b1[l] = v ? bv[1][l] : bv[0][l];
+      }
+      n_col_solve_vals<NL>(p, b1, v ? mv[1] : mv[0], sv, ew, ns, x);
+#pragma unroll
+      for (int l = 0; l < NL; l++) A[l][r][lc] = x[l];
+    }
+    __syncthreads();
+  }
+  for (int t = tid; t < NL * NTS_T * NTS_T; t += NTS_NT) {
+    const int l = t / (NTS_T * NTS_T), rr = (t / NTS_T) % NTS_T, c = t % NTS_T;
+    const int gi = x0 + NTS_H + c, gj2 = y0 + NTS_H + rr;
+    if (gi <= n && gj2 <= n) p.a[gidx(p.g, 1, l, gj2, gi)] = A[l][rr + NTS_H][c + NTS_H];
+  }
+}
+// K (2..4) half-sweeps of a split level starting with colour `color`, a_in -> a_out; -1: not available for this nl / S2 (use the colour passes)
+int launch_n_relax_tile_s(hipStream_t st, const double *a_in, double *a_out, const double *b, const double *mk, const NatGeom &g, int nl, int color, int K,
+                          double D, double iRd2, const LayerCoef &lc, const double *S2row) {
+  if (K < 2 || K > NTS_KMAX || (nl > 1 && !S2row)) return -1;
+  const int NTS_T = NTS_L - 2 * ((K + 1) & ~1);
+  NRelaxArgs p;
+  p.a = a_out; p.b = b; p.mk = mk; p.S2 = nullptr; p.g = g; p.color = color; p.sqD = D * D; p.iRd2 = iRd2; p.lc = lc; p.S2row = S2row;
+  const dim3 grid((g.nx + NTS_T - 1) / NTS_T, (g.ny + NTS_T - 1) / NTS_T);
+  switch (nl) {
+    case 1: hipLaunchKernelGGL(k_n_relax_tile_s<1>, grid, dim3(NTS_NT), 0, st, p, a_in, K); return 0;
+    case 2: hipLaunchKernelGGL(k_n_relax_tile_s<2>, grid, dim3(NTS_NT), 0, st, p, a_in, K); return 0;
+    case 3: hipLaunchKernelGGL(k_n_relax_tile_s<3>, grid, dim3(NTS_NT), 0, st, p, a_in, K); return 0;
+    case 4: hipLaunchKernelGGL(k_n_relax_tile_s<4>, grid, dim3(NTS_NT), 0, st, p, a_in, K); return 0;
+  }
+  return -1;
+}
+
 // NS full red-black sweeps in ONE pass over HBM, out of place (a_in -> a_out; neighbouring workgroups read each
 // other's tiles): a 64 x TH tile of the correction with a 2 NS halo goes to LDS, half-sweep h updates the
 // cells of colour h & 1 inside the region tile +- (2 NS - 1 - h) -- a cell is updated only when its four

@@ -78,6 +78,9 @@ struct msomn {
                         // half the bytes, but in the natural layout half of the lanes idle in every half-sweep and the vertex column
                         // solve (vertex-dependent coefficients, one reciprocal per layer) is arithmetic-bound: off
   int node_pfused = 1;   // option: prolongation folded into the first colour pass of the split levels
+  int node_tile_max = 513;  // option: ... and of <= node_tile_max vertices per side (wider levels: the colour passes are no longer launch-bound)
+  int node_tile_k = 8;      // option: half-sweeps per LDS-tiled pass (2..8)
+  int node_tile_s = 65;     // option: split levels of >= node_tile_s (and < node_march_s) vertices per side: LDS-tiled passes of up to 4 colour half-sweeps (0: off)
   int node_rhs_fused = 1;   // option: the baroclinic tendency in three passes (k_n_rhs_pre, k_n_del2_bnd, k_n_rhs_all) instead of twelve
   int node_corr_fused = 2;  // option: the correction a += da rides in the next cycle's residual pass (k_n_correct_residual)
   double *psi_alt = nullptr;
@@ -313,6 +316,9 @@ extern "C" int msomn_set_option(msomn_t *m, const char *key, double v) {
   else if (!strcmp(key, "node_pfused")) m->node_pfused = (int)v;
   else if (!strcmp(key, "node_corr_fused")) m->node_corr_fused = (int)v;
   else if (!strcmp(key, "node_rhs_fused")) m->node_rhs_fused = (int)v;
+  else if (!strcmp(key, "node_tile_s")) m->node_tile_s = (int)v;
+  else if (!strcmp(key, "node_tile_max")) m->node_tile_max = (int)v;
+  else if (!strcmp(key, "node_tile_k")) { if (v < 2 || v > 8) return MSOM_ERR_ARG; m->node_tile_k = (int)v; }
   else if (!strcmp(key, "s2_rows")) { m->s2_rows = (int)v; if (m->const_set) return choose_layouts(m); }
   else if (!strcmp(key, "node_split")) { m->node_split = (int)v; if (m->const_set) return choose_layouts(m); }
   else if (!strcmp(key, "node_march")) m->node_march = (int)v;
@@ -497,6 +503,28 @@ static void relax_sweeps(msomn *m, int k, int nsweeps, int prolong = 0) {
       if (k == 0) nprof_begin(m, NP_MARCH);
       launch_n_relax_march_s(m->st, L.da, L.da2, L.res, L.mask_s, L.ga, m->nl, c, K, L.D, m->iRd2_low, m->lc, L.S2row, nh - K >= 1);
       if (k == 0) nprof_end(m, NP_MARCH);
+      std::swap(L.da, L.da2);
+      nh -= K; c = (c + K) & 1;
+    }
+    if (nh == 1) launch_n_relax(m->st, L.da, L.res, L.mask_s, L.S2_s, L.ga, m->nl, c, L.D, m->iRd2_low, m->lc, 1, L.S2row);
+    return;
+  }
+  if (L.sp && m->node_tile_s && L.n + 1 >= m->node_tile_s && L.n + 1 <= m->node_tile_max && m->nl <= 4 && (m->nl == 1 || L.S2row) && nsweeps >= 2) {
+    // launch-bound split levels (round 3): first colour with the prolongation as before, then LDS-tiled passes
+    // (k_n_relax_tile_s, out of place; up to node_tile_k = 8 half-sweeps each), a single left-over half-sweep as a colour pass
+    int nh = 2 * nsweeps, c = 0;
+    if (prolong) {
+      const NLevel &C = m->lev[k + 1];
+      if (k == 0) nprof_begin(m, NP_RELAX_PROLONG);
+      launch_n_relax_prolong(m->st, L.da, L.res, L.mask_s, L.S2_s, L.ga, m->nl, L.D, m->iRd2_low, m->lc, L.S2row, C.da, C.ga, C.sp);
+      if (k == 0) nprof_end(m, NP_RELAX_PROLONG);
+      nh--; c = 1;
+    }
+    while (nh >= 2) {
+      const int K = nh < m->node_tile_k ? nh : m->node_tile_k;   // a left-over single half-sweep is cheaper as a colour pass than as a tile pass
+      if (k == 0) nprof_begin(m, NP_RELAX);
+      launch_n_relax_tile_s(m->st, L.da, L.da2, L.res, L.mask_s, L.ga, m->nl, c, K, L.D, m->iRd2_low, m->lc, L.S2row);
+      if (k == 0) nprof_end(m, NP_RELAX);
       std::swap(L.da, L.da2);
       nh -= K; c = (c + K) & 1;
     }

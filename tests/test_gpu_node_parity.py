@@ -394,23 +394,30 @@ def test_chained_half_sweeps_in_the_split_layout(nl, N, strict):
             g.set_option("node_march_s", 65)
             got, ref = g.dbg_relax(k, da, res, ns), o.relax(k, da, res, ns)
             same(got, ref, strict, 1e-10)
-            g.set_option("node_march_s", 0)
+            g.set_option("node_march_s", 0)         # -> LDS-tiled passes of up to 4 half-sweeps (k_n_relax_tile_s), nl <= 4
+            tiled = g.dbg_relax(k, da, res, ns)
+            same(tiled, ref, strict, 1e-10)
+            g.set_option("node_tile_s", 0)          # -> one launch per colour
             plain = g.dbg_relax(k, da, res, ns)
-            assert np.array_equal(got, plain) or not strict
+            g.set_option("node_tile_s", 65)
+            assert (np.array_equal(got, plain) and np.array_equal(tiled, plain)) or not strict
     g.set_option("node_march_s", 65)
     o.set_tnext(float("inf")); g.set_tnext(float("inf"))
     for _ in range(2):
         o.step(True); g.step(True)
     for name, idx in FIELDS:
         same(g.get(name), o.get(idx), strict, 1e-6)
-    o2, g2 = make_pair(N, nl, strict, mask=True, bc_fac=0.5, extra="gp_low = 0.02\n")
-    g2.set_option("node_split", 65)
-    g2.set_tnext(float("inf"))
-    for _ in range(2):
-        g2.step(True)
-    for name, _ in FIELDS:
-        assert np.array_equal(g2.get(name), g.get(name)) or not strict
-    assert g2.mgstats().i == g.mgstats().i
+    for tile in (65, 0):        # without the chained pass: the tiled passes on every split level, then one launch per colour
+        o2, g2 = make_pair(N, nl, strict, mask=True, bc_fac=0.5, extra="gp_low = 0.02\n")
+        g2.set_option("node_split", 65)
+        g2.set_option("node_march_s", 1 << 20)
+        g2.set_option("node_tile_s", tile)
+        g2.set_tnext(float("inf"))
+        for _ in range(2):
+            g2.step(True)
+        for name, _ in FIELDS:
+            assert np.array_equal(g2.get(name), g.get(name)) or not strict
+        assert g2.mgstats().i == g.mgstats().i
 
 
 @pytest.mark.parametrize("strict", [True, False])
