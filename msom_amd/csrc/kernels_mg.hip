@@ -1444,25 +1444,28 @@ void launch_relax_color(hipStream_t st, double *da, const double *res, const dou
 // With PROLONG the tile is not read from da_in but interpolated from the next coarser
 // level on the fly (mg_cycle's bilinear prolongation + boundary_level, mspg/elliptic.h:74-82).
 // Walls: ghost cells lag exactly as in k_relax_color (the owner rewrites its ghost).
-#define BH 4
+// Round 3: the halo BH is a template parameter and the number of half-sweeps (nh <= BH) and their first colour (c0) are arguments:
+// with BH = 8 one launch does the prolongation and all 8 half-sweeps of a level visit (nrelax = 4), which on the launch-bound
+// levels (64^2 .. 512^2 cells: ~5 us per colour pass whatever the size) replaces 8 launches.
 #define BTX 64
 struct BlockArgs {
   const double *da_in, *res, *coarse;
   double *da_out;
   SplitGeom g, cg;
   int walls;
+  int nh, c0;   // half-sweeps of this pass (<= BH), colour of the first
   RelaxCoef rc;
 };
 
-template <int NL, int BTY, int BNT, bool PROLONG, bool FINE>
+template <int NL, int BTY, int BNT, bool PROLONG, bool FINE, int BH = 4, int BTXT = BTX>
 __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
-  constexpr int NX = BTX + 2 * BH, NY = BTY + 2 * BH, HX = NX / 2, LS = NY * 2 * HX;
+  constexpr int NX = BTXT + 2 * BH, NY = BTY + 2 * BH, HX = NX / 2, LS = NY * 2 * HX;
   constexpr int NPOS = (HX * NY + BNT - 1) / BNT;
   __shared__ double sA[NL * LS];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * BTX, y0 = blockIdx.y * BTY;
+  const int x0 = blockIdx.x * BTXT, y0 = blockIdx.y * BTY;
   const int nx = p.g.nx, ny = p.g.ny;
-  const bool wW = (p.walls & WALL_W) && x0 == 0, wE = (p.walls & WALL_E) && x0 + BTX >= nx;
+  const bool wW = (p.walls & WALL_W) && x0 == 0, wE = (p.walls & WALL_E) && x0 + BTXT >= nx;
   const bool wS = (p.walls & WALL_S) && y0 == 0, wN = (p.walls & WALL_N) && y0 + BTY >= ny;
   const bool edge_tile = wW | wE | wS | wN;
   const double sqD = p.rc.sqD;
@@ -1515,8 +1518,8 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
 
   // ---- 4 colour half-sweeps on the shrinking region
 #pragma unroll 1
-  for (int h = 1; h <= 2 * 2; h++) {
-    const int col = (h - 1) & 1;
+  for (int h = 1; h <= p.nh; h++) {
+    const int col = (p.c0 + h - 1) & 1;
 #pragma unroll
     for (int n = 0; n < NPOS; n++) {
       const int s = tid + n * BNT;
@@ -1576,7 +1579,7 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       const int xx = 2 * k + c, gx = x0 - BH + xx;
-      if (xx < BH || xx >= BH + BTX || gx >= nx) continue;
+      if (xx < BH || xx >= BH + BTXT || gx >= nx) continue;
       const size_t gdst = split_idx(p.g, 0, gy, gx);
 #pragma unroll
       for (int l = 0; l < NL; l++) {
@@ -1620,6 +1623,7 @@ void launch_relax_block2(hipStream_t st, const double *da_in, const double *coar
                          const SplitGeom &sg, int nl, const RelaxCoef &rc, int walls, int fine) {
   BlockArgs p;
   p.da_in = da_in; p.res = res; p.coarse = coarse; p.da_out = da_out; p.g = sg; p.cg = cg; p.walls = walls; p.rc = rc;
+  p.nh = 4; p.c0 = 0;
   const int prolong = coarse != nullptr;
   switch (nl) {
     case 1: block_dispatch<1>(st, p, prolong, fine); break;
@@ -1632,6 +1636,51 @@ void launch_relax_block2(hipStream_t st, const double *da_in, const double *coar
     case 8: block_dispatch<8>(st, p, prolong, fine); break;
     default: break;
   }
+}
+
+// up to 8 half-sweeps starting with colour c0 (+ the prolongation from `coarse` when given): 64 x 16 tile, halo 8, 640 threads
+// (two cell pairs each), LDS nl x 80 x 32 doubles (123 KB at nl = 6: one workgroup per CU, which the launch-bound levels do not fill anyway).
+// Returns -1 where the kernel does not exist (nl > 6)
+template <int NL, int TX, int TY, int NT>
+static void block8_launch_t(hipStream_t st, const BlockArgs &p, int prolong) {
+  dim3 gr((p.g.nx + TX - 1) / TX, (p.g.ny + TY - 1) / TY);
+  if (prolong) hipLaunchKernelGGL((k_relax_block<NL, TY, NT, true, false, 8, TX>), gr, dim3(NT), 0, st, p);
+  else hipLaunchKernelGGL((k_relax_block<NL, TY, NT, false, false, 8, TX>), gr, dim3(NT), 0, st, p);
+}
+// tile shape: the launch-bound levels have few tiles and the pass lasts as long as ONE workgroup does, so small tiles (16 x 16: four
+// times the half-sweep work of the level in halo cells, but a quarter of the serial work per workgroup) win up to 256^2; wider levels
+// take 32 x 16.  Measured at nl = 6 / nl = 3 (block_variant 6 = 64 x 16 everywhere, 3 = 16 x 16 everywhere): 4096^2 x 6 6.55 / 6.46 /
+// 6.39 ms per step with 64 x 16 / 16 x 16 / this rule, 512^2 x 3 0.447 / 0.400 / 0.388
+template <int NL>
+static void block8_launch(hipStream_t st, const BlockArgs &p, int prolong) {
+  switch (g_block_variant) {
+    case 1: block8_launch_t<NL, 32, 16, 768>(st, p, prolong); return;
+    case 2: block8_launch_t<NL, 32, 8, 576>(st, p, prolong); return;
+    case 3: block8_launch_t<NL, 16, 16, 512>(st, p, prolong); return;
+    case 6: block8_launch_t<NL, 64, 16, 640>(st, p, prolong); return;
+    default:
+      if (p.g.nx <= 256) block8_launch_t<NL, 16, 16, 512>(st, p, prolong);
+      else block8_launch_t<NL, 32, 16, 768>(st, p, prolong);
+      return;
+  }
+}
+int launch_relax_block8(hipStream_t st, const double *da_in, const double *coarse, const SplitGeom &cg, const double *res, double *da_out,
+                        const SplitGeom &sg, int nl, const RelaxCoef &rc, int walls, int nh, int c0) {
+  if (nh < 1 || nh > 8 || nl > 6) return -1;
+  BlockArgs p;
+  p.da_in = da_in; p.res = res; p.coarse = coarse; p.da_out = da_out; p.g = sg; p.cg = cg; p.walls = walls; p.rc = rc;
+  p.nh = nh; p.c0 = c0;
+  const int prolong = coarse != nullptr;
+  switch (nl) {
+    case 1: block8_launch<1>(st, p, prolong); break;
+    case 2: block8_launch<2>(st, p, prolong); break;
+    case 3: block8_launch<3>(st, p, prolong); break;
+    case 4: block8_launch<4>(st, p, prolong); break;
+    case 5: block8_launch<5>(st, p, prolong); break;
+    case 6: block8_launch<6>(st, p, prolong); break;
+    default: return -1;
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------ K12 correction a += da (+ boundary(a))

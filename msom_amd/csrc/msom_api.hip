@@ -123,6 +123,8 @@ struct msom {
   int stochastic = 0, corrector_step = 0, noise_mode = 0, stoch_fused = 1;
   int prolong_fused = 1;  // first red half-sweep of a level interpolates its neighbours from the coarser level
   int block_sweeps = 0;  // experimental temporally blocked smoother (2 sweeps per pass); measured not faster at nl = 6
+  int block8 = 1;        // round 3: prolongation + up to 8 half-sweeps of a launch-bound level in one launch (k_relax_block, halo 8)
+  int block8_max = 1024; // ... on levels of at most this many cells a side (and not marched)
   int block_small = 0;   // the same kernel on the launch-bound levels only (not marched, <= block_small cells wide): 2 launches per level visit instead of 8
   int march = 1;         // chained half-sweeps in register windows (kernels_march.hip) on wide single-GPU levels
   int march_k = 4;       // at most this many half-sweeps per pass (2..4)
@@ -709,6 +711,8 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "march_lean")) { extern int g_march_lean; g_march_lean = (int)v; }
   else if (!strcmp(key, "march_k")) m->march_k = (int)v < 2 ? 2 : ((int)v > 4 ? 4 : (int)v);
   else if (!strcmp(key, "block_small")) m->block_small = (int)v;
+  else if (!strcmp(key, "block8")) m->block8 = (int)v;
+  else if (!strcmp(key, "block8_max")) m->block8_max = (int)v;
   else if (!strcmp(key, "block_sweeps")) { m->block_sweeps = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "mg_global_sum")) m->mg_global_sum = (int)v;
   else if (!strcmp(key, "agglomerate")) { m->agglomerate = (int)v; if (m->const_set) return build_coefs(m); }
@@ -1113,6 +1117,15 @@ static bool block_ok(msom *m, const Lev &L) {
   const bool want = m->block_sweeps || (m->block_small && L.sg->nx <= m->block_small);
   return want && m->uniformS && m->nl <= MSOM_FASTNL && !L.tiled && !(m->walls & WALL_PER) && L.sg->nx >= 64 && L.sg->ny >= 16;
 }
+// launch-bound levels (round 3): the prolongation and up to 8 colour half-sweeps of a level visit in ONE launch of the LDS-tiled
+// smoother with a halo of 8 (k_relax_block<.., 8>, option block8; levels of 64 .. block8_max cells a side that are not marched).
+// One GPU, walls, uniform S, nl <= 6 (LDS).  Measured at 4096^2 x 6 / 512^2 x 3: see DESIGN.md section 4
+static bool march_ok(msom *m, const Lev &L);
+static bool block8_ok(msom *m, const Lev &L) {
+  if (!m->block8 || m->block_sweeps || !m->uniformS || m->nl > 6 || L.tiled || L.walls != WALL_ALL) return false;
+  if (L.sg->nx < 64 || L.sg->ny < 16 || L.sg->nx > m->block8_max) return false;
+  return !march_ok(m, L);
+}
 // can the level chain its half-sweeps in registers (k_relax_march)?  One GPU (no halo exchange between half-sweeps),
 // walls, uniform S, and a level big enough to be HBM-bound: a marching wavefront pays one memory latency per row, which
 // only ~2000 concurrent chunks hide (measured at nl = 6: 4096^2 1.54 -> 1.05 ms per 7 half-sweeps, 2048^2 385 -> 310 us,
@@ -1140,6 +1153,7 @@ static int march_levels(msom *m) {
 // is the prolongation coarse -> L folded into the first smoothing pass of L?
 static bool fuse_prolong(msom *m, const Lev &L, int nrelax) {
   if (block_ok(m, L) && nrelax >= 2) return true;
+  if (block8_ok(m, L) && nrelax >= 1) return true;
   return m->prolong_fused && m->nl <= MSOM_FASTNL && nrelax >= 1 && L.sg->nx >= 4 && L.sg->ny >= 4;
 }
 
@@ -1285,6 +1299,18 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
     if (L.tiled) STICKY(m, exch_split(m, *L.da, *L.sg, nl, corners_last));
     return;
   }
+  if (block8_ok(m, L)) {
+    int n = 2 * nrelax, c = 0;
+    const Lev *src = coarse;   // first pass: the correction is interpolated from the coarser level on the fly
+    while (n > 0) {
+      const int K = n < 8 ? n : 8;
+      if (K == 1) { launch_relax_color(m->st, *L.da, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, c, L.walls, L.fine); break; }
+      if (launch_relax_block8(m->st, *L.da, src ? *src->da : nullptr, src ? *src->sg : *L.sg, L.res, *L.da_alt, *L.sg, nl, *L.rc, L.walls, K, c)) m->sticky = MSOM_ERR_ARG;
+      std::swap(*L.da, *L.da_alt);
+      src = nullptr; n -= K; c = (c + K) & 1;
+    }
+    return;
+  }
   if (block_ok(m, L)) {
     for (; it + 2 <= nrelax; it += 2) {
       const bool pl = coarse && it == 0;
@@ -1390,7 +1416,7 @@ static void mg_cycle(msom *m, int nrelax, int first_restrict) {
   bool ok = m->use_graph && m->nranks == 1 && !m->profile;   // (corr_req only acts inside a marching pass, excluded below)
   for (int k = 0; ok && k < m->nlev; k++) {
     Lev L = tile_lev(m, k);
-    if (march_ok(m, L) || block_ok(m, L)) ok = false;   // those passes ping-pong between two buffers: pointers differ from cycle to cycle
+    if (march_ok(m, L) || block_ok(m, L) || block8_ok(m, L)) ok = false;   // those passes ping-pong between two buffers: pointers differ from cycle to cycle
   }
   if (!ok) { mg_cycle_levels(m, nrelax, first_restrict); return; }
   const long key = (long)nrelax * 8 + first_restrict;

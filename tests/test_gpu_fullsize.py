@@ -1,7 +1,7 @@
 """Differential tests of the PRODUCT PATH at BASELINE.json's sizes (C3 2048^2 x 3, C4 4096^2 x 6), where the CPU oracle is too
 slow: the default kernels -- chained smoother with its lean interior body, prolongation and correction riders, one-launch
 coarse levels, fused residual passes, one-layer-per-wavefront tendency kernel with the advance folded in -- against the SAME
-library driven through the kernel-per-reference-loop chain (march = 0, fused = 0, mg_fused = 0, mg_coarse = 0, prolong_fused = 0:
+library driven through the kernel-per-reference-loop chain (march = 0, block8 = 0, fused = 0, mg_fused = 0, mg_coarse = 0, prolong_fused = 0:
 the path the small-grid tests hold to the oracle bit for bit).  Strict build: bit-identical; product build: <= 1e-10 relative.
 The strip / chunk logic of the marching kernels only meets many interior chunks, both marching directions and several
 workgroup rounds at these sizes (a hazard of the lean smoother body showed at 2048^2 x 6 and nowhere below)."""
@@ -14,7 +14,7 @@ from test_gpu_parity import rel
 
 pytestmark = pytest.mark.gpu
 
-REFERENCE_CHAIN = dict(march=0, fused=0, mg_fused=0, mg_coarse=0, prolong_fused=0, adv_fused=0)
+REFERENCE_CHAIN = dict(march=0, block8=0, fused=0, mg_fused=0, mg_coarse=0, prolong_fused=0, adv_fused=0)
 
 
 def run(N, nl, strict, opts, steps, tol):

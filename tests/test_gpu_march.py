@@ -22,6 +22,8 @@ def run(txt, strict, nl, ny, nx, steps=2, **opts):
     g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx))
     g.set_const()
     opts.setdefault("uniform_S", 1)
+    if opts.get("march") == 0:
+        opts.setdefault("block8", 0)      # the reference side of a comparison: one launch per colour on every level
     for k, v in opts.items():
         g.option(k, v)
     if opts.get("march") and opts["uniform_S"] == 1 and nl > 1:
@@ -170,3 +172,35 @@ def test_randomised_product_build_vs_oracle(seed):
     assert g.t == pytest.approx(o.t, rel=1e-12), desc
     assert rel(g.get(F["PSI"]), o.get(orc.PSI)) <= 1e-9, desc
     assert rel(g.get(F["Q"]), o.get(orc.Q)) <= 1e-9, desc
+
+
+@pytest.mark.parametrize("nx,ny,nl", [(64, 64, 3), (128, 64, 2), (256, 256, 6), (512, 128, 1), (256, 64, 4), (1024, 128, 5), (128, 128, 6)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_tiled_level_visit_equals_half_sweep_per_launch(nx, ny, nl, strict):
+    """option block8 (default on, round 3): prolongation + all (up to 8) half-sweeps of a visit of a launch-bound level in ONE launch of
+    the LDS-tiled smoother with a halo of 8 (k_relax_block<.., 8>; more half-sweeps: further passes, a single left-over one as a colour
+    pass).  TOLERANCE 1e-8: several cycles per solve, nrelax adapts (4, 5, ... sweeps => 8, 8 + 2, ... half-sweeps).  Against one launch
+    per colour: bit for bit in the strict build, round-off in the product build; every tile shape (block_variant)"""
+    txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else "") + SLIP)
+    a = run(txt, strict, nl, ny, nx, march=0, block8=0)
+    for variant in (0, 1, 3, 6):
+        b = run(txt, strict, nl, ny, nx, march=0, block8=1, block_variant=variant)
+        if strict:
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], variant
+        else:
+            assert rel(b[0], a[0]) <= 1e-10 and a[2][0] == b[2][0], variant
+    g = QG(txt); g.option("block_variant", 0); g.close()      # the knob is a global of the library: back to the default
+
+
+def test_tiled_level_visit_against_oracle():
+    """product build, defaults, against the CPU oracle (general column solver, red-black) at 256^2 x 3 (levels 64 .. 256 in the
+    tiled pass, <= 32 in the one-launch coarse kernel): 5 steps at TOLERANCE 1e-12, <= 1e-10 relative on psi and q -- the bound of
+    test_fast_ten_steps_tight_tolerance"""
+    nx, ny, nl = 256, 256, 3
+    o, g = make_pair(nx, ny, nl, strict=False, TOLERANCE=1e-12)
+    assert g.param("uniform_S") == 1.0
+    for _ in range(5):
+        o.step(); g.step()
+    assert g.t == pytest.approx(o.t, rel=1e-12)
+    assert rel(g.get(F["Q"]), o.get(orc.Q)) <= 1e-10
+    assert rel(g.get(F["PSI"]), o.get(orc.PSI)) <= 1e-10

@@ -510,6 +510,7 @@ def test_blocked_smoother_equals_plain_sweeps(nx, ny, nl, strict):
         g.option("quiet", 1)
         g.option("uniform_S", 1)
         g.option("block_sweeps", blk)
+        g.option("block8", 0)       # blk = 0: one launch per colour (the 8-half-sweep form of the kernel has its test in test_gpu_march.py)
         g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx))
         g.set_const()
         assert g.param("uniform_S") == (1.0 if nl > 1 else 0.0)
