@@ -312,11 +312,15 @@ def vertex_sqg_leg(N=2048, nl=3, steps=6):
         g.step(True)
     g.set_option("profile", 0)
     wv = 8.0 * (N + 1) ** 2 * nl
-    spec = {"relax_fine": ("k_n_relax_s<nl> (one colour half-sweep, split layout, S2 row tables)", (1.5 + 0.5 / nl) * wv, "other colour w/2 + own residual w/2 + own mask w/(2 nl) -> own colour w/2"),
+    spec = {"march_fine": ("k_n_relax_march_s<nl,K> (K = 2..4 chained colour half-sweeps, split layout; the figure is an average over the K of the cycle)", (1.5 + 0.5 / nl) * wv,
+                           "a pass of K half-sweeps: other colour w/2 + residual and mask of the colours it updates (counted once: w/2 + w/(2 nl)) -> last colour w/2; the same bytes as ONE colour pass"),
+            "relax_fine": ("k_n_relax_s<nl> (one colour half-sweep, split layout, S2 row tables)", (1.5 + 0.5 / nl) * wv, "other colour w/2 + own residual w/2 + own mask w/(2 nl) -> own colour w/2"),
             "relax_prolong_fine": ("k_n_relax_prolong_s<nl> (prolongation + first colour half-sweep)", (1.75 + 0.5 / nl) * wv, "coarse w/4 + residual w/2 + mask -> both colours w"),
-            "residual": ("k_n_residual (residual to the split layout + max)", (3.0 + 1.0 / nl) * wv, "psi, q, mask in; residual out"),
-            "correct": ("k_n_correct (psi += da, boundary value)", 3.0 * wv, "psi, da in; psi out"),
-            "rhs": ("rhs_pv chain: mask, del2, Jacobians + beta + drag + topography, two stretch / del2 pairs, forcing, mask (11 launches)", None, "11 passes; no single compulsory figure"),
+            "residual": ("k_n_residual (first residual of a solve, to the split layout + max)", (3.0 + 1.0 / nl) * wv, "psi, q, mask in; residual out"),
+            "correct_residual": ("k_n_correct_residual_m<nl> (correction of cycle i + residual of cycle i + 1, rows marched)", (5.0 + 1.0 / nl) * wv, "psi, da, q, mask in; psi (second buffer), residual out"),
+            "correct": ("k_n_correct (psi += da, boundary value: last cycle of a solve)", 3.0 * wv, "psi, da in; psi out"),
+            "rhs": ("rhs_pv in three passes: k_n_rhs_pre (mask, zeta), k_n_del2_bnd (tmp), k_n_rhs_all (Jacobians, beta, drag, stretch / del2 pairs, forcing, mask) [+ k_n_lap_bs with sqg]",
+                    (5.0 + 1.0 / nl + 2.0 + 4.0 + (nl - 1.0) / nl + 3.0 / nl) * wv, "q in/out, psi in, psi out, zeta out, mask | zeta in, tmp out | psi, zeta, tmp, S2 in, dq out, 2-d fields"),
             "coarse": ("k_n_mg_coarse<nl> (levels of <= 33^2 vertices in one launch)", None, "launch-latency bound")}
     ks = {}
     for slot, (name, nbytes, what) in spec.items():

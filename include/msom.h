@@ -105,7 +105,8 @@ int msom_destroy(msom_t *m);
  * into the first pass, "march_dma" [2] memory side of the pass (0: register-window loads, 1: LDS-DMA prefetch with one strip per
  * workgroup, 2: four strips per workgroup marching in step; PROCESS-WIDE tuning knob like march_rows / march_xcd / march_flip /
  * march_dbg / rhs_dbg / block_variant, which are globals of the library rather than fields of the handle), "graph" [0] replay the launches of a multigrid cycle from a captured hipGraph on the launch-bound grids
- * (measured neutral), "march_partial" [1], "march_correct" [1] correction folded into the last pass, "march_xcd" [1] XCD-contiguous block numbering, "march_flip" [1] odd chunks march downwards, "block_sweeps" [0] LDS-tiled blocked smoother, "agglomerate" [1] / "agg_size" [256]
+ * (measured neutral), "march_partial" [1], "march_correct" [1] correction folded into the last pass, "march_xcd" [1] XCD-contiguous block numbering, "march_flip" [1] odd chunks march downwards, "block_sweeps" [0] LDS-tiled blocked smoother (2 sweeps per launch, every level), "block8" [1] / "block8_max" [1024] round 3: prolongation + up to 8 half-sweeps of a
+ * visit of a launch-bound level (64 .. block8_max cells a side, not marched; one GPU, walls, uniform S, nl <= 6) in one launch of that kernel with a halo of 8, "agglomerate" [1] / "agg_size" [256]
  * gathered coarse levels of tiled runs, "mg_global_sum" [0]; "rhs_dbg", "block_variant": timing
  * experiments of tools/. */
 int msom_set_option(msom_t *m, const char *key, double value);
@@ -276,7 +277,11 @@ void msomn_destroy(msomn_t *m);                                 /* trash_vars qg
 /* keys: TOLERANCE NITERMAX NITERMIN (nodal-poisson.h:19-23) DT quiet stochastic seed; implementation switches (result-preserving in
  * the strict build): node_split [65] levels of >= that many vertices a side keep correction / residual / mask / S2 copies in the
  * x-parity split layout (0: off), s2_rows [1] row tables for an S2 that does not depend on x, node_pfused [1] prolongation folded into the first colour pass of the split levels, mg_coarse [32] levels of at most that
- * many cells a side in one launch, tiled_relax [0], node_march [0] (measured slower, kept for the tests) */
+ * many cells a side in one launch, tiled_relax [0], node_march [0] (measured slower, kept for the tests); round 3: node_march_s [2049] split
+ * levels of >= that many vertices a side chain up to 4 colour half-sweeps per pass, node_tile_s [65] / node_tile_max [513] / node_tile_k [8]
+ * the split levels between those sizes run up to node_tile_k colour half-sweeps per LDS-tiled launch (nl <= 4), node_rhs_fused [1] the
+ * baroclinic tendency in three passes instead of the twelve loops of the reference, node_corr_fused [2] the correction of a cycle applied
+ * inside the residual pass of the next (2: rows marched, 1: one thread per vertex, 0: separate passes), profile [0] */
 int msomn_set_option(msomn_t *m, const char *key, double value);
 /* keys: N nl L0 DT tend dtout nlevels iRd2_low bc_fac idh0_<l> idh1_<l>; NaN if unknown */
 double msomn_get_param(msomn_t *m, const char *key);

@@ -1468,6 +1468,10 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
   const bool wW = (p.walls & WALL_W) && x0 == 0, wE = (p.walls & WALL_E) && x0 + BTXT >= nx;
   const bool wS = (p.walls & WALL_S) && y0 == 0, wN = (p.walls & WALL_N) && y0 + BTY >= ny;
   const bool edge_tile = wW | wE | wS | wN;
+  // doubly periodic single tile (round 3): a cell of the region beyond the domain is the periodic image of a domain cell -- loaded
+  // (or interpolated) from its wrapped position and relaxed like any other; nothing but the tile interior is stored, the ghost
+  // lines are refreshed by the caller (launch_split_wrap) after the last pass of the visit.  Needs nx, ny >= the region
+  const bool per = (p.walls & WALL_PER) != 0;
   const double sqD = p.rc.sqD;
 
   // ---- load / interpolate the tile (+ halo), fetch the residual of the owned cells.
@@ -1485,15 +1489,16 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       const int xx = 2 * k + c, gx = x0 - BH + xx;
-      const bool inb = act && gx >= -1 && gx <= nx && gy >= -1 && gy <= ny;          // stored cell or ghost line
-      const bool ind = act && gx >= 0 && gx < nx && gy >= 0 && gy < ny;               // cell of the domain
-      const size_t gsrc = split_idx(p.g, 0, gy, gx);
+      const int wx = per ? (gx + nx) % nx : gx, wy = per ? (gy + ny) % ny : gy;
+      const bool inb = act && (per || (gx >= -1 && gx <= nx && gy >= -1 && gy <= ny));          // stored cell or ghost line
+      const bool ind = act && (per || (gx >= 0 && gx < nx && gy >= 0 && gy < ny));               // cell of the domain (or an image of one)
+      const size_t gsrc = split_idx(p.g, 0, wy, wx);
       size_t c00 = 0, c10 = 0, c01 = 0, c11 = 0;
       bool pv = false;
       if (PROLONG) {
         pv = inb && (ind || !((gx < 0 || gx >= nx) && (gy < 0 || gy >= ny)));
         // ghost line: homogeneous Dirichlet image of the interpolated wall cell
-        const int mx = gx < 0 ? 0 : (gx >= nx ? nx - 1 : gx), my = gy < 0 ? 0 : (gy >= ny ? ny - 1 : gy);
+        const int mx = per ? wx : (gx < 0 ? 0 : (gx >= nx ? nx - 1 : gx)), my = per ? wy : (gy < 0 ? 0 : (gy >= ny ? ny - 1 : gy));
         const int I = mx >> 1, J = my >> 1, cx = (mx & 1) ? 1 : -1, cy = (my & 1) ? 1 : -1;
         c00 = split_idx(p.cg, 0, J, I); c10 = split_idx(p.cg, 0, J, I + cx);
         c01 = split_idx(p.cg, 0, J + cy, I); c11 = split_idx(p.cg, 0, J + cy, I + cx);
@@ -1526,7 +1531,7 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
       const int yy = s / HX, k = s - yy * HX;
       const int c = (yy + col) & 1;  // which of the two owned cells has this colour
       const int xx = 2 * k + c, gx = x0 - BH + xx, gy = y0 - BH + yy;
-      const bool ok = s < HX * NY && gx >= 0 && gx < nx && gy >= 0 && gy < ny && (xx >= h || wW) && (NX - 1 - xx >= h || wE) &&
+      const bool ok = s < HX * NY && (per || (gx >= 0 && gx < nx && gy >= 0 && gy < ny)) && (xx >= h || wW) && (NX - 1 - xx >= h || wE) &&
                       (yy >= h || wS) && (NY - 1 - yy >= h || wN);
       if (ok) {
         const int o = ob[n];
@@ -1575,7 +1580,7 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
     const int yy = s / HX, k = s - yy * HX;
     if (s >= HX * NY || yy < BH || yy >= BH + BTY) continue;
     const int gy = y0 - BH + yy;
-    if (gy >= ny) continue;
+    if (gy >= ny) continue;   // (tiles start at multiples of the tile size: gy, gx >= 0 here)
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       const int xx = 2 * k + c, gx = x0 - BH + xx;
@@ -1650,7 +1655,7 @@ static void block8_launch_t(hipStream_t st, const BlockArgs &p, int prolong) {
 // tile shape: the launch-bound levels have few tiles and the pass lasts as long as ONE workgroup does, so small tiles (16 x 16: four
 // times the half-sweep work of the level in halo cells, but a quarter of the serial work per workgroup) win up to 256^2; wider levels
 // take 32 x 16.  Measured at nl = 6 / nl = 3 (block_variant 6 = 64 x 16 everywhere, 3 = 16 x 16 everywhere): 4096^2 x 6 6.55 / 6.46 /
-// 6.39 ms per step with 64 x 16 / 16 x 16 / this rule, 512^2 x 3 0.447 / 0.400 / 0.388
+// 6.39 ms per step with 64 x 16 / 16 x 16 / this rule, 512^2 x 3 0.447 / 0.400 / 0.388; 64 x 16 on the 1024^2 level only: 6.49 vs 6.43
 template <int NL>
 static void block8_launch(hipStream_t st, const BlockArgs &p, int prolong) {
   switch (g_block_variant) {

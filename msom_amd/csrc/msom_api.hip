@@ -1122,8 +1122,11 @@ static bool block_ok(msom *m, const Lev &L) {
 // One GPU, walls, uniform S, nl <= 6 (LDS).  Measured at 4096^2 x 6 / 512^2 x 3: see DESIGN.md section 4
 static bool march_ok(msom *m, const Lev &L);
 static bool block8_ok(msom *m, const Lev &L) {
-  if (!m->block8 || m->block_sweeps || !m->uniformS || m->nl > 6 || L.tiled || L.walls != WALL_ALL) return false;
+  if (!m->block8 || m->block_sweeps || !m->uniformS || m->nl > 6 || L.tiled || (L.walls != WALL_ALL && L.walls != WALL_PER)) return false;
   if (L.sg->nx < 64 || L.sg->ny < 16 || L.sg->nx > m->block8_max) return false;
+  // doubly periodic single tile: the kernel wraps its loads; the region (<= 48 x 32 cells) must not meet its own image; the gathered
+  // coarse levels of tiled runs keep their per-colour launches
+  if (L.walls == WALL_PER && (L.k < 0 || L.sg->ny < 64)) return false;
   return !march_ok(m, L);
 }
 // can the level chain its half-sweeps in registers (k_relax_march)?  One GPU (no halo exchange between half-sweeps),
@@ -1308,6 +1311,9 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
       if (launch_relax_block8(m->st, *L.da, src ? *src->da : nullptr, src ? *src->sg : *L.sg, L.res, *L.da_alt, *L.sg, nl, *L.rc, L.walls, K, c)) m->sticky = MSOM_ERR_ARG;
       std::swap(*L.da, *L.da_alt);
       src = nullptr; n -= K; c = (c + K) & 1;
+      // periodic: the pass stored no ghost cell; boundary_level(da, l) = the wrapped copies, corners included (a following colour
+      // pass reads them, and so does the prolongation to the next finer level)
+      if (L.walls & WALL_PER) launch_split_wrap(m->st, *L.da, *L.sg, nullptr, nullptr, make_split(L.sg->nx, MARCH_HALO), nl, MARCH_HALO, 2);
     }
     return;
   }

@@ -48,8 +48,8 @@ struct NProf {
   double total_ms = 0;
   long launches = 0;
 };
-enum { NP_RELAX, NP_RELAX_PROLONG, NP_RESIDUAL, NP_CORRECT, NP_RHS, NP_COARSE, NP_MARCH, NP_COUNT };
-static const char *const NP_NAMES[NP_COUNT] = {"relax_fine", "relax_prolong_fine", "residual", "correct", "rhs", "coarse", "march_fine"};
+enum { NP_RELAX, NP_RELAX_PROLONG, NP_RESIDUAL, NP_CORRECT, NP_RHS, NP_COARSE, NP_MARCH, NP_CORR_RES, NP_COUNT };
+static const char *const NP_NAMES[NP_COUNT] = {"relax_fine", "relax_prolong_fine", "residual", "correct", "rhs", "coarse", "march_fine", "correct_residual"};
 
 struct msomn {
   NodeParams p;
@@ -627,11 +627,11 @@ static int vpoisson(msomn *m, double *&a, const double *b) {
     if (pending_correct && m->node_corr_fused) {
       int ra = need_psi_alt(m);
       if (ra) return ra;
-      nprof_begin(m, NP_RESIDUAL);
+      nprof_begin(m, NP_CORR_RES);
       launch_n_correct_residual(m->st, a, m->psi_alt, m->lev[0].da, m->lev[0].sp ? &m->lev[0].ga : nullptr, m->psi_bc, b, m->lev[0].mask, m->lev[0].S2,
                                 m->lev[0].res, m->d_scal + NSC_RES, m->g, nl, m->D, m->iRd2_low, m->lc, m->lev[0].sp ? &m->lev[0].ga : nullptr, m->lev[0].S2row,
                                 m->node_corr_fused >= 2);
-      nprof_end(m, NP_RESIDUAL);
+      nprof_end(m, NP_CORR_RES);
       std::swap(a, m->psi_alt);
     } else {
       if (pending_correct) {

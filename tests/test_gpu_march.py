@@ -192,6 +192,22 @@ def test_tiled_level_visit_equals_half_sweep_per_launch(nx, ny, nl, strict):
     g = QG(txt); g.option("block_variant", 0); g.close()      # the knob is a global of the library: back to the default
 
 
+@pytest.mark.parametrize("nx,ny,nl", [(64, 64, 3), (256, 128, 2), (512, 512, 6), (128, 64, 1)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_tiled_level_visit_on_the_periodic_domain(nx, ny, nl, strict):
+    """sbc = -1 (doubly periodic single tile): the region of a tile beyond the domain holds periodic images loaded from their wrapped
+    positions; the ghost lines are refreshed after each pass (launch_split_wrap).  Levels of fewer than 64 rows keep the colour launches"""
+    txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else "") + "sbc = -1\ntau0 = 0\n")
+    a = run(txt, strict, nl, ny, nx, march=0, block8=0)
+    for variant in (0, 6):
+        b = run(txt, strict, nl, ny, nx, march=0, block8=1, block_variant=variant)
+        if strict:
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], variant
+        else:
+            assert rel(b[0], a[0]) <= 1e-10 and a[2][0] == b[2][0], variant
+    g = QG(txt); g.option("block_variant", 0); g.close()
+
+
 def test_tiled_level_visit_against_oracle():
     """product build, defaults, against the CPU oracle (general column solver, red-black) at 256^2 x 3 (levels 64 .. 256 in the
     tiled pass, <= 32 in the one-launch coarse kernel): 5 steps at TOLERANCE 1e-12, <= 1e-10 relative on psi and q -- the bound of
