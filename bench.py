@@ -184,6 +184,7 @@ class Leg:
         self.g = g
 
     def barrier(self):
+        self.g.sync()     # the library's own stream (msom_step may return with its last tendency pass still running)
         if self.dist is not None:
             import torch
 
@@ -205,7 +206,7 @@ class Leg:
         self.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            g.step()   # msom_step synchronises the library's stream before returning
+            g.step()
         self.barrier()
         elapsed = time.perf_counter() - t0
         g.option("profile", 0)

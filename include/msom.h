@@ -232,6 +232,10 @@ int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, double add, doub
  * and a back-to-back kernel microbenchmark outside any step */
 int msom_profile_read(msom_t *m, const char *kernel, double *avg_ms, long *launches);
 int msom_profile_reset(msom_t *m);
+/* waits for everything the handle has queued on its stream.  With option "step_sync" = 0 [default 1] and "async_solve", msom_step returns
+ * while its last tendency pass is still running; every call that returns device data to the host synchronises by itself, so this
+ * is for timing and for callers that share the device pointers of the fields with their own streams. */
+int msom_sync(msom_t *m);
 int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double *avg_ms);
 /* one-rank RCCL communicator on the current device: grouped send/recv to self, all-reduce and
  * all-gather through the library's transport code (wiring check on a single GPU) */

@@ -86,6 +86,7 @@ def load_library(strict=False):
         "msom_dbg_op": (ci, [vp, cs, ci, ci, cd, cd]),
         "msom_profile_read": (ci, [vp, cs, _dp, C.POINTER(C.c_long)]),
         "msom_profile_reset": (ci, [vp]),
+        "msom_sync": (ci, [vp]),
         "msom_bench_kernel": (ci, [vp, cs, ci, _dp]),
         "msom_dbg_rccl_selftest": (ci, []),
         "msom_wavelet_filter": (ci, [vp, cd]),
@@ -395,6 +396,10 @@ class QG:
 
     def profile_reset(self):
         self._chk(self.L.msom_profile_reset(self.h))
+
+    def sync(self):
+        """wait for the work queued on the handle's stream (msom_step may return before its last kernel has finished)"""
+        self._chk(self.L.msom_sync(self.h))
 
     def bench_kernel(self, kernel, reps=20):
         ms = C.c_double()

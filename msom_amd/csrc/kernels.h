@@ -106,7 +106,8 @@ int residual2_blocks(const NatGeom &g);
 void launch_residual2(hipStream_t st, int mode, const double *a, const double *da, double *a_out, const double *b, const double *S,
                       const NatGeom &g, double *res, const SplitGeom &sg, double *res_c, const SplitGeom &cg, int nl, const RelaxCoef &rc,
                       int uniformS, int walls, double *maxres, double *sum_partial, int want_sum, double *umax_partial, double *umax_out,
-                      int umax_clean = 0);
+                      int umax_clean = 0,
+                      double *res_c2 = nullptr, const SplitGeom *cg2 = nullptr);
 void launch_restrict(hipStream_t st, const double *fine, const SplitGeom &fg, double *coarse, const SplitGeom &cg, int nl);
 void launch_prolong(hipStream_t st, const double *coarse, const SplitGeom &cg, double *fine, const SplitGeom &fg, int nl, int walls);
 void launch_relax_color(hipStream_t st, double *da, const double *res, const double *S, const SplitGeom &sg, int nl, const RelaxCoef &rc,

@@ -158,13 +158,19 @@ struct Res2Args {
   NatGeom g;
   SplitGeom sg, cg;
   int nl, uniformS, want_sum, walls, dbg;
+  double *res_c2;   // RESTRICT: non-null = the restriction of res_c to the next level as well (geometry cg2); needs ny % 4 == 0, hk even
+  SplitGeom cg2;
   RelaxCoef rc;
 };
 
 // UMAX (without CORRECT): max |u| of a itself, for the pass that follows a correction done elsewhere (kernels_march.hip)
 template <bool CORRECT, bool WRITE, bool RESTRICT, bool UMAX = false>
 __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
-  __shared__ double sr[RESTRICT ? MSOM_MAXNL : 1][BY][BX][2];
+  // RESTRICT: the residuals of the block's 4 x 128 cells, nl layers (dynamic LDS, nl x 4 KB: a static array for MSOM_MAXNL layers
+  // was 64 KB and held the kernel at two workgroups per CU), then its level-1 means [nl][2][BX]
+  extern __shared__ double sr_dyn[];
+  auto sr = [&](int l, int y, int x, int c) -> double & { return sr_dyn[((l * BY + y) * BX + x) * 2 + c]; };
+  auto s1 = [&](int l, int y, int x) -> double & { return sr_dyn[p.nl * BY * BX * 2 + (l * 2 + y) * BX + x]; };
   __shared__ double smm[BY], sms[BY];
   constexpr bool VEL = CORRECT || UMAX;
   __shared__ double smu[VEL ? MSOM_MAXNL : 1][BY];
@@ -238,7 +244,7 @@ __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
         p.res[se + (size_t)l * p.sg.ls] = re;
         p.res[so + (size_t)l * p.sg.ls] = ro;
       }
-      if (RESTRICT) { sr[l][threadIdx.y][threadIdx.x][0] = re; sr[l][threadIdx.y][threadIdx.x][1] = ro; }
+      if (RESTRICT) { sr(l, threadIdx.y, threadIdx.x, 0) = re; sr(l, threadIdx.y, threadIdx.x, 1) = ro; }
       m = fmax(m, fmax(fabs(re), fabs(ro)));
       if (VEL && !(p.dbg & 64)) {
         // face velocities of the corrected psi (comp_vel, msqg/qg.h:276-283): west and south face
@@ -265,11 +271,29 @@ __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
       const int J = j >> 1;
       for (int l = 0; l < nl; l++) {
         double sum = 0.;
-        sum += sr[l][threadIdx.y][threadIdx.x][0];
-        sum += sr[l][threadIdx.y + 1][threadIdx.x][0];
-        sum += sr[l][threadIdx.y][threadIdx.x][1];
-        sum += sr[l][threadIdx.y + 1][threadIdx.x][1];
-        p.res_c[split_idx(p.cg, l, J, kx)] = sum / 4;
+        sum += sr(l, threadIdx.y, threadIdx.x, 0);
+        sum += sr(l, threadIdx.y + 1, threadIdx.x, 0);
+        sum += sr(l, threadIdx.y, threadIdx.x, 1);
+        sum += sr(l, threadIdx.y + 1, threadIdx.x, 1);
+        const double v = sum / 4;
+        p.res_c[split_idx(p.cg, l, J, kx)] = v;
+        if (p.res_c2) s1(l, threadIdx.y >> 1, threadIdx.x) = v;
+      }
+    }
+    // round 3: the next restriction as well (was a launch of k_restrict reading the level-1 residual back): the block holds the
+    // 2 x 64 level-1 cells of 1 x 32 level-2 cells; same sum order (restrict_pt), same values
+    if (p.res_c2) {
+      __syncthreads();
+      const int II = threadIdx.x, JJ = j >> 2;
+      if (threadIdx.y == 0 && II < BX / 2 && 2 * II + 1 + blockIdx.x * BX < p.sg.hk && j < p.g.ny) {
+        for (int l = 0; l < nl; l++) {
+          double sum = 0.;
+          sum += s1(l, 0, 2 * II);
+          sum += s1(l, 1, 2 * II);
+          sum += s1(l, 0, 2 * II + 1);
+          sum += s1(l, 1, 2 * II + 1);
+          p.res_c2[split_idx(p.cg2, l, JJ, blockIdx.x * (BX / 2) + II)] = sum / 4;
+        }
       }
     }
   }
@@ -572,8 +596,11 @@ int residual2_blocks(const NatGeom &g) {
 // mode bits: 1 = CORRECT, 2 = WRITE, 4 = RESTRICT
 void launch_residual2(hipStream_t st, int mode, const double *a, const double *da, double *a_out, const double *b, const double *S,
                       const NatGeom &g, double *res, const SplitGeom &sg, double *res_c, const SplitGeom &cg, int nl, const RelaxCoef &rc,
-                      int uniformS, int walls, double *maxres, double *sum_partial, int want_sum, double *umax_partial, double *umax_out, int umax_clean) {
+                      int uniformS, int walls, double *maxres, double *sum_partial, int want_sum, double *umax_partial, double *umax_out, int umax_clean,
+                      double *res_c2, const SplitGeom *cg2) {
   Res2Args p;
+  p.res_c2 = res_c2;
+  if (cg2) p.cg2 = *cg2; else p.cg2 = cg;
   extern int g_rhs_dbg;
   p.dbg = g_rhs_dbg;
   p.umax_partial = umax_partial;
@@ -592,7 +619,7 @@ void launch_residual2(hipStream_t st, int mode, const double *a, const double *d
       hipLaunchKernelGGL(k_max_final_mg, dim3(64), dim3(256), 0, st, umax_partial, umax_out, (int)(gr.x * gr.y), nl);
       break;
     case 2: hipLaunchKernelGGL((k_residual2<false, true, false>), gr, block2d(), 0, st, p); break;
-    case 6: hipLaunchKernelGGL((k_residual2<false, true, true>), gr, block2d(), 0, st, p); break;
+    case 6: hipLaunchKernelGGL((k_residual2<false, true, true>), gr, block2d(), (size_t)nl * (BY * BX * 2 + 2 * BX) * sizeof(double), st, p); break;
     case 0: hipLaunchKernelGGL((k_residual2<false, false, false>), gr, block2d(), 0, st, p); break;
     case 8:  // max |res(a)| and max |u(a)| of an a that is already corrected
       if (uniformS && g.nx >= 64 && g.ny >= 16 && g_resmax_rows >= 0 && nl <= MSOM_FASTNL) {

@@ -67,6 +67,8 @@ struct msom {
   // altogether, tools/ab_nosync.py).  If the solve turns out to need another cycle the pass is simply run again afterwards:
   // its output went to the predictor (stage 1) or to a spare buffer that only replaces q when the solve had converged (stage 2).
   int async_solve = 1;               // option
+  int step_sync = 1;                 // option: 0 = msom_step returns without waiting for its last tendency pass (async_solve only); measured: 512^2 x 3
+                                     // 0.394 -> 0.378 ms per step, 2048^2 x 3 and 4096^2 x 6 unchanged -- off
   std::function<void(const std::function<void()> &)> spec_hook;   // queued by mg_solve after the first cycle's residual pass; calls its
                                      // argument (the host's read of the scalars) between the dt kernel and the tendency pass
   int spec_launched = 0, spec_valid = 0;
@@ -123,6 +125,7 @@ struct msom {
   int stochastic = 0, corrector_step = 0, noise_mode = 0, stoch_fused = 1;
   int prolong_fused = 1;  // first red half-sweep of a level interpolates its neighbours from the coarser level
   int block_sweeps = 0;  // experimental temporally blocked smoother (2 sweeps per pass); measured not faster at nl = 6
+  int restrict2 = 1;     // round 3: the pre-cycle residual pass restricts two levels down (k_residual2, res_c2)
   int block8 = 1;        // round 3: prolongation + up to 8 half-sweeps of a launch-bound level in one launch (k_relax_block, halo 8)
   int block8_max = 1024; // ... on levels of at most this many cells a side (and not marched)
   int block_small = 0;   // the same kernel on the launch-bound levels only (not marched, <= block_small cells wide): 2 launches per level visit instead of 8
@@ -708,10 +711,12 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "dbg_interleave")) g_dbg_interleave = (int)v;
   else if (!strcmp(key, "dbg_nosync")) m->dbg_nosync = (int)v;
   else if (!strcmp(key, "async_solve")) m->async_solve = (int)v;
+  else if (!strcmp(key, "step_sync")) m->step_sync = (int)v;
   else if (!strcmp(key, "march_lean")) { extern int g_march_lean; g_march_lean = (int)v; }
   else if (!strcmp(key, "march_k")) m->march_k = (int)v < 2 ? 2 : ((int)v > 4 ? 4 : (int)v);
   else if (!strcmp(key, "block_small")) m->block_small = (int)v;
   else if (!strcmp(key, "block8")) m->block8 = (int)v;
+  else if (!strcmp(key, "restrict2")) m->restrict2 = (int)v;
   else if (!strcmp(key, "block8_max")) m->block8_max = (int)v;
   else if (!strcmp(key, "block_sweeps")) { m->block_sweeps = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "mg_global_sum")) m->mg_global_sum = (int)v;
@@ -1451,12 +1456,16 @@ static void residual(msom *m, const double *a, const double *b, int slot, int wa
   if (m->profile) prof_end(m, m->prof_resid);
 }
 // fused variants (kernels_mg.hip k_residual2); mode bits 1 = CORRECT, 2 = WRITE, 4 = RESTRICT
+// the pre-cycle residual pass also restricts to level 2 (round 3: the launch of k_restrict that read the level-1 residual back, 53 us at
+// 4096^2 x 6, becomes 1/16 w of extra stores): the block of 4 rows x 128 cells holds whole level-2 cells when ny % 4 == 0 and nx % 4 == 0
+static bool restrict2_ok(const msom *m) { return m->restrict2 && m->mg_fused && m->nlev > 2 && m->g.ny % 4 == 0 && m->sg[0].hk % 2 == 0; }
 static void residual2(msom *m, int mode, const double *b, int slot, int want_sum) {
   ProfSlot &which = (mode & 8) ? m->prof_resmax : (mode & 1) ? m->prof_rescorr : m->prof_respre;
   if (m->profile) { prof_begin(m, m->prof_resid); prof_begin(m, which); }
+  const bool r2 = (mode & 4) && restrict2_ok(m);
   launch_residual2(m->st, mode, m->f[MSOM_PSI], m->da[0], m->psi_alt, b, m->f[MSOM_S], m->g, m->res[0], m->sg[0],
                    m->nlev > 1 ? m->res[1] : nullptr, m->sg[m->nlev > 1 ? 1 : 0], m->nl, m->rc[0], m->uniformS, m->walls, m->d_scal + slot,
-                   m->partial, want_sum, m->partial_umax, m->d_scal + SC_UMAX, m->umax_clean);
+                   m->partial, want_sum, m->partial_umax, m->d_scal + SC_UMAX, m->umax_clean, r2 ? m->res[2] : nullptr, r2 ? &m->sg[2] : nullptr);
   if (mode & (1 | 8)) m->umax_clean = 0;
   if (m->profile) { prof_end(m, m->prof_resid); prof_end(m, which); }
 }
@@ -1534,7 +1543,9 @@ static int mg_solve(msom *m, const double *b, msom_mgstats *s) {
   for (s->i = 0; s->i < p.nitermax && (s->i < p.nitermin || s->resa > p.tolerance); s->i++) {
     m->corr_req = fused && m->march_correct;
     m->corr_done = 0;
-    mg_cycle(m, s->nrelax, fused ? 2 : 1);
+    // restrictions still to do: from level 1 (plain path), 2 (the residual pass restricted once) or 3 (twice; not when the residual
+    // came out of the tendency pass, option rhs_resid)
+    mg_cycle(m, s->nrelax, fused ? ((restrict2_ok(m) && !(have_res && s->i == 0)) ? 3 : 2) : 1);
     m->corr_req = 0;
     if (s->i > 0) HIPCHK(hipMemsetAsync(m->d_scal + SC_RES1, 0, sizeof(double), m->st));
     if (m->corr_done) {  // a_new = a + da already sits in psi_alt (last smoother pass): boundary(a), then max |res|, max |u|
@@ -2088,11 +2099,19 @@ extern "C" int msom_step(msom_t *m, double *dt_used) {
     if (!advanced && (r = advance_qg(m, MSOM_Q, MSOM_Q, MSOM_DQ, m->dt))) return r;
   }
   if (tracers && ((r = tracer_update(m, MSOM_PTR_PRED)) || (r = tracer_advance(m, MSOM_PTR, MSOM_PTR, m->dt)))) return r;
-  if ((r = sync_stream(m))) return r;
+  // With the speculative tendency pass the host already follows the GPU solve by solve (it waits for the published residual of every
+  // solve) and everything it returns -- dt, t -- is known: with step_sync = 0 the last tendency pass is left running and the next step's
+  // launches queue up behind it (every call that hands device data to the host synchronises the stream itself, msom_sync on request)
+  if (!spec || m->step_sync) { if ((r = sync_stream(m))) return r; }
+  else if (m->sticky) return m->sticky;
   m->t = tnext;
   m->iter++;
   if (dt_used) *dt_used = m->dt;
   return MSOM_OK;
+}
+extern "C" int msom_sync(msom_t *m) {
+  if (!m) return MSOM_ERR_ARG;
+  return sync_stream(m);
 }
 extern "C" int msom_set_tnext(msom_t *m, double tnext) {
   if (!m) return MSOM_ERR_ARG;

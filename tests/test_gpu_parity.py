@@ -796,3 +796,24 @@ def test_speculative_tendency_pass_changes_nothing(nx, ny, nl, extra, tol, stric
     for a, b in zip(*outs):
         assert a[0] == b[0] and a[1] == b[1] and a[4] == b[4]
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nx,ny,nl", [(64, 64, 3), (256, 128, 6), (128, 256, 1), (512, 512, 2), (1024, 64, 4)])
+def test_residual_pass_that_restricts_two_levels(nx, ny, nl, strict):
+    """option restrict2 (default on, round 3): the pre-cycle residual pass writes the level-2 residual as well (k_residual2, res_c2) and
+    the restriction chain starts one level lower.  Same sums in the same order as k_restrict: q, psi, cycle counts and residuals equal
+    to the run with the option off, bit for bit in both builds; several cycles per solve (the pass runs before every cycle)"""
+    txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else ""))
+    out = []
+    for on in (1, 0):
+        g = QG(txt, strict=strict)
+        g.option("quiet", 1); g.option("TOLERANCE", 1e-9); g.option("restrict2", on)
+        g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx)); g.set_const()
+        for _ in range(2):
+            g.step()
+        st = g.mgstats()
+        out.append((g.get(F["PSI"]), g.get(F["Q"]), (st.i, st.resb, st.resa, st.nrelax)))
+        g.close()
+    assert out[0][2] == out[1][2] and out[0][2][0] >= 2
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

@@ -31,4 +31,5 @@ for rep in range(2):
         t0 = time.perf_counter()
         for _ in range(20):
             g.step()
+        g.sync()
         print(f"dma={dma} prolong={pl} step ms {(time.perf_counter() - t0) / 20 * 1e3:.3f}", flush=True)

@@ -14,5 +14,6 @@ for rep in range(2):
         for _ in range(5): g.step()
         t0 = time.perf_counter()
         for _ in range(n): g.step()
+        g.sync()
         print(f"N={N} nl={nl} dbg_nosync={ns}: {(time.perf_counter() - t0) / n * 1e3:.4f} ms/step", flush=True)
 g.option("dbg_nosync", 0)

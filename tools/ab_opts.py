@@ -14,5 +14,6 @@ for rep in range(2):
         for _ in range(4): g.step()
         t0 = time.perf_counter()
         for _ in range(12): g.step()
+        g.sync()
         print(f"{spec or 'default':40s} {(time.perf_counter() - t0) / 12 * 1e3:8.3f} ms/step", flush=True)
         g.close()

@@ -17,4 +17,5 @@ for rep in range(2):
         for _ in range(3): g.step()
         t0 = time.perf_counter()
         for _ in range(steps): g.step()
+        g.sync()
         print(f"N={N} nl={nl} [{s}] step ms {(time.perf_counter() - t0) / steps * 1e3:.4f}  cycles {g.mgstats().i}", flush=True)

@@ -24,6 +24,7 @@ for rep in range(2):
         for _ in range(2): g.step()
         t0 = time.perf_counter()
         for _ in range(nst): g.step()
+        g.sync()
         dt = (time.perf_counter() - t0) / nst * 1e3
         print(f"[{s}] step {dt:.4f} ms | {prof}", flush=True)
         for k in keys:   # back to the first set's values (the first set should name every key)

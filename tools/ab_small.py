@@ -13,5 +13,6 @@ for N, nl in ((128, 1), (512, 3), (1024, 3), (2048, 3)):
         t0 = time.perf_counter()
         n = 50
         for _ in range(n): g.step()
+        g.sync()
         print(f"{N}^2 x {nl}  {opt:16s} {(time.perf_counter() - t0) / n * 1e3:8.3f} ms/step", flush=True)
         g.close()

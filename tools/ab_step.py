@@ -10,6 +10,7 @@ for _ in range(3): g.step()
 def run(n=8):
     t0 = time.perf_counter()
     for _ in range(n): g.step()
+    g.sync()
     return (time.perf_counter() - t0) / n * 1e3
 cfgs = [("default", {})] + [(a, {a.split('=')[0]: float(a.split('=')[1])}) for a in sys.argv[1:]]
 for rep in range(2):

@@ -11,6 +11,7 @@ for _ in range(3): g.step()
 def run(n=8):
     t0 = time.perf_counter()
     for _ in range(n): g.step()
+    g.sync()
     return (time.perf_counter() - t0) / n * 1e3
 for rep in range(2):
     for v in vals:

@@ -21,4 +21,5 @@ for k in ("sweep", "red_prolong", "resid_restrict", "resid_correct", "resid_max"
     if n: print(f"{k:16s} {ms:.4f} ms x {n / 5:.1f} per step")
 t0 = time.perf_counter()
 for _ in range(10): g.step()
+g.sync()
 print("step ms", (time.perf_counter() - t0) * 100, "uniform_S", g.param("uniform_S"), "cycles", g.mgstats().i)
