@@ -98,8 +98,9 @@ int msom_destroy(msom_t *m);
  * stochastic variant rides in that kernel too: -q/tau and the noise are read in its finalisation next to q_in, "rhs_variant" [6: one layer per
  * wavefront with register windows; 1: LDS tiles],
  * "rhs_resid" [0] first residual of the next inversion as its by-product, "mg_fused" [1] fused
- * residual/restriction and correction/residual passes, "prolong_fused" [1], "mg_coarse" [2] coarse levels
- * in one launch (1: their arrays in global memory, 2: resident in LDS, 3: as 2 with the LDS pool pre-filled with NaN -- test aid),
+ * residual/restriction and correction/residual passes, "prolong_fused" [1], "mg_coarse" [4] coarse levels
+ * in one launch (1: their arrays in global memory, 2: resident in LDS, 3: as 2 with the LDS pool pre-filled with NaN -- test aid; round 3,
+ * default 4: the lean LDS form k_mg_coarse_lean where it applies -- uniform S or one layer, walls or doubly periodic -- else as 2),
  * "resmax_rows" [0 = 32] rows per chunk of the marching max-only residual pass (-1: the LDS-tiled kernel), "march" [1] chained half-sweep smoother on HBM-bound single-GPU levels (2: on every level that is
  * wide enough), "march_k" [4] half-sweeps per pass, "march_rows" [0 = auto] chunk height, "march_min" [23] log2 of the cell-layers a level needs, "march_prolong" [1] prolongation folded
  * into the first pass, "march_dma" [2] memory side of the pass (0: register-window loads, 1: LDS-DMA prefetch with one strip per

@@ -94,7 +94,9 @@ void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const do
 #define MGC_NT 512
 struct CoarseLev { double *da, *res; const double *S; SplitGeom g; RelaxCoef rc; };
 struct CoarseArgs { CoarseLev lev[MGC_MAXLEV]; int n, walls, prolong_fused, lds; };
-void launch_mg_coarse(hipStream_t st, const CoarseArgs *d_args, int nrelax, int nl, int uniformS);
+void launch_mg_coarse(hipStream_t st, const CoarseArgs *d_args, int nrelax, int nl, int uniformS, int lean = 0);
+size_t mg_coarse_lean_doubles(const CoarseArgs &h, int nl);   // LDS doubles the lean form needs (<= MGC_POOL)
+#define MGC_POOL 19200  // doubles of LDS pool of the one-launch coarse kernels: 150 KB
 size_t mg_coarse_static_lds();  // bytes of static LDS k_mg_coarse declares (its launch needs a device that grants them)
 void launch_nat_to_split(hipStream_t st, const double *nat, const NatGeom &g, double *sp, const SplitGeom &sg, int nl);
 void launch_split_to_nat(hipStream_t st, const double *sp, const SplitGeom &sg, double *nat, const NatGeom &g, int nl);

@@ -1182,7 +1182,6 @@ __global__ void __launch_bounds__(BX *BY) k_relax_red_prolong3(RelaxPArgs p) {
 // copied in only when the cycle comes back up, over the residuals of the coarser levels (dead by then), which is what lets
 // 32^2 x 6 layers fit.  Only that level's correction (ghosts included) goes back to global memory.  Same per-point functions,
 // same values as the separate launches.
-#define MGC_POOL 19200  // doubles: 150 KB
 __device__ __forceinline__ SplitGeom mgc_compact(const SplitGeom &g) {
   SplitGeom c = g;
   c.hp = g.hk + 2; c.rp = 2 * c.hp; c.rows = g.ny + 2; c.ls = (size_t)c.rp * c.rows;
@@ -1313,23 +1312,267 @@ __global__ void __launch_bounds__(MGC_NT) k_mg_coarse(const CoarseArgs *pa, int 
   } else if (lds_from <= 1) mgc_level<NL, UNIFORM, false, true>(pool, sh, a, 0, nrelax, tid);
   else mgc_level<NL, UNIFORM, false, false>(pool, sh, a, 0, nrelax, tid);
 }
+// ---- the same group of levels, lean form (round 3; option mg_coarse = 4, the default where it applies): uniform S (or one layer), a
+// single tile with walls or doubly periodic.  k_mg_coarse above runs the device functions of the stand-alone kernels on LDS copies in the
+// padded split layout (generic pointers: flat loads and stores next to ds ones, 2300 branches of ghost and layout cases) and takes
+// 65 us at nl = 3 / 96 us at nl = 6 for ~50 phases -- a third of a 512^2 x 3 step.  Here every level is a plain [layer][row][column]
+// array in LDS with a one-cell ghost ring (correction) or none (residual), the phases are spelled out with the expressions of
+// restrict_pt, prolong_pt, relax_color_pt<.., UNIFORM> and split_write_ghosts in their order (validation build: the same bits).
+size_t mg_coarse_lean_doubles(const CoarseArgs &h, int nl) {
+  size_t o = 0;
+  for (int k = 0; k < h.n; k++) o += (size_t)nl * ((size_t)(h.lev[k].g.nx + 2) * (h.lev[k].g.ny + 2) + (size_t)h.lev[k].g.nx * h.lev[k].g.ny);
+  return o;
+}
+#define MGC_NOGHOST (-(1 << 30))   // (ghost offsets are relative to cell (0, 0): -1 and below are real targets)
 template <int NL>
-static void mg_coarse_dispatch(hipStream_t st, const CoarseArgs *d_args, int nrelax, int uniformS) {
+__global__ void __launch_bounds__(MGC_NT) k_mg_coarse_lean(const CoarseArgs *pa, int nrelax) {
+  __shared__ double pool[MGC_POOL];
+  const CoarseArgs &a = *pa;
+  const int tid = threadIdx.x;
+  // The argument block lives in global memory (7 KB: too large for the kernel-argument segment) and every barrier is a fence: what the
+  // phases need of it -- level sizes, pool offsets, the column-solver constants -- is copied to LDS once, and each level takes its
+  // constants into registers before its sweeps (a phase then waits for LDS only)
+  __shared__ int s_geo[MGC_MAXLEV][4];               // nx, ny, offset of the correction's cell (0, 0), offset of the residual
+  __shared__ double s_co[MGC_MAXLEV][1 + 3 * NL];    // sqD, w[], it1[], t2[]
+  __shared__ int s_n, s_walls;
+  if (tid == 0) {
+    int o = 0;
+    for (int q = 0; q < a.n; q++) {
+      const int nx = a.lev[q].g.nx, ny = a.lev[q].g.ny;
+      s_geo[q][0] = nx; s_geo[q][1] = ny;
+      s_geo[q][2] = o + (nx + 2) + 1;
+      o += NL * (nx + 2) * (ny + 2);
+      s_geo[q][3] = o;
+      o += NL * nx * ny;
+    }
+    s_n = a.n; s_walls = a.walls;
+  }
+  if (tid < MGC_MAXLEV && tid < a.n) {
+    const RelaxCoef &rc = a.lev[tid].rc;
+    s_co[tid][0] = rc.sqD;
+    for (int l = 0; l < NL; l++) { s_co[tid][1 + l] = rc.w[l]; s_co[tid][1 + NL + l] = rc.it1[l]; s_co[tid][1 + 2 * NL + l] = rc.t2[l]; }
+  }
+  __syncthreads();
+  const int n = s_n;
+  const bool per = (s_walls & WALL_PER) != 0;
+  // offsets of level k: correction [NL][ny + 2][nx + 2] (od points at cell (0, 0) of layer 0), residual [NL][ny][nx]
+  auto geom = [&](int k, int &nx, int &ny, int &od, int &orr) { nx = s_geo[k][0]; ny = s_geo[k][1]; od = s_geo[k][2]; orr = s_geo[k][3]; };
+  // boundary_level: the ghosts an edge cell owns (split_write_ghosts)
+  auto ghosts = [&](double *d, int nx, int ny, int j, int i, double v) {
+    const int pw = nx + 2;
+    const bool w = i == 0, e = i == nx - 1, s_ = j == 0, nn = j == ny - 1;
+    if (!(w | e | s_ | nn)) return;
+    if (per) {
+      if (w) d[j * pw + nx] = v;
+      if (e) d[j * pw - 1] = v;
+      if (s_) d[ny * pw + i] = v;
+      if (nn) d[-pw + i] = v;
+      if (w && s_) d[ny * pw + nx] = v;
+      if (w && nn) d[-pw + nx] = v;
+      if (e && s_) d[ny * pw - 1] = v;
+      if (e && nn) d[-pw - 1] = v;
+    } else {
+      if (w) d[j * pw - 1] = -v;
+      if (e) d[j * pw + nx] = -v;
+      if (s_) d[-pw + i] = -v;
+      if (nn) d[ny * pw + i] = -v;
+      if (w && s_) d[-pw - 1] = v;
+      if (w && nn) d[ny * pw - 1] = v;
+      if (e && s_) d[-pw + nx] = v;
+      if (e && nn) d[ny * pw + nx] = v;
+    }
+  };
+  int nx0, ny0, od0, or0;
+  geom(0, nx0, ny0, od0, or0);
+  {  // residual of the group's finest level from memory
+    const CoarseLev &G = a.lev[0];
+    for (int t = tid; t < nx0 * ny0 * NL; t += MGC_NT) {
+      const int i = t % nx0, j = (t / nx0) % ny0, l = t / (nx0 * ny0);
+      pool[or0 + (l * ny0 + j) * nx0 + i] = G.res[split_idx(G.g, l, j, i)];
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k + 1 < n; k++) {   // restrictions (restrict_pt)
+    int fx, fy, fd, fr, cx, cy, cd, cr;
+    geom(k, fx, fy, fd, fr);
+    geom(k + 1, cx, cy, cd, cr);
+    for (int t = tid; t < cx * cy; t += MGC_NT) {
+      const int I = t % cx, J = t / cx;
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        const double *f = pool + fr + l * fy * fx;
+        double sum = 0.;
+        sum += f[(2 * J) * fx + 2 * I];
+        sum += f[(2 * J + 1) * fx + 2 * I];
+        sum += f[(2 * J) * fx + 2 * I + 1];
+        sum += f[(2 * J + 1) * fx + 2 * I + 1];
+        pool[cr + (l * cy + J) * cx + I] = sum / 4;
+      }
+    }
+    __syncthreads();
+  }
+  for (int k = n - 1; k >= 0; k--) {
+    int nx, ny, od, orr;
+    geom(k, nx, ny, od, orr);
+    const int pw = nx + 2, lsd = pw * (ny + 2);
+    if (k == n - 1) {   // first guess 0, ghosts included
+      for (int t = tid; t < NL * lsd; t += MGC_NT) pool[od - pw - 1 + t] = 0.;
+    } else {            // bilinear prolongation + boundary_level (prolong_pt)
+      int cx, cy, cd, cr;
+      geom(k + 1, cx, cy, cd, cr);
+      const int cpw = cx + 2, cls = cpw * (cy + 2);
+      for (int t = tid; t < nx * ny; t += MGC_NT) {
+        const int i = t % nx, j = t / nx;
+        const int I = i >> 1, J = j >> 1, sx = (i & 1) ? 1 : -1, sy = (j & 1) ? 1 : -1;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+          const double *c = pool + cd + l * cls;
+          double *d = pool + od + l * lsd;
+          const double v = BILINEAR(c[J * cpw + I], c[J * cpw + I + sx], c[(J + sy) * cpw + I], c[(J + sy) * cpw + I + sx]);
+          d[j * pw + i] = v;
+          ghosts(d, nx, ny, j, i, v);
+        }
+      }
+    }
+    __syncthreads();
+    double cw[NL], cit1[NL], ct2[NL];
+    const double sqD = s_co[k][0];
+#pragma unroll
+    for (int l = 0; l < NL; l++) { cw[l] = s_co[k][1 + l]; cit1[l] = s_co[k][1 + NL + l]; ct2[l] = s_co[k][1 + 2 * NL + l]; }
+    // a phase of a small level is one wavefront's serial instruction stream: the thread's cell of either colour (a level has at most
+    // 32 x 32 / 2 = MGC_NT cells per colour), its offsets and whether it owns ghosts are formed once per level, not once per phase
+    const int hk = nx >> 1, cells = nx * ny, lhk = hk > 0 ? 31 - __clz(hk) : 0;
+    int oc[2], rc_[2], gt[2][3];
+    double gsn[2][3];
+    bool act[2], edge[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      int i, j;
+      if (nx & 1) { i = tid % nx; j = tid / nx; act[c] = tid < cells && ((i + j) & 1) == c; }   // a 1-wide level
+      else { j = tid >> lhk; i = 2 * (tid - (j << lhk)) + ((j + c) & 1); act[c] = tid < hk * ny; }   // hk is a power of two (grid sizes are)
+      oc[c] = od + j * pw + i;
+      rc_[c] = orr + j * nx + i;
+      edge[c] = act[c] && (i == 0 || i == nx - 1 || j == 0 || j == ny - 1);
+      // the ghosts this cell owns, as offsets from the layer's cell (0, 0) and signs (levels of >= 2 x 2 cells: at most the two edge
+      // images and the corner image; degenerate levels go through ghosts())
+      gt[c][0] = gt[c][1] = gt[c][2] = MGC_NOGHOST;
+      gsn[c][0] = gsn[c][1] = gsn[c][2] = 1.;
+      if (edge[c] && nx >= 2 && ny >= 2) {
+        const bool w = i == 0, e = i == nx - 1, s_ = j == 0, nn = j == ny - 1;
+        int q = 0;
+        if (per) {
+          if (w) gt[c][q++] = j * pw + nx;
+          if (e) gt[c][q++] = j * pw - 1;
+          if (s_) gt[c][q++] = ny * pw + i;
+          if (nn) gt[c][q++] = -pw + i;
+          if (w && s_) gt[c][q++] = ny * pw + nx;
+          if (w && nn) gt[c][q++] = -pw + nx;
+          if (e && s_) gt[c][q++] = ny * pw - 1;
+          if (e && nn) gt[c][q++] = -pw - 1;
+        } else {
+          if (w) { gsn[c][q] = -1.; gt[c][q++] = j * pw - 1; }
+          if (e) { gsn[c][q] = -1.; gt[c][q++] = j * pw + nx; }
+          if (s_) { gsn[c][q] = -1.; gt[c][q++] = -pw + i; }
+          if (nn) { gsn[c][q] = -1.; gt[c][q++] = ny * pw + i; }
+          if (w && s_) gt[c][q++] = -pw - 1;
+          if (w && nn) gt[c][q++] = ny * pw - 1;
+          if (e && s_) gt[c][q++] = -pw + nx;
+          if (e && nn) gt[c][q++] = ny * pw + nx;
+        }
+      }
+    }
+    const bool degenerate = nx < 2 || ny < 2;
+    // one half-sweep of colour c by this thread's cell
+    auto phase = [&](int c) {
+      if (!act[c]) return;
+      double rhs[NL], x[NL];
+      const int o = oc[c];
+      if (NL == 1) {
+        double nn = -sqD * pool[rc_[c]], dd = 0.;
+        nn += pool[o + 1] + pool[o - 1]; dd += 2.;
+        nn += pool[o + pw] + pool[o - pw]; dd += 2.;
+        x[0] = nn / dd;
+      } else {
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+          double r = -sqD * pool[rc_[c] + l * cells];
+          r += pool[o + l * lsd + 1] + pool[o + l * lsd - 1];
+          r += pool[o + l * lsd + pw] + pool[o + l * lsd - pw];
+          rhs[l] = r;
+        }
+#pragma unroll
+        for (int l = 1; l < NL; l++) rhs[l] -= cw[l] * rhs[l - 1];
+        x[NL - 1] = rhs[NL - 1] * cit1[NL - 1];
+#pragma unroll
+        for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - ct2[l] * x[l + 1]) * cit1[l];
+      }
+#pragma unroll
+      for (int l = 0; l < NL; l++) pool[o + l * lsd] = x[l];
+      if (edge[c]) {
+        if (degenerate) {
+          const int j = (o - od) / pw, i = (o - od) - j * pw;
+#pragma unroll
+          for (int l = 0; l < NL; l++) ghosts(pool + od + l * lsd, nx, ny, j, i, x[l]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 3; q++)
+            if (gt[c][q] != MGC_NOGHOST) {
+#pragma unroll
+              for (int l = 0; l < NL; l++) pool[od + l * lsd + gt[c][q]] = gsn[c][q] * x[l];
+            }
+        }
+      }
+    };
+    const int per_colour = (nx & 1) ? cells : hk * ny;
+    if (per_colour <= 64) {
+      // a level of at most 64 cells per colour is one wavefront's work: its LDS operations execute in order, so the half-sweeps need no
+      // workgroup barrier between them (the other wavefronts wait once, at the end of the level)
+      if (tid < 64) {
+        for (int it = 0; it < nrelax; it++)
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            phase(c);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+      }
+      __syncthreads();
+    } else {
+      for (int it = 0; it < nrelax; it++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          phase(c);
+          __syncthreads();
+        }
+    }
+  }
+  {  // correction of the group's finest level to memory, ghosts included (the next finer level interpolates from it)
+    const CoarseLev &G = a.lev[0];
+    const int w = nx0 + 2, h = ny0 + 2;
+    for (int t = tid; t < w * h * NL; t += MGC_NT) {
+      const int i = t % w - 1, j = (t / w) % h - 1, l = t / (w * h);
+      G.da[split_idx(G.g, l, j, i)] = pool[od0 + l * w * h + j * w + i];
+    }
+  }
+}
+template <int NL>
+static void mg_coarse_dispatch(hipStream_t st, const CoarseArgs *d_args, int nrelax, int uniformS, int lean) {
+  if (lean) { hipLaunchKernelGGL((k_mg_coarse_lean<NL>), dim3(1), dim3(MGC_NT), 0, st, d_args, nrelax); return; }
   if (uniformS) hipLaunchKernelGGL((k_mg_coarse<NL, true>), dim3(1), dim3(MGC_NT), 0, st, d_args, nrelax);
   else hipLaunchKernelGGL((k_mg_coarse<NL, false>), dim3(1), dim3(MGC_NT), 0, st, d_args, nrelax);
 }
 size_t mg_coarse_static_lds() { return sizeof(double) * MGC_POOL + sizeof(MgcShared); }
 
-void launch_mg_coarse(hipStream_t st, const CoarseArgs *d_args, int nrelax, int nl, int uniformS) {
+void launch_mg_coarse(hipStream_t st, const CoarseArgs *d_args, int nrelax, int nl, int uniformS, int lean) {
   switch (nl) {
-    case 1: mg_coarse_dispatch<1>(st, d_args, nrelax, uniformS); break;
-    case 2: mg_coarse_dispatch<2>(st, d_args, nrelax, uniformS); break;
-    case 3: mg_coarse_dispatch<3>(st, d_args, nrelax, uniformS); break;
-    case 4: mg_coarse_dispatch<4>(st, d_args, nrelax, uniformS); break;
-    case 5: mg_coarse_dispatch<5>(st, d_args, nrelax, uniformS); break;
-    case 6: mg_coarse_dispatch<6>(st, d_args, nrelax, uniformS); break;
-    case 7: mg_coarse_dispatch<7>(st, d_args, nrelax, uniformS); break;
-    case 8: mg_coarse_dispatch<8>(st, d_args, nrelax, uniformS); break;
+    case 1: mg_coarse_dispatch<1>(st, d_args, nrelax, uniformS, lean); break;
+    case 2: mg_coarse_dispatch<2>(st, d_args, nrelax, uniformS, lean); break;
+    case 3: mg_coarse_dispatch<3>(st, d_args, nrelax, uniformS, lean); break;
+    case 4: mg_coarse_dispatch<4>(st, d_args, nrelax, uniformS, lean); break;
+    case 5: mg_coarse_dispatch<5>(st, d_args, nrelax, uniformS, lean); break;
+    case 6: mg_coarse_dispatch<6>(st, d_args, nrelax, uniformS, lean); break;
+    case 7: mg_coarse_dispatch<7>(st, d_args, nrelax, uniformS, lean); break;
+    case 8: mg_coarse_dispatch<8>(st, d_args, nrelax, uniformS, lean); break;
     default: break;
   }
 }

@@ -161,7 +161,9 @@ struct msom {
   int mgc_dim = MGC_MAXDIM;  // widest level of that group
   int mgc_pfused = 1;   // option: prolongation fused into the first red phase inside k_mg_coarse (nl <= 4)
   int umax_clean = 0;  // the max|u| accumulators were zeroed with the solve's scalars and not used since
-  int mgc_first = -1, mgc_opt = 2;  // first (finest) level of the group, -1: none; option "mg_coarse" (1: through global memory, 2: levels resident in LDS)
+  int mgc_first = -1, mgc_opt = 4;  // first (finest) level of the group, -1: none; option "mg_coarse" (1: through global memory, 2: levels resident in LDS,
+                                    // 3: as 2 with a NaN-filled pool, 4: the lean LDS form k_mg_coarse_lean where it applies, else 2)
+  int mgc_lean = 0;
   int res_ready = -1;  // field id whose first multigrid residual (levels 0, 1; SC_RESF; partial sums) the last tendency pass already produced
   int adv_fused = 1;   // fold q_out = q_in + dt dq into the tendency pass
   int rhs_resid = 0;   // let the fused tendency + advance pass produce it: measured slower (23 spilled VGPRs in the 256-VGPR kernel: 2.21 ms vs 1.63 + 0.50 ms), kept as an option
@@ -781,6 +783,7 @@ extern "C" double msom_get_param(msom_t *m, const char *key) {
   // which kernels the dispatch picks for this handle (bench.py names what ran from these, not from a table)
   if (!strcmp(key, "resmax_marching")) { extern int g_resmax_rows; return m->uniformS && m->nl <= MSOM_FASTNL && m->g.nx >= 64 && m->g.ny >= 16 && g_resmax_rows >= 0; }
   if (!strcmp(key, "march_lean")) { extern int g_march_lean; return g_march_lean; }
+  if (!strcmp(key, "mg_coarse_lean")) return m->mgc_first >= 0 && m->mgc_lean;   // the coarse group runs in k_mg_coarse_lean
   if (!strcmp(key, "march_levels")) return march_levels(m);   // tile levels whose half-sweeps are chained (kernels_march.hip)
   auto idx = [](const char *s, int n) { const int k = atoi(s); return k >= 0 && k < n ? k : -1; };
   if (!strncmp(key, "idh0_", 5)) { const int k = idx(key + 5, MSOM_MAXNL); return k < 0 ? NAN : m->lc.idh0[k]; }
@@ -951,6 +954,7 @@ static int setup_agglomeration(msom *m) {
 // this tile's own levels (single tile); levels that need halo exchanges stay on the per-kernel path
 static int setup_mg_coarse(msom *m) {
   m->mgc_first = -1;
+  m->mgc_lean = 0;
   if (!m->mgc_opt || m->block_sweeps || m->nlev < 1 || m->nl > MSOM_FASTNL) return MSOM_OK;
   const bool glob = m->agg_level >= 0;
   if (!glob && m->nranks > 1) return MSOM_OK;
@@ -974,13 +978,17 @@ static int setup_mg_coarse(msom *m) {
   h.n = m->nlev - k0;
   h.walls = glob ? (m->bc == BC_PERIODIC ? WALL_PER : WALL_ALL) : m->walls;
   h.prolong_fused = m->prolong_fused && m->mgc_pfused;  // the kernel itself compiles the fused phase out from nl = 5 on (registers)
-  h.lds = m->mgc_opt >= 2 ? m->mgc_opt - 1 : 0;
+  h.lds = m->mgc_opt == 3 ? 2 : (m->mgc_opt >= 2 ? 1 : 0);
   for (int k = k0; k < m->nlev; k++) {
     CoarseLev &L = h.lev[k - k0];
     if (glob) { const int q = k - m->agg_level; L.da = m->gda[q]; L.res = m->gres[q]; L.S = nullptr; L.g = m->gsg[q]; }
     else { L.da = m->da[k]; L.res = m->res[k]; L.S = m->S[k]; L.g = m->sg[k]; }
     L.rc = m->rc[k];
   }
+  // mg_coarse = 4 (default): the lean LDS form of the kernel where it exists -- uniform S or one layer, walls on every side or the
+  // doubly periodic single tile (also the gathered levels of a tiled run, which are a whole domain), all levels inside the pool
+  m->mgc_lean = m->mgc_opt >= 4 && (m->uniformS || m->nl == 1) && (h.walls == WALL_ALL || h.walls == WALL_PER) &&
+                mg_coarse_lean_doubles(h, m->nl) <= (size_t)MGC_POOL;
   if (!m->d_cargs) HIPCHK(hipMalloc(&m->d_cargs, sizeof(CoarseArgs)));
   HIPCHK(hipMemcpyAsync(m->d_cargs, &h, sizeof h, hipMemcpyHostToDevice, m->st));
   HIPCHK(hipStreamSynchronize(m->st));
@@ -1397,7 +1405,7 @@ static void mg_cycle_levels(msom *m, int nrelax, int first_restrict) {
     const int gtop = kg >= 0 ? kg : m->nlev - 1;  // coarsest level restricted by its own launch
     for (int k = kc + 1; k <= gtop; k++) launch_restrict(m->st, m->gres[k - 1 - kc], m->gsg[k - 1 - kc], m->gres[k - kc], m->gsg[k - kc], nl);
     if (kg >= 0) {
-      launch_mg_coarse(m->st, m->d_cargs, nrelax, nl, m->uniformS);
+      launch_mg_coarse(m->st, m->d_cargs, nrelax, nl, m->uniformS, m->mgc_lean);
       if (hipGetLastError() != hipSuccess && !m->sticky) m->sticky = MSOM_ERR_HIP;
     }
     for (int k = (kg >= 0 ? kg : m->nlev) - 1; k >= kc; k--) {
@@ -1408,7 +1416,7 @@ static void mg_cycle_levels(msom *m, int nrelax, int first_restrict) {
     // this rank's tile of the level-kc correction, with its ghost ring
     launch_extract_tile(m->st, m->gda[0], m->gsg[0], m->da[kc], tg, nl, m->ix * tg.nx, m->iy * tg.ny);
   } else if (kg >= 0) {
-    launch_mg_coarse(m->st, m->d_cargs, nrelax, nl, m->uniformS);
+    launch_mg_coarse(m->st, m->d_cargs, nrelax, nl, m->uniformS, m->mgc_lean);
     if (hipGetLastError() != hipSuccess && !m->sticky) m->sticky = MSOM_ERR_HIP;
   }
   for (int k = (glob ? kc : (kg >= 0 ? kg : m->nlev)) - 1; k >= 0; k--) {

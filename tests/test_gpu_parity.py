@@ -817,3 +817,34 @@ def test_residual_pass_that_restricts_two_levels(nx, ny, nl, strict):
         g.close()
     assert out[0][2] == out[1][2] and out[0][2][0] >= 2
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("nx,ny,nl,extra", [(256, 128, 6, ""), (64, 64, 3, ""), (32, 32, 1, ""), (512, 64, 2, ""), (64, 64, 5, ""), (256, 256, 4, ""),
+                                            (128, 128, 3, "sbc = -1\ntau0 = 0\n"), (64, 128, 6, "sbc = -1\ntau0 = 0\n"), (128, 128, 3, "sbc = 1.5\nRe = 300\n")])
+@pytest.mark.parametrize("strict", [True, False])
+def test_lean_coarse_kernel_equals_per_kernel_path(nx, ny, nl, extra, strict):
+    """mg_coarse = 4 (default, round 3): k_mg_coarse_lean -- the levels of <= 32 cells a side as plain arrays in LDS, the phases spelled out
+    with the expressions of the stand-alone kernels -- against one launch per half-sweep on every level (mg_coarse = 0, block8 = 0) and
+    against the older one-launch form (mg_coarse = 2); uniform S (validation build: on request); walls, partial slip, doubly periodic;
+    TOLERANCE 1e-8: several cycles per solve, nrelax adapts"""
+    txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else "") + extra)
+    out = {}
+    for opt in (0, 2, 4):
+        g = QG(txt, strict=strict)
+        g.option("quiet", 1); g.option("TOLERANCE", 1e-8); g.option("uniform_S", 1)
+        g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx))
+        g.set_const()
+        g.option("mg_coarse", opt)
+        if opt == 0:
+            g.option("block8", 0)
+        assert g.param("mg_coarse_lean") == (1.0 if opt == 4 else 0.0)
+        for _ in range(2):
+            g.step()
+        st = g.mgstats()
+        out[opt] = (g.get(F["PSI"]), g.get(F["Q"]), (st.i, st.resa, st.nrelax))
+        g.close()
+    for opt in (2, 4):
+        if strict:
+            assert np.array_equal(out[0][0], out[opt][0]) and np.array_equal(out[0][1], out[opt][1]) and out[0][2] == out[opt][2], opt
+        else:
+            assert rel(out[opt][0], out[0][0]) <= 1e-10 and out[0][2][0] == out[opt][2][0], opt
