@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(BX *BY) k_residual2(Res2Args p) {
 #define CR_LP 132  // LDS row pitch (130 used)
 // CORR = false: a is already the corrected field (kernels_march.hip applied a += da): only max |res|, max |u|
 template <bool UNIFORM, bool CORR = true>
-__global__ void __launch_bounds__(BX *BY, 4) k_correct_residual(Res2Args p) {
+__global__ void __launch_bounds__(BX *BY, UNIFORM ? 4 : 3) k_correct_residual(Res2Args p) {   // general S: 128 VGPRs spilled 37 registers (round 3: 3 waves per SIMD)
   __shared__ __align__(16) double T[2][CR_TR + 2][CR_LP];
   __shared__ double smm[BY];
   __shared__ double smu[MSOM_MAXNL][BY];
