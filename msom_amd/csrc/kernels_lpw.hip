@@ -378,16 +378,30 @@ void launch_rhs_lpw(hipStream_t st, const double *psi, const double *S, const do
   for (int l = 0; l < MSOM_MAXNL; l++) a.Su[l] = Su ? Su[l] : 0.;
   const int strips = (g.nx + LPW_W - 1) / LPW_W;
   int H = chunk_rows;
-  if (H <= 0) {  // enough workgroups to fill 256 CUs a few times over, chunks long enough to amortise the 6 warm-up rows
-    const int want = (1024 + strips - 1) / strips;
-    H = (g.ny + want - 1) / want;
-    H = ((H + 7) / 8) * 8;
-    if (H > 64) H = 64;
+  a.NS = LPW_MAXW / nl < 1 ? 1 : LPW_MAXW / nl;
+  if (a.NS > strips) a.NS = strips;
+  if (H <= 0) {
+    // One workgroup (all of a CU's wavefront slots at the product build's register count) per CU at a time: the launch takes
+    // ceil(workgroups / CUs) rounds of H + 6 row steps (6 warm-up rows per chunk).  Round 3: the chunk height that minimises that product
+    // -- the former rule (about 1024 / strips chunks, at most 64 rows) gave 2048^2 x 3 288 workgroups of 64 rows = 1.125 rounds, i.e. two
+    // rounds of 70 steps where 40 rows give two of 46 (0.117 -> 0.09 ms per launch); 4096^2 x 6 keeps its 64 rows (9 rounds)
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t pr;
+      ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    const int wgx = (strips + a.NS - 1) / a.NS;
+    // (workgroups do not end together: past three rounds the idle tail is taken as half a round rather than a whole one -- with whole
+    // rounds 4096^2 x 3 would take 32 rows, measured 3 % slower than 64)
+    double best = -1.;
+    for (int h = 64; h >= 8; h -= 8) {
+      const double r = (double)wgx * ((g.ny + h - 1) / h) / ncu, cost = (r <= 3. ? ceil(r) : r + 0.5) * (h + 6);
+      if (best < 0. || cost < best) { best = cost; H = h; }
+    }
   }
   if (H < 8) H = 8;
   a.H = H;
-  a.NS = LPW_MAXW / nl < 1 ? 1 : LPW_MAXW / nl;
-  if (a.NS > strips) a.NS = strips;
   const dim3 gr((strips + a.NS - 1) / a.NS, (g.ny + H - 1) / H), bl(64 * nl * a.NS);
   const int sel = (uniformS ? 4 : 0) | (have_qforc ? 2 : 0) | (q_out ? 1 : 0);
   if (stoch) {  // only with the advance fused (the caller folds -q/tau and the noise into q_in)
