@@ -84,6 +84,7 @@ struct msomn {
   int node_rhs_fused = 1;   // option: the baroclinic tendency in three passes (k_n_rhs_pre, k_n_del2_bnd, k_n_rhs_all) instead of twelve
   int node_corr_fused = 2;  // option: the correction a += da rides in the next cycle's residual pass (k_n_correct_residual)
   double *psi_alt = nullptr;
+  hipEvent_t ev_res = nullptr;   // marks the copy of max |res| to the host inside vpoisson
   int node_march_s = 2049;  // option: split levels of >= node_march_s vertices per side chain up to 4 colour half-sweeps per pass (k_n_relax_march_s,
                             // round 3).  2049^2 x 3, 9 cycles per solve (tools/ab_node_prof.py): 3 passes of 83 us replace 9 colour launches of 33 us:
                             // 17.3 -> 16.6 ms per step; on the 1025^2 and 513^2 levels the pass loses (17.4 / 18.4): too few chunks for a
@@ -198,6 +199,7 @@ extern "C" void msomn_destroy(msomn_t *m) {
   for (auto *v : {&m->ws, &m->wr, &m->wsig, &m->wmc})
     for (double *q : *v) if (q) (void)hipFree(q);
   if (m->psi_alt) (void)hipFree(m->psi_alt);
+  if (m->ev_res) (void)hipEventDestroy(m->ev_res);
   if (m->qeff) (void)hipFree(m->qeff);
   if (m->d2bs) (void)hipFree(m->d2bs);
   if (m->d_scal) (void)hipFree(m->d_scal);
@@ -645,13 +647,13 @@ static int vpoisson(msomn *m, double *&a, const double *b) {
       nprof_end(m, NP_RESIDUAL);
     }
     pending_correct = false;
-    double max;
-    int r = read_scalar(m, NSC_RES, &max);
-    if (r) return r;
-    mg.resa = max;
-    if (mg.i == 0) mg.resb = max;
-    if (max < m->tolerance && mg.i >= m->nitermin) break;
-    // (boundary_level of the residual: its boundary vertices were stored as 0 by the pass above, zb = 1)
+    // max |res| travels to the host; the restrictions of the cycle that follows unless the solve ends here are queued behind the copy
+    // (round 3): the GPU works through them while the host waits for the number and decides -- they write nothing but the coarse levels'
+    // residuals, which nobody reads if the solve is over.  (boundary_level of the residual: the pass above stored 0 on the boundary
+    // vertices, zb = 1; the boundary vertices of every coarser level end up 0 as well)
+    HIPCHK(hipMemcpyAsync(m->h_scal + NSC_RES, m->d_scal + NSC_RES, sizeof(double), hipMemcpyDeviceToHost, m->st));
+    if (!m->ev_res) HIPCHK(hipEventCreateWithFlags(&m->ev_res, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(m->ev_res, m->st));
     // kc: first level of the group that one workgroup handles in one launch (<= 33^2 vertices, at least two levels)
     int kc = nlev;
     if (m->mg_coarse) {
@@ -659,9 +661,13 @@ static int vpoisson(msomn *m, double *&a, const double *b) {
       while (k0 < nlev && m->lev[k0].n > m->mg_coarse) k0++;
       if (nlev - k0 >= 2 && nlev - k0 <= NMGC_MAXLEV) kc = k0;
     }
-    for (int k = 1; k < nlev && k <= kc; k++) {  // the boundary vertices of every level end up 0 (boundary_level)
+    for (int k = 1; k < nlev && k <= kc; k++)
       launch_n_restrict(m->st, m->lev[k - 1].res, m->lev[k - 1].ga, m->lev[k].res, m->lev[k].ga, nl, 0, m->lev[k - 1].sp, m->lev[k].sp, 1);
-    }
+    HIPCHK(hipEventSynchronize(m->ev_res));
+    const double max = m->h_scal[NSC_RES];
+    mg.resa = max;
+    if (mg.i == 0) mg.resb = max;
+    if (max < m->tolerance && mg.i >= m->nitermin) break;
     if (kc < nlev) {
       NCoarseArgs ca;
       ca.n = nlev - kc; ca.iRd2 = m->iRd2_low; ca.lc = m->lc;
