@@ -780,22 +780,39 @@ def test_speculative_tendency_pass_changes_nothing(nx, ny, nl, extra, tol, stric
     again the ordinary way if the solve needs more cycles (tol 1e-9: always).  Same numbers as with the option off, step by
     step, in both builds; with output times ahead (dtnext() shortens dt) and with none"""
     outs = []
-    for async_solve in (0, 1):
+    for async_solve, step_sync in ((0, 1), (1, 1), (1, 0)):     # step_sync = 0: msom_step returns with its last tendency pass still running
         txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else "") + extra)
         g = QG(txt, strict=strict)
-        g.option("quiet", 1); g.option("TOLERANCE", tol); g.option("async_solve", async_solve)
+        g.option("quiet", 1); g.option("TOLERANCE", tol); g.option("async_solve", async_solve); g.option("step_sync", step_sync)
         g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx)); g.set_const()
         rec = []
         for k in range(6):
             g.set_tnext(float("inf") if k < 3 else g.t + 0.0371)      # an output event ahead: dtnext() cuts dt to land on it
             dt = g.step()
+            if step_sync == 0 and k % 2:
+                g.step(); dt2 = g.step()          # steps queued back to back, nothing read in between
+                g.sync()
             st = g.mgstats()
             rec.append((dt, g.t, g.get(F["Q"]), g.get(F["PSI"]), (st.i, st.resa)))
         outs.append(rec)
         g.close()
-    for a, b in zip(*outs):
+    for a, b in zip(outs[0], outs[1]):
         assert a[0] == b[0] and a[1] == b[1] and a[4] == b[4]
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    # the lazily synchronised run took extra steps after the odd ones: compare the steps before the first of them, then run the
+    # synchronous variant through the same sequence
+    assert outs[2][0][0] == outs[0][0][0] and np.array_equal(outs[2][0][2], outs[0][0][2]) and np.array_equal(outs[2][0][3], outs[0][0][3])
+    g = QG(orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else "") + extra), strict=strict)
+    g.option("quiet", 1); g.option("TOLERANCE", tol)
+    g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx)); g.set_const()
+    for k in range(6):
+        g.set_tnext(float("inf") if k < 3 else g.t + 0.0371)
+        g.step()
+        if k % 2:
+            g.step(); g.step()
+        assert g.t == outs[2][k][1]
+        assert np.array_equal(g.get(F["Q"]), outs[2][k][2]) and np.array_equal(g.get(F["PSI"]), outs[2][k][3])
+    g.close()
 
 
 @pytest.mark.parametrize("strict", [True, False])
