@@ -407,6 +407,13 @@ def test_chained_half_sweeps_in_the_split_layout(nl, N, strict):
         o.step(True); g.step(True)
     for name, idx in FIELDS:
         same(g.get(name), o.get(idx), strict, 1e-6)
+    o3, g3 = make_pair(N, nl, strict, mask=True, bc_fac=0.5, extra="gp_low = 0.02\n")     # the other way of cutting 9 half-sweeps into passes: 4 + 3 + 2
+    g3.set_option("node_split", 65); g3.set_option("node_march_s", 65); g3.set_option("node_march_tail1", 0)
+    g3.set_tnext(float("inf"))
+    for _ in range(2):
+        g3.step(True)
+    for name, _ in FIELDS:
+        assert np.array_equal(g3.get(name), g.get(name)) or not strict
     for tile in (65, 0):        # without the chained pass: the tiled passes on every split level, then one launch per colour
         o2, g2 = make_pair(N, nl, strict, mask=True, bc_fac=0.5, extra="gp_low = 0.02\n")
         g2.set_option("node_split", 65)
