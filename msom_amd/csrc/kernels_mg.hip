@@ -1914,8 +1914,7 @@ void launch_relax_block2(hipStream_t st, const double *da_in, const double *coar
 }
 
 // up to 8 half-sweeps starting with colour c0 (+ the prolongation from `coarse` when given): 64 x 16 tile, halo 8, 640 threads
-// (two cell pairs each), LDS nl x 80 x 32 doubles (123 KB at nl = 6: one workgroup per CU, which the launch-bound levels do not fill anyway).
-// Returns -1 where the kernel does not exist (nl > 6)
+// LDS nl x region doubles (16 x 16 tiles: 32 x 32, 32 x 16 tiles: 48 x 32; 98 KB at nl = 8).  Returns -1 where the kernel does not exist (nl > 8)
 template <int NL, int TX, int TY, int NT>
 static void block8_launch_t(hipStream_t st, const BlockArgs &p, int prolong) {
   dim3 gr((p.g.nx + TX - 1) / TX, (p.g.ny + TY - 1) / TY);
@@ -1932,16 +1931,17 @@ static void block8_launch(hipStream_t st, const BlockArgs &p, int prolong) {
     case 1: block8_launch_t<NL, 32, 16, 768>(st, p, prolong); return;
     case 2: block8_launch_t<NL, 32, 8, 576>(st, p, prolong); return;
     case 3: block8_launch_t<NL, 16, 16, 512>(st, p, prolong); return;
-    case 6: block8_launch_t<NL, 64, 16, 640>(st, p, prolong); return;
-    default:
-      if (p.g.nx <= 256) block8_launch_t<NL, 16, 16, 512>(st, p, prolong);
-      else block8_launch_t<NL, 32, 16, 768>(st, p, prolong);
-      return;
+    case 6:
+      if constexpr (NL <= 6) { block8_launch_t<NL, 64, 16, 640>(st, p, prolong); return; }   // (164 KB of LDS at nl = 8)
+      break;
+    default: break;
   }
+  if (p.g.nx <= 256) block8_launch_t<NL, 16, 16, 512>(st, p, prolong);
+  else block8_launch_t<NL, 32, 16, 768>(st, p, prolong);
 }
 int launch_relax_block8(hipStream_t st, const double *da_in, const double *coarse, const SplitGeom &cg, const double *res, double *da_out,
                         const SplitGeom &sg, int nl, const RelaxCoef &rc, int walls, int nh, int c0) {
-  if (nh < 1 || nh > 8 || nl > 6) return -1;
+  if (nh < 1 || nh > 8 || nl > MSOM_FASTNL) return -1;
   BlockArgs p;
   p.da_in = da_in; p.res = res; p.coarse = coarse; p.da_out = da_out; p.g = sg; p.cg = cg; p.walls = walls; p.rc = rc;
   p.nh = nh; p.c0 = c0;
@@ -1953,6 +1953,8 @@ int launch_relax_block8(hipStream_t st, const double *da_in, const double *coars
     case 4: block8_launch<4>(st, p, prolong); break;
     case 5: block8_launch<5>(st, p, prolong); break;
     case 6: block8_launch<6>(st, p, prolong); break;
+    case 7: block8_launch<7>(st, p, prolong); break;
+    case 8: block8_launch<8>(st, p, prolong); break;
     default: return -1;
   }
   return 0;

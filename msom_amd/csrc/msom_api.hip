@@ -1132,10 +1132,10 @@ static bool block_ok(msom *m, const Lev &L) {
 }
 // launch-bound levels (round 3): the prolongation and up to 8 colour half-sweeps of a level visit in ONE launch of the LDS-tiled
 // smoother with a halo of 8 (k_relax_block<.., 8>, option block8; levels of 64 .. block8_max cells a side that are not marched).
-// One GPU, walls or doubly periodic, uniform S or one layer, nl <= 6 (LDS).  Measured at 4096^2 x 6 / 512^2 x 3: see DESIGN.md section 4
+// One GPU, walls or doubly periodic, uniform S or one layer, nl <= 8 (the fast kernels' limit).  Measured at 4096^2 x 6 / 512^2 x 3: see DESIGN.md section 4
 static bool march_ok(msom *m, const Lev &L);
 static bool block8_ok(msom *m, const Lev &L) {
-  if (!m->block8 || m->block_sweeps || !(m->uniformS || m->nl == 1) || m->nl > 6 || L.tiled || (L.walls != WALL_ALL && L.walls != WALL_PER)) return false;
+  if (!m->block8 || m->block_sweeps || !(m->uniformS || m->nl == 1) || m->nl > MSOM_FASTNL || L.tiled || (L.walls != WALL_ALL && L.walls != WALL_PER)) return false;
   if (L.sg->nx < 64 || L.sg->ny < 16 || L.sg->nx > m->block8_max) return false;
   // doubly periodic single tile: the kernel wraps its loads; the region (<= 48 x 32 cells) must not meet its own image; the gathered
   // coarse levels of tiled runs keep their per-colour launches

@@ -174,7 +174,7 @@ def test_randomised_product_build_vs_oracle(seed):
     assert rel(g.get(F["Q"]), o.get(orc.Q)) <= 1e-9, desc
 
 
-@pytest.mark.parametrize("nx,ny,nl", [(64, 64, 3), (128, 64, 2), (256, 256, 6), (512, 128, 1), (256, 64, 4), (1024, 128, 5), (128, 128, 6), (64, 16, 3), (1024, 16, 2), (32, 128, 4)])
+@pytest.mark.parametrize("nx,ny,nl", [(64, 64, 3), (128, 64, 2), (256, 256, 6), (512, 128, 1), (256, 64, 4), (1024, 128, 5), (128, 128, 6), (64, 16, 3), (1024, 16, 2), (32, 128, 4), (256, 128, 8), (128, 128, 7)])
 @pytest.mark.parametrize("strict", [True, False])
 def test_tiled_level_visit_equals_half_sweep_per_launch(nx, ny, nl, strict):
     """option block8 (default on, round 3): prolongation + all (up to 8) half-sweeps of a visit of a launch-bound level in ONE launch of
