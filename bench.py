@@ -254,6 +254,8 @@ class Leg:
             ("march2", "k_relax_march<nl,2>", 2.5 * w, "as march4"),
             ("sweep", "k_relax_color_x2 red + black (two launches)", 2.0 * plain_bytes, "per colour: other colour in, own residual in [, S], own colour out"),
             ("red_prolong", "k_relax_red_prolong3 (first red half-sweep + bilinear prolongation)", 1.25 * w, "residual w/2 + coarse w/4 + red out w/2"),
+            ("resid_restrict", "k_residual2<write+restrict> (pre-cycle residual + the first two restrictions)", (3.25 + 1.0 / 16.0) * w, "psi, q in, residual out, level-1 and level-2 residuals out w/4 + w/16")
+            if g.param("restrict2") == 1.0 else
             ("resid_restrict", "k_residual2<write+restrict> (pre-cycle residual + first restriction)", 3.25 * w, "psi, q in, residual out, level-1 residual out w/4"),
             ("resid_correct", "k_correct_residual (psi += da, residual max, max|u|)", 4.0 * w, "psi, da, q in, psi out"),
             ("resid_max", "k_resmax_march<nl> (marching max|res|, max|u| of the corrected psi)" if g.param("resmax_marching") == 1.0 else

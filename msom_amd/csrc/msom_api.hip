@@ -756,6 +756,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
 }
 
 static int march_levels(msom *m);
+static bool restrict2_ok(const msom *m);
 extern "C" double msom_get_param(msom_t *m, const char *key) {
   if (!m || !key) return NAN;
   const Params &p = m->p;
@@ -783,6 +784,7 @@ extern "C" double msom_get_param(msom_t *m, const char *key) {
   // which kernels the dispatch picks for this handle (bench.py names what ran from these, not from a table)
   if (!strcmp(key, "resmax_marching")) { extern int g_resmax_rows; return m->uniformS && m->nl <= MSOM_FASTNL && m->g.nx >= 64 && m->g.ny >= 16 && g_resmax_rows >= 0; }
   if (!strcmp(key, "march_lean")) { extern int g_march_lean; return g_march_lean; }
+  if (!strcmp(key, "restrict2")) return restrict2_ok(m);   // the pre-cycle residual pass restricts two levels down
   if (!strcmp(key, "mg_coarse_lean")) return m->mgc_first >= 0 && m->mgc_lean;   // the coarse group runs in k_mg_coarse_lean
   if (!strcmp(key, "march_levels")) return march_levels(m);   // tile levels whose half-sweeps are chained (kernels_march.hip)
   auto idx = [](const char *s, int n) { const int k = atoi(s); return k >= 0 && k < n ? k : -1; };
