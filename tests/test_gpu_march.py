@@ -220,3 +220,15 @@ def test_tiled_level_visit_against_oracle():
     assert g.t == pytest.approx(o.t, rel=1e-12)
     assert rel(g.get(F["Q"]), o.get(orc.Q)) <= 1e-10
     assert rel(g.get(F["PSI"]), o.get(orc.PSI)) <= 1e-10
+
+
+@pytest.mark.parametrize("opts", [dict(prolong_fused=0), dict(mg_fused=0), dict(mg_coarse=0), dict(mg_coarse=2, restrict2=0), dict(async_solve=0, fused=0),
+                                  dict(block8_max=128), dict(mg_coarse_dim=16), dict(graph=1)], ids=str)
+def test_tiled_level_visit_beside_the_other_switches(opts):
+    """the round-3 defaults (block8, restrict2, lean coarse kernel) with one older switch flipped at a time, against the kernel-per-loop
+    chain: validation build with uniform S, bit for bit; 256 x 128 x 3 and 512 x 512 x 2, several cycles per solve"""
+    for nx, ny, nl in ((256, 128, 3), (512, 512, 2)):
+        txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else "") + SLIP)
+        a = run(txt, True, nl, ny, nx, march=0, block8=0, mg_coarse=0, mg_fused=0, prolong_fused=0, fused=0, adv_fused=0)
+        b = run(txt, True, nl, ny, nx, **opts)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], (nx, opts)
