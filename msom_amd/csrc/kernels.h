@@ -117,7 +117,7 @@ void launch_relax_color(hipStream_t st, double *da, const double *res, const dou
 void launch_relax_ring(hipStream_t st, double *da, const double *res, const double *S, const SplitGeom &sg, int nl, const RelaxCoef &rc,
                        int uniformS, int color, int walls);
 int launch_relax_block8(hipStream_t st, const double *da_in, const double *coarse, const SplitGeom &cg, const double *res, double *da_out,
-                        const SplitGeom &sg, int nl, const RelaxCoef &rc, int walls, int nh, int c0);
+                        const SplitGeom &sg, int nl, const RelaxCoef &rc, int walls, int nh, int c0, const double *S = nullptr);
 void launch_relax_block2(hipStream_t st, const double *da_in, const double *coarse, const SplitGeom &cg, const double *res, double *da_out,
                          const SplitGeom &sg, int nl, const RelaxCoef &rc, int walls, int fine);
 void launch_relax_red_prolong(hipStream_t st, double *da, const double *coarse, const SplitGeom &cg, const double *res, const double *S,

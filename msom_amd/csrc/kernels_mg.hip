@@ -1724,10 +1724,13 @@ struct BlockArgs {
   SplitGeom g, cg;
   int walls;
   int nh, c0;   // half-sweeps of this pass (<= BH), colour of the first
+  const double *S;   // GENERAL instantiation: the level's S field (split layout, nl - 1 layers), read once per owned cell
   RelaxCoef rc;
 };
 
-template <int NL, int BTY, int BNT, bool PROLONG, bool FINE, int BH = 4, int BTXT = BTX>
+// GENERAL (round 3): the column system of relax_color_pt<NL, false> -- S per cell, three divisions per layer -- instead of the
+// constant-coefficient one; S of the two owned cells stays in registers beside their residuals
+template <int NL, int BTY, int BNT, bool PROLONG, bool FINE, int BH = 4, int BTXT = BTX, bool GENERAL = false>
 __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
   constexpr int NX = BTXT + 2 * BH, NY = BTY + 2 * BH, HX = NX / 2, LS = NY * 2 * HX;
   constexpr int NPOS = (HX * NY + BNT - 1) / BNT;
@@ -1748,6 +1751,7 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
   // A thread owns NPOS positions (row yy, pair index k) = the cells (yy, 2k) and (yy, 2k+1):
   // exactly one cell of each colour per position, so every lane works in every half-sweep.
   double rres[NPOS][2][NL];
+  double rS[GENERAL ? NPOS : 1][2][NL > 1 ? NL - 1 : 1];
   int ob[NPOS];  // LDS index of (layer 0, row yy, parity 0, k)
 #pragma unroll
   for (int n = 0; n < NPOS; n++) {
@@ -1786,6 +1790,7 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
           v = p.da_in[gsrc + (size_t)l * p.g.ls];
         if (act) sA[l * LS + ob[n] + c * HX] = v;
         rres[n][c][l] = ind ? p.res[gsrc + (size_t)l * p.g.ls] : 0.;
+        if (GENERAL && NL > 1 && l < NL - 1) rS[n][c][l] = ind ? p.S[gsrc + (size_t)l * p.g.ls] : 0.;
       }
     }
   }
@@ -1812,6 +1817,27 @@ __global__ void __launch_bounds__(BNT) k_relax_block(BlockArgs p) {
           nn += sA[ie] + sA[iw]; d += 2.;
           nn += sA[own + 2 * HX] + sA[own - 2 * HX]; d += 2.;
           x[0] = nn / d;
+        } else if (GENERAL) {   // relax_color_pt<NL, false>, expression for expression
+          double t0[NL], t1[NL], t2[NL];
+#pragma unroll
+          for (int l = 0; l < NL; l++) {
+            rhs[l] = -sqD * (c ? rres[n][1][l] : rres[n][0][l]);
+            t0[l] = l > 0 ? -sqD * (c ? rS[n][1][l > 0 ? l - 1 : 0] : rS[n][0][l > 0 ? l - 1 : 0]) * p.rc.idh0[l] : 0.;
+            t2[l] = l < NL - 1 ? -sqD * (c ? rS[n][1][l < NL - 1 ? l : 0] : rS[n][0][l < NL - 1 ? l : 0]) * p.rc.idh1[l] : 0.;
+            t1[l] = l == 0 ? -t2[l] : (l < NL - 1 ? -t0[l] - t2[l] : -t0[l]);
+            rhs[l] += 1. * sA[l * LS + ie] + 1. * sA[l * LS + iw];
+            t1[l] += 1. + 1.;
+            rhs[l] += 1. * sA[l * LS + own + 2 * HX] + 1. * sA[l * LS + own - 2 * HX];
+            t1[l] += 1. + 1.;
+          }
+#pragma unroll
+          for (int l = 1; l < NL; l++) {
+            t1[l] -= t0[l] * t2[l - 1] / t1[l - 1];
+            rhs[l] -= t0[l] * rhs[l - 1] / t1[l - 1];
+          }
+          x[NL - 1] = rhs[NL - 1] / t1[NL - 1];
+#pragma unroll
+          for (int l = NL - 2; l >= 0; l--) x[l] = (rhs[l] - t2[l] * x[l + 1]) / t1[l];
         } else {
 #pragma unroll
           for (int l = 0; l < NL; l++) {
@@ -1898,7 +1924,7 @@ void launch_relax_block2(hipStream_t st, const double *da_in, const double *coar
                          const SplitGeom &sg, int nl, const RelaxCoef &rc, int walls, int fine) {
   BlockArgs p;
   p.da_in = da_in; p.res = res; p.coarse = coarse; p.da_out = da_out; p.g = sg; p.cg = cg; p.walls = walls; p.rc = rc;
-  p.nh = 4; p.c0 = 0;
+  p.nh = 4; p.c0 = 0; p.S = nullptr;
   const int prolong = coarse != nullptr;
   switch (nl) {
     case 1: block_dispatch<1>(st, p, prolong, fine); break;
@@ -1915,11 +1941,11 @@ void launch_relax_block2(hipStream_t st, const double *da_in, const double *coar
 
 // up to 8 half-sweeps starting with colour c0 (+ the prolongation from `coarse` when given): 64 x 16 tile, halo 8, 640 threads
 // LDS nl x region doubles (16 x 16 tiles: 32 x 32, 32 x 16 tiles: 48 x 32; 98 KB at nl = 8).  Returns -1 where the kernel does not exist (nl > 8)
-template <int NL, int TX, int TY, int NT>
+template <int NL, int TX, int TY, int NT, bool GEN = false>
 static void block8_launch_t(hipStream_t st, const BlockArgs &p, int prolong) {
   dim3 gr((p.g.nx + TX - 1) / TX, (p.g.ny + TY - 1) / TY);
-  if (prolong) hipLaunchKernelGGL((k_relax_block<NL, TY, NT, true, false, 8, TX>), gr, dim3(NT), 0, st, p);
-  else hipLaunchKernelGGL((k_relax_block<NL, TY, NT, false, false, 8, TX>), gr, dim3(NT), 0, st, p);
+  if (prolong) hipLaunchKernelGGL((k_relax_block<NL, TY, NT, true, false, 8, TX, GEN>), gr, dim3(NT), 0, st, p);
+  else hipLaunchKernelGGL((k_relax_block<NL, TY, NT, false, false, 8, TX, GEN>), gr, dim3(NT), 0, st, p);
 }
 // tile shape: the launch-bound levels have few tiles and the pass lasts as long as ONE workgroup does, so small tiles (16 x 16: four
 // times the half-sweep work of the level in halo cells, but a quarter of the serial work per workgroup) win up to 256^2; wider levels
@@ -1927,6 +1953,13 @@ static void block8_launch_t(hipStream_t st, const BlockArgs &p, int prolong) {
 // 6.39 ms per step with 64 x 16 / 16 x 16 / this rule, 512^2 x 3 0.447 / 0.400 / 0.388; 64 x 16 on the 1024^2 level only: 6.49 vs 6.43
 template <int NL>
 static void block8_launch(hipStream_t st, const BlockArgs &p, int prolong) {
+  if (p.S) {   // general S field: the default tile shapes only
+    if constexpr (NL > 1) {
+      if (p.g.nx <= 256) block8_launch_t<NL, 16, 16, 512, true>(st, p, prolong);
+      else block8_launch_t<NL, 32, 16, 768, true>(st, p, prolong);
+    }
+    return;
+  }
   switch (g_block_variant) {
     case 1: block8_launch_t<NL, 32, 16, 768>(st, p, prolong); return;
     case 2: block8_launch_t<NL, 32, 8, 576>(st, p, prolong); return;
@@ -1940,9 +1973,10 @@ static void block8_launch(hipStream_t st, const BlockArgs &p, int prolong) {
   else block8_launch_t<NL, 32, 16, 768>(st, p, prolong);
 }
 int launch_relax_block8(hipStream_t st, const double *da_in, const double *coarse, const SplitGeom &cg, const double *res, double *da_out,
-                        const SplitGeom &sg, int nl, const RelaxCoef &rc, int walls, int nh, int c0) {
+                        const SplitGeom &sg, int nl, const RelaxCoef &rc, int walls, int nh, int c0, const double *S) {
   if (nh < 1 || nh > 8 || nl > MSOM_FASTNL) return -1;
   BlockArgs p;
+  p.S = nl > 1 ? S : nullptr;   // non-null: the general column solver
   p.da_in = da_in; p.res = res; p.coarse = coarse; p.da_out = da_out; p.g = sg; p.cg = cg; p.walls = walls; p.rc = rc;
   p.nh = nh; p.c0 = c0;
   const int prolong = coarse != nullptr;

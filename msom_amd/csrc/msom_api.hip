@@ -1134,10 +1134,11 @@ static bool block_ok(msom *m, const Lev &L) {
 }
 // launch-bound levels (round 3): the prolongation and up to 8 colour half-sweeps of a level visit in ONE launch of the LDS-tiled
 // smoother with a halo of 8 (k_relax_block<.., 8>, option block8; levels of 64 .. block8_max cells a side that are not marched).
-// One GPU, walls or doubly periodic, uniform S or one layer, nl <= 8 (the fast kernels' limit).  Measured at 4096^2 x 6 / 512^2 x 3: see DESIGN.md section 4
+// One GPU, walls or doubly periodic, nl <= 8 (the fast kernels' limit); uniform S, one layer, or a general S field.  Measured at 4096^2 x 6 / 512^2 x 3: see DESIGN.md section 4
 static bool march_ok(msom *m, const Lev &L);
 static bool block8_ok(msom *m, const Lev &L) {
-  if (!m->block8 || m->block_sweeps || !(m->uniformS || m->nl == 1) || m->nl > MSOM_FASTNL || L.tiled || (L.walls != WALL_ALL && L.walls != WALL_PER)) return false;
+  // (a general S field: the kernel's GENERAL instantiation, S of the owned cells in registers; the gathered levels of a tiled run have no S array)
+  if (!m->block8 || m->block_sweeps || !(m->uniformS || m->nl == 1 || L.S) || m->nl > MSOM_FASTNL || L.tiled || (L.walls != WALL_ALL && L.walls != WALL_PER)) return false;
   if (L.sg->nx < 64 || L.sg->ny < 16 || L.sg->nx > m->block8_max) return false;
   // doubly periodic single tile: the kernel wraps its loads; the region (<= 48 x 32 cells) must not meet its own image; the gathered
   // coarse levels of tiled runs keep their per-colour launches
@@ -1323,7 +1324,7 @@ static void relax_sweeps(msom *m, Lev &L, const Lev *coarse, int nrelax, int cor
     while (n > 0) {
       const int K = n < 8 ? n : 8;
       if (K == 1) { launch_relax_color(m->st, *L.da, L.res, L.S, *L.sg, nl, *L.rc, m->uniformS, c, L.walls, L.fine); break; }
-      if (launch_relax_block8(m->st, *L.da, src ? *src->da : nullptr, src ? *src->sg : *L.sg, L.res, *L.da_alt, *L.sg, nl, *L.rc, L.walls, K, c)) m->sticky = MSOM_ERR_ARG;
+      if (launch_relax_block8(m->st, *L.da, src ? *src->da : nullptr, src ? *src->sg : *L.sg, L.res, *L.da_alt, *L.sg, nl, *L.rc, L.walls, K, c, m->uniformS ? nullptr : L.S)) m->sticky = MSOM_ERR_ARG;
       std::swap(*L.da, *L.da_alt);
       src = nullptr; n -= K; c = (c + K) & 1;
       // periodic: the pass stored no ghost cell; boundary_level(da, l) = the wrapped copies, corners included (a following colour
