@@ -111,6 +111,7 @@ void launch_residual2(hipStream_t st, int mode, const double *a, const double *d
                       int umax_clean = 0,
                       double *res_c2 = nullptr, const SplitGeom *cg2 = nullptr);
 void launch_restrict(hipStream_t st, const double *fine, const SplitGeom &fg, double *coarse, const SplitGeom &cg, int nl);
+void launch_restrict_pyramid(hipStream_t st, const double *fine, double *const *out, const SplitGeom *g, int n, int nl);   // g[0] fine, g[1..n] outputs; n <= 5
 void launch_prolong(hipStream_t st, const double *coarse, const SplitGeom &cg, double *fine, const SplitGeom &fg, int nl, int walls);
 void launch_relax_color(hipStream_t st, double *da, const double *res, const double *S, const SplitGeom &sg, int nl, const RelaxCoef &rc,
                         int uniformS, int color, int walls, int fine, int region = 0);

@@ -659,6 +659,66 @@ void launch_restrict(hipStream_t st, const double *fine, const SplitGeom &fg, do
   hipLaunchKernelGGL(k_restrict, grid2d(cg.nx, cg.ny), block2d(), 0, st, fine, fg, coarse, cg, nl);
 }
 
+// Several restrictions in one launch (round 3): the chain below the level the residual pass restricts to is 4-5 launches of ~5 us.
+// A workgroup takes a tile of 2^n x 2^n cells of the finest level of the chain and produces its 2^(n-1) x 2^(n-1), ..., 1 x 1 means
+// on the n coarser levels, level by level through LDS (the mean of four children needs nothing outside the tile); sums in restrict_pt's
+// order from the values just stored, so every level gets the bits of the launch-per-level chain.
+#define RPYR_MAX 5
+struct RestrictPyramidArgs {
+  const double *fine;
+  double *out[RPYR_MAX];
+  SplitGeom g[RPYR_MAX + 1];   // g[0]: the fine level, g[k]: output level k
+  int n, nl;
+};
+__global__ void __launch_bounds__(256) k_restrict_pyramid(RestrictPyramidArgs a) {
+  extern __shared__ double rp[];   // two buffers of nl x (T/2)^2 and nl x (T/4)^2 doubles
+  const int tid = threadIdx.x, n = a.n, nl = a.nl, T = 1 << n;
+  const int X0 = blockIdx.x * T, Y0 = blockIdx.y * T;
+  double *cur = rp, *nxt = rp + nl * (T / 2) * (T / 2);
+  {
+    const int s = T >> 1;
+    for (int t = tid; t < s * s * nl; t += 256) {
+      const int I = t % s, J = (t / s) % s, l = t / (s * s);
+      const int fi = X0 + 2 * I, fj = Y0 + 2 * J;
+      double sum = 0.;
+      sum += a.fine[split_idx(a.g[0], l, fj, fi)];
+      sum += a.fine[split_idx(a.g[0], l, fj + 1, fi)];
+      sum += a.fine[split_idx(a.g[0], l, fj, fi + 1)];
+      sum += a.fine[split_idx(a.g[0], l, fj + 1, fi + 1)];
+      const double v = sum / 4;
+      cur[(l * s + J) * s + I] = v;
+      a.out[0][split_idx(a.g[1], l, (Y0 >> 1) + J, (X0 >> 1) + I)] = v;
+    }
+  }
+  for (int k = 2; k <= n; k++) {
+    __syncthreads();
+    const int s = T >> k, sf = s << 1;
+    for (int t = tid; t < s * s * nl; t += 256) {
+      const int I = t % s, J = (t / s) % s, l = t / (s * s);
+      const double *f = cur + l * sf * sf;
+      double sum = 0.;
+      sum += f[(2 * J) * sf + 2 * I];
+      sum += f[(2 * J + 1) * sf + 2 * I];
+      sum += f[(2 * J) * sf + 2 * I + 1];
+      sum += f[(2 * J + 1) * sf + 2 * I + 1];
+      const double v = sum / 4;
+      nxt[(l * s + J) * s + I] = v;
+      a.out[k - 1][split_idx(a.g[k], l, (Y0 >> k) + J, (X0 >> k) + I)] = v;
+    }
+    double *tmp = cur; cur = nxt; nxt = tmp;
+  }
+}
+// levels[0] -> levels[1 .. n] (n <= RPYR_MAX); every level must halve exactly (cell-centred grids do)
+void launch_restrict_pyramid(hipStream_t st, const double *fine, double *const *out, const SplitGeom *g, int n, int nl) {
+  RestrictPyramidArgs a;
+  a.fine = fine; a.n = n; a.nl = nl;
+  for (int k = 0; k <= n; k++) a.g[k] = g[k];
+  for (int k = 0; k < n; k++) a.out[k] = out[k];
+  const int T = 1 << n;
+  const size_t lds = (size_t)nl * ((T / 2) * (T / 2) + (T / 4 > 0 ? (T / 4) * (T / 4) : 1)) * sizeof(double);
+  hipLaunchKernelGGL(k_restrict_pyramid, dim3(g[0].nx / T, g[0].ny / T), dim3(256), lds, st, a);
+}
+
 // bilinear: (9 c + 3 (c[child.x] + c[0,child.y]) + c[child.x,child.y]) / 16, then
 // boundary_level(da) on the fine level (ghosts written by the wall threads)
 __device__ __forceinline__ void prolong_pt(const double *__restrict__ coarse, const SplitGeom &cg, double *fine, const SplitGeom &fg, int nl, int walls, int i, int j) {

@@ -125,6 +125,7 @@ struct msom {
   int stochastic = 0, corrector_step = 0, noise_mode = 0, stoch_fused = 1;
   int prolong_fused = 1;  // first red half-sweep of a level interpolates its neighbours from the coarser level
   int block_sweeps = 0;  // experimental temporally blocked smoother (2 sweeps per pass); measured not faster at nl = 6
+  int restrict_pyr = 1;  // round 3: the restriction chain below that in launches of up to 5 levels (k_restrict_pyramid)
   int restrict2 = 1;     // round 3: the pre-cycle residual pass restricts two levels down (k_residual2, res_c2)
   int block8 = 1;        // round 3: prolongation + up to 8 half-sweeps of a launch-bound level in one launch (k_relax_block, halo 8)
   int block8_max = 1024; // ... on levels of at most this many cells a side (and not marched)
@@ -719,6 +720,7 @@ extern "C" int msom_set_option(msom_t *m, const char *key, double v) {
   else if (!strcmp(key, "block_small")) m->block_small = (int)v;
   else if (!strcmp(key, "block8")) m->block8 = (int)v;
   else if (!strcmp(key, "restrict2")) m->restrict2 = (int)v;
+  else if (!strcmp(key, "restrict_pyr")) m->restrict_pyr = (int)v;
   else if (!strcmp(key, "block8_max")) m->block8_max = (int)v;
   else if (!strcmp(key, "block_sweeps")) { m->block_sweeps = (int)v; if (m->const_set) return build_coefs(m); }
   else if (!strcmp(key, "mg_global_sum")) m->mg_global_sum = (int)v;
@@ -1395,7 +1397,29 @@ static void mg_cycle_levels(msom *m, int nrelax, int first_restrict) {
   const bool glob = kc < m->nlev;
   // tile levels: restrict down to the gather level / to the finest level of the one-launch group
   const int rmax = glob ? kc : (kg >= 0 ? kg : m->nlev - 1);
-  for (int k = first_restrict; k < m->nlev && k <= rmax; k++) launch_restrict(m->st, m->res[k - 1], m->sg[k - 1], m->res[k], m->sg[k], nl);
+  {
+    // the chain in launches of up to 5 levels each (k_restrict_pyramid, round 3) where a tile of 2^n cells a side of the chain's finest
+    // level exists on every level down; a single restriction keeps its own kernel
+    int k = first_restrict;
+    const int kend = rmax < m->nlev - 1 ? rmax : m->nlev - 1;
+    while (k <= kend) {
+      int n = kend - k + 1;
+      if (n > 5) n = 5;
+      const SplitGeom &fg = m->sg[k - 1];
+      while (n > 1 && (fg.nx % (1 << n) || fg.ny % (1 << n))) n--;
+      if (n >= 2 && m->restrict_pyr) {
+        SplitGeom g[6];
+        double *out[5];
+        for (int q = 0; q <= n; q++) g[q] = m->sg[k - 1 + q];
+        for (int q = 0; q < n; q++) out[q] = m->res[k + q];
+        launch_restrict_pyramid(m->st, m->res[k - 1], out, g, n, nl);
+      } else {
+        n = 1;
+        launch_restrict(m->st, m->res[k - 1], m->sg[k - 1], m->res[k], m->sg[k], nl);
+      }
+      k += n;
+    }
+  }
   if (glob) {
     // gather the level-kc residual of all tiles, restrict it further on the global grid
     const SplitGeom &tg = m->sg[kc];

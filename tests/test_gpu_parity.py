@@ -865,3 +865,25 @@ def test_lean_coarse_kernel_equals_per_kernel_path(nx, ny, nl, extra, strict):
             assert np.array_equal(out[0][0], out[opt][0]) and np.array_equal(out[0][1], out[opt][1]) and out[0][2] == out[opt][2], opt
         else:
             assert rel(out[opt][0], out[0][0]) <= 1e-10 and out[0][2][0] == out[opt][2][0], opt
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nx,ny,nl,coarse", [(256, 256, 3, 4), (1024, 128, 2, 4), (128, 512, 6, 4), (512, 512, 1, 4), (256, 256, 4, 0), (2048, 64, 3, 0)])
+def test_restriction_chain_in_one_launch(nx, ny, nl, coarse, strict):
+    """option restrict_pyr (default on, round 3): the restrictions below the level the residual pass reaches in launches of up to five levels
+    (k_restrict_pyramid: a tile of 2^n x 2^n cells and its means on n levels through LDS) against one launch per level; with the one-launch
+    coarse group (mg_coarse = 4: the chain ends at 32 cells a side) and without (mg_coarse = 0: down to the coarsest level, two pyramid
+    launches on the larger grids); bit for bit in both builds"""
+    txt = orc.double_gyre_params(nx, nl, extra=(f"Ny = {ny}\n" if ny != nx else ""))
+    out = []
+    for on in (1, 0):
+        g = QG(txt, strict=strict)
+        g.option("quiet", 1); g.option("TOLERANCE", 1e-9); g.option("restrict_pyr", on); g.option("mg_coarse", coarse)
+        g.set(F["PSI"], orc.synthetic_psi(nl, ny, nx)); g.set_const()
+        for _ in range(2):
+            g.step()
+        st = g.mgstats()
+        out.append((g.get(F["PSI"]), g.get(F["Q"]), (st.i, st.resb, st.resa, st.nrelax)))
+        g.close()
+    assert out[0][2] == out[1][2]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
