@@ -419,7 +419,12 @@ static int comp_q(msomn *m, const double *psi, double *q) {
 
 // second psi buffer of the out-of-place passes (k_n_rhs_pre, k_n_correct_residual): the pad cells around the grid are written by
 // no kernel and no upload, they are zero in both
-static int need_psi_alt(msomn *m) { return m->psi_alt ? MSOM_OK : dalloc(&m->psi_alt, m->g.ls * m->nl); }
+static int need_psi_alt(msomn *m) {
+  if (m->psi_alt) return MSOM_OK;
+  HIPCHK(hipMalloc((void **)&m->psi_alt, m->g.ls * m->nl * sizeof(double)));
+  HIPCHK(hipMemsetAsync(m->psi_alt, 0, m->g.ls * m->nl * sizeof(double), m->st));   // in the stream of the kernels that follow
+  return MSOM_OK;
+}
 // rhs_pv_baroclinic qg_baroclinic_ms.h:104-196 / rhs_pv_barotropic qg_barotropic.h:16-29
 static int rhs_pv_body(msomn *m, double *q, double *dq);
 static int rhs_pv(msomn *m, double *q, double *dq) {
