@@ -106,7 +106,7 @@ int msom_destroy(msom_t *m);
  * into the first pass, "march_dma" [2] memory side of the pass (0: register-window loads, 1: LDS-DMA prefetch with one strip per
  * workgroup, 2: four strips per workgroup marching in step; PROCESS-WIDE tuning knob like march_rows / march_xcd / march_flip /
  * march_dbg / rhs_dbg / block_variant, which are globals of the library rather than fields of the handle), "graph" [0] replay the launches of a multigrid cycle from a captured hipGraph on the launch-bound grids
- * (measured neutral), "march_partial" [1], "march_correct" [1] correction folded into the last pass, "march_xcd" [1] XCD-contiguous block numbering, "march_flip" [1] odd chunks march downwards, "block_sweeps" [0] LDS-tiled blocked smoother (2 sweeps per launch, every level), "restrict2" [1] the pre-cycle residual pass restricts two levels down, "restrict_pyr" [1] the rest of the restriction chain in launches of up to five levels, "step_sync" [1] (see msom_sync), "block8" [1] / "block8_max" [1024] round 3: prolongation + up to 8 half-sweeps of a
+ * (measured neutral), "march_partial" [1], "march_correct" [1] correction folded into the last pass, "march_xcd" [1] XCD-contiguous block numbering, "march_flip" [1] odd chunks march downwards, "block_sweeps" [0] LDS-tiled blocked smoother (2 sweeps per launch, every level), "restrict2" [1] the pre-cycle residual pass restricts two levels down, "restrict_pyr" [1] the rest of the restriction chain in launches of up to five levels, "step_sync" [-1] (see msom_sync), "block8" [1] / "block8_max" [1024] round 3: prolongation + up to 8 half-sweeps of a
  * visit of a launch-bound level (64 .. block8_max cells a side, not marched; one GPU, walls or doubly periodic, nl <= 8; uniform or general S) in one launch of that kernel with a halo of 8, "agglomerate" [1] / "agg_size" [256]
  * gathered coarse levels of tiled runs, "mg_global_sum" [0]; "rhs_dbg", "block_variant": timing
  * experiments of tools/. */
@@ -233,9 +233,9 @@ int msom_dbg_op(msom_t *m, const char *op, int f_in, int f_out, double add, doub
  * and a back-to-back kernel microbenchmark outside any step */
 int msom_profile_read(msom_t *m, const char *kernel, double *avg_ms, long *launches);
 int msom_profile_reset(msom_t *m);
-/* waits for everything the handle has queued on its stream.  With option "step_sync" = 0 [default 1] and "async_solve", msom_step returns
- * while its last tendency pass is still running; every call that returns device data to the host synchronises by itself, so this
- * is for timing and for callers that share the device pointers of the fields with their own streams. */
+/* waits for everything the handle has queued on its stream.  With option "step_sync" = 0 (default -1: on grids below 2^23 cell-layers;
+ * 1: never) and "async_solve", msom_step returns while its last tendency pass is still running; every call that returns device data
+ * to the host synchronises by itself, so this is for timing and for callers that share the fields' device pointers with their own streams. */
 int msom_sync(msom_t *m);
 int msom_bench_kernel(msom_t *m, const char *kernel, int reps, double *avg_ms);
 /* one-rank RCCL communicator on the current device: grouped send/recv to self, all-reduce and

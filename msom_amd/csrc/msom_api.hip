@@ -67,8 +67,9 @@ struct msom {
   // altogether, tools/ab_nosync.py).  If the solve turns out to need another cycle the pass is simply run again afterwards:
   // its output went to the predictor (stage 1) or to a spare buffer that only replaces q when the solve had converged (stage 2).
   int async_solve = 1;               // option
-  int step_sync = 1;                 // option: 0 = msom_step returns without waiting for its last tendency pass (async_solve only); measured: 512^2 x 3
-                                     // 0.394 -> 0.378 ms per step, 2048^2 x 3 and 4096^2 x 6 unchanged -- off
+  int step_sync = -1;                // option: 0 = msom_step returns without waiting for its last tendency pass (async_solve only), 1 = it waits,
+                                     // -1 (default) = it waits on grids of >= 2^23 cell-layers.  Measured (same process): 128^2 x 1 0.203 -> 0.185 ms per
+                                     // step, 512^2 x 3 0.374 -> 0.352, 2048^2 x 3 1.238 -> 1.226, 4096^2 x 6 6.15 -> 6.20 (worse)
   std::function<void(const std::function<void()> &)> spec_hook;   // queued by mg_solve after the first cycle's residual pass; calls its
                                      // argument (the host's read of the scalars) between the dt kernel and the tendency pass
   int spec_launched = 0, spec_valid = 0;
@@ -2137,7 +2138,8 @@ extern "C" int msom_step(msom_t *m, double *dt_used) {
   // With the speculative tendency pass the host already follows the GPU solve by solve (it waits for the published residual of every
   // solve) and everything it returns -- dt, t -- is known: with step_sync = 0 the last tendency pass is left running and the next step's
   // launches queue up behind it (every call that hands device data to the host synchronises the stream itself, msom_sync on request)
-  if (!spec || m->step_sync) { if ((r = sync_stream(m))) return r; }
+  const bool lazy = m->step_sync == 0 || (m->step_sync < 0 && (size_t)m->g.nx * m->g.ny * m->nl < ((size_t)1 << 23));
+  if (!spec || !lazy) { if ((r = sync_stream(m))) return r; }
   else if (m->sticky) return m->sticky;
   m->t = tnext;
   m->iter++;
