@@ -283,7 +283,8 @@ void msomn_destroy(msomn_t *m);                                 /* trash_vars qg
  * the strict build): node_split [65] levels of >= that many vertices a side keep correction / residual / mask / S2 copies in the
  * x-parity split layout (0: off), s2_rows [1] row tables for an S2 that does not depend on x, node_pfused [1] prolongation folded into the first colour pass of the split levels, mg_coarse [32] levels of at most that
  * many cells a side in one launch, tiled_relax [0], node_march [0] (measured slower, kept for the tests); round 3: node_march_s [2049] split
- * levels of >= that many vertices a side chain up to 4 colour half-sweeps per pass, node_tile_s [65] / node_tile_max [513] / node_tile_k [8]
+ * levels of >= that many vertices a side chain up to 4 colour half-sweeps per pass (node_march_tail1 [1]: 9 half-sweeps as 4 + 4 + a colour
+ * launch, 0: 4 + 3 + 2), node_tile_s [65] / node_tile_max [513] / node_tile_k [8]
  * the split levels between those sizes run up to node_tile_k colour half-sweeps per LDS-tiled launch (nl <= 4), node_rhs_fused [1] the
  * baroclinic tendency in three passes instead of the twelve loops of the reference, node_corr_fused [2] the correction of a cycle applied
  * inside the residual pass of the next (2: rows marched, 1: one thread per vertex, 0: separate passes), profile [0] */
