@@ -19,7 +19,7 @@ f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 N, nl = 4096, 6
 wb = 8.0 * N * N * nl
 alg = {"k_relax_color_x2<6, true, true>": 1.5, "k_rhs_fused_pipe<32, 512, false>": 3.0, "k_correct_residual<true, true>": 4.0,
-       "k_residual2<false, true, true, false>": 3.25, "k_relax_red_prolong3<6, true>": 1.25, "k_relax_march<6, 4, false, false>": 2.5, "k_relax_march<6, 3, false, false>": 2.5, "k_rhs_lpw<4, true, false, true>": 3.0, "k_rhs_lpw<4, true, false, true, false>": 3.0, "k_resmax_march<6>": 2.0,
+       "k_residual2<false, true, true, false>": 3.25 + 1.0 / 16.0, "k_relax_red_prolong3<6, true>": 1.25, "k_relax_march<6, 4, false, false>": 2.5, "k_relax_march<6, 3, false, false>": 2.5, "k_rhs_lpw<4, true, false, true>": 3.0, "k_rhs_lpw<4, true, false, true, false>": 3.0, "k_resmax_march<6>": 2.0,
        "k_relax_march_dma<6, 4, 2, 4, false>": 2.5, "k_relax_march_dma<6, 4, 4, 1, true>": 2.25, "k_relax_march_dma<6, 4, 2, 1, false>": 2.5,
        "k_relax_march_dma<6, 4, 4, 1, true, false>": 1.75, "k_relax_march_dma<6, 4, 2, 4, false, true>": 3.5, "k_relax_march_dma<6, 4, 2, 4, false, false>": 2.5,
        "k_correct_residual<true, false>": 2.0}
