@@ -9,6 +9,7 @@ overridden, synthetic seed-free initial stream function, fp64):
   C4 (default)  4096 x 4096 x 6   -- the configuration the metric is quoted on; fits one MI355X (14 of 288 GB)
   C3            2048 x 2048 x 3
   C2             512 x  512 x 3
+  C1             128 x  128 x 1   -- BASELINE configs[0]: the 1-layer barotropic double gyre the CPU reference runs
   C5            2048 x 2048 x 3, stochastic variant (msqg/qg_stochastic.h; noise from the device Philox generator)
 N = 1: the whole grid on one GPU.  N > 1 (one process per GPU, RCCL): by default WEAK scaling -- every rank owns one
 tile of the configuration's N = 1 size (`--tile NXxNY` overrides it), the domain grows with the tile grid and the
@@ -48,6 +49,7 @@ def kernel_source_sha1():
 
 
 CONFIGS = {
+    "C1": dict(N=128, nl=1, stochastic=False),
     "C2": dict(N=512, nl=3, stochastic=False),
     "C3": dict(N=2048, nl=3, stochastic=False),
     "C4": dict(N=4096, nl=6, stochastic=False),
@@ -449,7 +451,7 @@ def main():
         if world == 1 and args.config == "C4" and not args.tile:
             # the other BASELINE configurations on one GPU, short legs (their kernels are timed the same way)
             # (a leg that fails is recorded as such: the headline line must still be printed)
-            for name in ("C2", "C3", "C5"):
+            for name in ("C1", "C2", "C3", "C5"):
                 c = CONFIGS[name]
                 try:
                     lg = Leg(c["N"], c["N"], c["nl"], 1, 1, 0, None, c["N"], stochastic=c["stochastic"], local_rank=local_rank)
